@@ -1,0 +1,139 @@
+/*
+ * s2vt.h -- C ABI of libs2vt_hip.so: the MI355X-native S2VT REINFORCE hot path.
+ *
+ * The reference (adwardlee/multitask-end-to-end-video-captioning) has no FFI layer: its boundary
+ * is the Python class Video_Caption_Generator whose build_* methods emit TensorFlow-1.1 graph ops
+ * (tf_s2vt.py:53-266, reinforcement_multisampling_tf_s2vt.py:63-466).  Each entry point below
+ * replaces the TF ops of one stretch of those graphs; the reference lines are cited per function.
+ * INTEGRATION.md shows the ctypes binding and how Video_Caption_Generator.build_* map onto it.
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, POD structs.  No torch / TF types.  All tensors are row-major
+ *     fp32 (token ids int32), DEVICE pointers owned by the caller; the library allocates nothing
+ *     on the device -- scratch comes from a caller-provided workspace (query *_workspace_bytes).
+ *   - Every call takes a hipStream_t (as void*) and is asynchronous w.r.t. the host; no hidden
+ *     synchronisation.  A handle-free API: all state is in the arguments.
+ *   - Return value: 0 = S2VT_OK, < 0 = S2VT_E_*.  Never throws, never exits.  After
+ *     S2VT_E_HIP, s2vt_last_hip_error() holds the hipError_t.
+ *   - Numeric contract: forward contractions are ascending-k fp32 fmaf chains on
+ *     v_mfma_f32_16x16x4_f32, transcendental functions are fixed instruction sequences, sampling
+ *     is Gumbel-max over Philox4x32-10 -- forward activations, logits and token ids are
+ *     bit-identical to oracle/s2vt_oracle.c.  Gradients / reductions are order-free fp32.
+ */
+#ifndef S2VT_H
+#define S2VT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2VT_OK 0
+#define S2VT_E_BADARG (-1)   /* null pointer, non-positive size, inconsistent dims */
+#define S2VT_E_ALIGN (-2)    /* workspace not 256-byte aligned */
+#define S2VT_E_WORKSPACE (-3)/* workspace too small */
+#define S2VT_E_HIP (-4)      /* a HIP call failed: see s2vt_last_hip_error() */
+
+typedef void* s2vt_stream;   /* hipStream_t */
+
+/* Model dimensions: the constructor arguments of Video_Caption_Generator (tf_s2vt.py:54-66). */
+typedef struct s2vt_dims {
+    int32_t dim_image;            /* d   = 1536 */
+    int32_t n_words;              /* |V|        */
+    int32_t word_dim;             /* E   = 500  */
+    int32_t lstm_dim;             /* H   = 1000 */
+    int32_t n_video_lstm_step;    /* Tv  = 5    */
+    int32_t n_caption_lstm_step;  /* Tc  = 20 (35 in the reference files) */
+    int32_t label_dim;            /* A   = 400 attributes (multitask head), 0 if absent */
+    int32_t reserved;
+} s2vt_dims;
+
+/* Trainable variables (tf_s2vt.py:68-88; LSTM kernels are created lazily by BasicLSTMCell under
+ * s2vt/LSTM{1,2}/basic_lstm_cell/{weights,biases}).  The same struct carries gradients. */
+typedef struct s2vt_params {
+    float* Wemb;            /* [V, E]                                                    */
+    float* encode_image_W;  /* [d, E]                                                    */
+    float* encode_image_b;  /* [E]                                                       */
+    float* lstm1_W;         /* [E + H, 4H]   rows [x ; h], columns [i | j | f | o]       */
+    float* lstm1_b;         /* [4H]                                                      */
+    float* lstm2_W;         /* [H + E + H, 4H] rows [out1 ; embed ; h2]                  */
+    float* lstm2_b;         /* [4H]                                                      */
+    float* embed_word_W;    /* [H, V]                                                    */
+    float* embed_word_b;    /* [V]                                                       */
+    float* attr_W;          /* [d, A] or NULL (reinforce_multitask_e2e_attribute_loss.py:112-114) */
+    float* attr_b;          /* [A]    or NULL                                            */
+} s2vt_params;
+
+/* ---- library info / errors --------------------------------------------------------------- */
+int s2vt_version(void);
+int s2vt_last_hip_error(void);
+const char* s2vt_error_string(int code);
+
+/* ---- test hook: evaluate the contract's scalar functions on the device --------------------
+ * fn: 0 exp, 1 log, 2 tanh, 3 sigmoid.  y[i] = fn(x[i]).  (Bitwise comparison with the oracle.) */
+int s2vt_math_eval(int fn, const float* x, float* y, int64_t n, s2vt_stream stream);
+/* Gumbel noise words of the sampler stream for (video, sample, step), columns [0, V). */
+int s2vt_gumbel_eval(uint64_t seed, int32_t video, int32_t sample, int32_t step, float* out, int32_t V,
+                     s2vt_stream stream);
+
+/* ---- tf.nn.xw_plus_b / tf.matmul over a concatenated operand -------------------------------
+ * C[m, :] = act( chain over [A0[r0(m)] ; A1[r1(m)] ; A2[r2(m)]] @ W  (+ bias) ), the chain
+ * optionally continuing from Cinit.  Replaces tf.nn.xw_plus_b (tf_s2vt.py:98,153) and the
+ * tf.concat + matmul inside BasicLSTMCell.  A segment with ptr == NULL is an all-zero input
+ * (the reference's `padding`) and is skipped; rowidx gathers rows (tf.nn.embedding_lookup). */
+typedef struct s2vt_operand {
+    const float* ptr;       /* [rows, ld] */
+    const int32_t* rowidx;  /* optional [M] */
+    int32_t ld;
+    int32_t k;              /* columns of this segment = rows of W it multiplies */
+    int32_t rowmod;         /* > 0: row(m) = m % rowmod before rowidx */
+    int32_t reserved;
+} s2vt_operand;
+
+int s2vt_gemm(const s2vt_operand* segs, int32_t nseg, const float* W, int32_t ldw, const float* bias,
+              const float* Cinit, int32_t ldcinit, float* C, int32_t ldc, int32_t M, int32_t N, int32_t act_tanh,
+              int32_t tile_cfg, s2vt_stream stream);
+
+/* ---- BasicLSTMCell + DropoutWrapper, one call (tf_s2vt.py:74-77,119-143) --------------------
+ * z = [x0 ; x1 ; h_prev] @ W + b ; i,j,f,o = split(z) ; c' = c*sig(f+1) + sig(i)*tanh(j) ;
+ * h' = tanh(c')*sig(o) ; out = keep<1 ? (h'/keep)*mask : h'  (mask from the dropout Philox
+ * stream, keyed by video_id/sample_id/drop_code).  W rows are consumed in the order x0, x1, h.
+ * x0/x1 may be NULL (zero input) -- their rows of W are skipped, h_prev multiplies the LAST H rows.
+ * gates (optional, [M,4H]) receives sig(i) | tanh(j) | sig(f+1) | sig(o) for the backward pass. */
+int s2vt_lstm_cell_fwd(const s2vt_operand* x0, const s2vt_operand* x1, const float* h_prev, const float* c_prev,
+                       int32_t state_rowmod, const float* W, const float* b, float* c_new, float* h_new, float* out,
+                       float* gates, int32_t M, int32_t H, float keep, uint64_t seed, const int32_t* video_id,
+                       const int32_t* sample_id, uint32_t drop_code, int32_t tile_cfg, s2vt_stream stream);
+
+/* ---- vocab logits + token pick, one decode step ---------------------------------------------
+ * logits = out2 @ embed_word_W + embed_word_b (tf_s2vt.py:153); token = tf.argmax(logits,1) for
+ * rows with sample_id < 0 (tf_s2vt.py:262) or one draw of tf.multinomial(log_softmax(logits),1)
+ * (reinforcement_multisampling_tf_s2vt.py:333-336) as Gumbel-max otherwise.  The logits stay
+ * on chip unless logits_out != NULL.  packed[m] must be zero on entry; on exit it holds
+ * (orderable(key) << 32) | ~token.  tokens_out (optional) receives the int32 ids. */
+int s2vt_vocab_pick(const float* out2, int32_t ld, const float* W, const float* b, int32_t M, int32_t H, int32_t V,
+                    const int32_t* video_id, const int32_t* sample_id, int32_t step, uint64_t seed,
+                    unsigned long long* packed, int32_t* tokens_out, float* logits_out, int32_t tile_cfg,
+                    s2vt_stream stream);
+
+/* ---- frame embedding (tf_s2vt.py:97-101): emb[B*Tv, E] = video[B*Tv, d] @ encode_image_W + b */
+int s2vt_frame_embed_fwd(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, float* emb,
+                         s2vt_stream stream);
+
+/* ---- samplers: build_multinomial_sampler x K + build_sampler, one call ------------------------
+ * (reinforcement_multisampling_tf_s2vt.py:294-391, driven at :743-753).  Frame embed + encode once,
+ * then Tc decode steps for K sampled rows-blocks (+ one greedy block when with_greedy) entirely
+ * on the device: no host round trip per step.  Rows are sample-major (row k*B + j = sample k of
+ * video j, :764-782), the greedy block last.  ids_out: int32 [(K + with_greedy) * B, Tc].
+ * Noise: Philox stream (seed; video = video_base + j; sample = k; step). */
+size_t s2vt_sample_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t K, int32_t with_greedy);
+int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t K,
+                int32_t with_greedy, uint64_t seed, int32_t video_base, int32_t* ids_out, void* workspace,
+                size_t workspace_bytes, s2vt_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2VT_H */

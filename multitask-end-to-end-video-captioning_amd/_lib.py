@@ -1,0 +1,87 @@
+"""ctypes binding of libs2vt_hip.so (include/s2vt.h).  There is NO fallback: if the library is not
+built, or a call fails, this raises -- the product path never routes through a CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class S2VTLibraryError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim_image", "n_words", "word_dim", "lstm_dim", "n_video_lstm_step",
+                                         "n_caption_lstm_step", "label_dim", "reserved")]
+
+
+PARAM_FIELDS = ("Wemb", "encode_image_W", "encode_image_b", "lstm1_W", "lstm1_b", "lstm2_W", "lstm2_b", "embed_word_W",
+                "embed_word_b", "attr_W", "attr_b")
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
+
+
+class Operand(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_int32), ("k", C.c_int32), ("rowmod", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libs2vt_hip.so")
+
+
+_vp, _i32, _i64, _u32, _u64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
+_DP, _PP, _OP = C.POINTER(Dims), C.POINTER(Params), C.POINTER(Operand)
+
+# name -> (restype, argtypes); every symbol include/s2vt.h declares
+SIGNATURES = {
+    "s2vt_version": (C.c_int, []),
+    "s2vt_last_hip_error": (C.c_int, []),
+    "s2vt_error_string": (C.c_char_p, [C.c_int]),
+    "s2vt_math_eval": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp]),
+    "s2vt_gumbel_eval": (C.c_int, [_u64, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "s2vt_gemm": (C.c_int, [_OP, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "s2vt_lstm_cell_fwd": (C.c_int, [_OP, _OP, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _u64, _vp,
+                                     _vp, _u32, _i32, _vp]),
+    "s2vt_vocab_pick": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _u64, _vp, _vp, _vp, _i32, _vp]),
+    "s2vt_frame_embed_fwd": (C.c_int, [_DP, _PP, _vp, _i32, _vp, _vp]),
+    "s2vt_sample_workspace_bytes": (_sz, [_DP, _i32, _i32, _i32]),
+    "s2vt_sample": (C.c_int, [_DP, _PP, _vp, _i32, _i32, _i32, _u64, _i32, _vp, _vp, _sz, _vp]),
+}
+
+
+def lib():
+    """Load libs2vt_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if absent."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise S2VTLibraryError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        try:
+            L = C.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise S2VTLibraryError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise S2VTLibraryError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, what: str = "s2vt call"):
+    if rc != 0:
+        L = lib()
+        msg = L.s2vt_error_string(rc).decode()
+        extra = f" hipError={L.s2vt_last_hip_error()}" if rc == -4 else ""
+        raise S2VTLibraryError(f"{what} failed: {msg} (code {rc}){extra}")

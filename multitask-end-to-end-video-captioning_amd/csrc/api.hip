@@ -1,0 +1,379 @@
+// api.hip -- extern "C" boundary of libs2vt_hip.so (declared in include/s2vt.h) and the on-device
+// drivers of the sampler loops.  Everything here is host code + a few trivial helper kernels; the
+// contraction kernels live in gemm_mfma.h / fwd.hip.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstring>
+
+#include "../../include/s2vt.h"
+#include "internal.h"
+
+using namespace s2vt;
+
+namespace {
+
+std::atomic<int> g_last_hip{0};
+
+int hip_fail(hipError_t e)
+{
+    g_last_hip.store((int)e);
+    return S2VT_E_HIP;
+}
+
+#define HIP_TRY(expr)                               \
+    do {                                            \
+        hipError_t _e = (expr);                     \
+        if (_e != hipSuccess) return hip_fail(_e);  \
+    } while (0)
+
+inline hipStream_t S(s2vt_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// bump allocator over the caller's workspace (256-byte granules)
+struct Carver {
+    char* base;
+    size_t off = 0, cap;
+    Carver(void* p, size_t bytes) : base(static_cast<char*>(p)), cap(bytes) {}
+    template <typename T>
+    T* take(size_t n)
+    {
+        const size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+__global__ void math_eval_kernel(int fn, const float* x, float* y, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    y[i] = fn == 0 ? dm_expf(v) : fn == 1 ? dm_logf(v) : fn == 2 ? dm_tanhf(v) : dm_sigmoidf(v);
+}
+
+__global__ void gumbel_eval_kernel(uint32_t lo, uint32_t hi, uint32_t video, uint32_t sample, uint32_t step, float* out,
+                                   int V)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < V) out[n] = gumbel_at(lo, hi, video, sample, step, (uint32_t)n);
+}
+
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// row ids of the sampler: row r = k*B + j -> video video_base + j, sample k (greedy block: -1)
+__global__ void sampler_rows_kernel(int32_t* vid, int32_t* sid, int B, int K, int R, int video_base)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    vid[i] = video_base + i % B;
+    sid[i] = (i / B) < K ? i / B : -1;
+}
+
+// packed [T][R] -> ids [R][T]
+__global__ void unpack_ids_kernel(const unsigned long long* packed, int32_t* ids, int R, int T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * T) return;
+    const int m = i / T, t = i % T;
+    ids[i] = (int32_t)(~(uint32_t)packed[(size_t)t * R + m]);
+}
+
+void seg_from_operand(ASeg& s, const s2vt_operand* o, int kw)
+{
+    std::memset(&s, 0, sizeof(s));
+    if (!o) return;
+    s.ptr = o->ptr;
+    s.rowidx = o->rowidx;
+    s.ld = o->ld;
+    s.k = o->k;
+    s.kw = kw;
+    s.rowmod = o->rowmod;
+}
+
+ASeg make_seg(const float* ptr, int ld, int k, int kw, int rowmod = 0, const int* rowidx = nullptr,
+              const unsigned long long* rowkey = nullptr)
+{
+    ASeg s;
+    std::memset(&s, 0, sizeof(s));
+    s.ptr = ptr; s.ld = ld; s.k = k; s.kw = kw; s.rowmod = rowmod; s.rowidx = rowidx; s.rowkey = rowkey;
+    return s;
+}
+
+struct NoiseIds {
+    const int32_t* video_id;
+    const int32_t* sample_id;
+    uint64_t seed;
+};
+
+// One BasicLSTMCell call.  segs/nseg describe [x0 ; x1 ; h_prev] with their W row offsets.
+hipError_t lstm_call(const ASeg* segs, int nseg, const float* W, const float* b, const float* c_prev, int cprev_rowmod,
+                     float* c_new, float* h_new, float* out, float* gates, int M, int H, float keep, const NoiseIds& ids,
+                     uint32_t drop_code, int cfg, hipStream_t st)
+{
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
+    a.nseg = nseg;
+    a.W = W; a.ldw = 4 * H; a.M = M; a.N = H; a.gstride = H; a.bias = b;
+    a.c_prev = c_prev; a.cprev_rowmod = cprev_rowmod; a.c_new = c_new; a.h_new = h_new; a.out = out; a.gates = gates;
+    a.keep = keep; a.drop_code = drop_code;
+    a.video_id = ids.video_id; a.sample_id = ids.sample_id;
+    a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32);
+    return launch_gemm(a, EPI_LSTM, cfg, st);
+}
+
+hipError_t pick_call(const float* A, int lda, const float* W, const float* b, int M, int H, int V, const NoiseIds& ids,
+                     int step, unsigned long long* packed, float* logits_out, int cfg, hipStream_t st)
+{
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.seg[0] = make_seg(A, lda, H, 0);
+    a.nseg = 1;
+    a.W = W; a.ldw = V; a.M = M; a.N = V; a.gstride = 0; a.bias = b;
+    a.video_id = ids.video_id; a.sample_id = ids.sample_id;
+    a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32);
+    a.step = step; a.pick = packed; a.logits_out = logits_out; a.ldc = V;
+    return launch_gemm(a, EPI_PICK, cfg, st);
+}
+
+hipError_t store_call(const ASeg* segs, int nseg, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+                      int N, int act, int cfg, hipStream_t st, const float* cinit = nullptr, int ldcinit = 0)
+{
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
+    a.nseg = nseg;
+    a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.gstride = 0; a.bias = bias;
+    a.cinit = cinit; a.ldcinit = ldcinit;
+    a.C = C; a.ldc = ldc; a.act = act;
+    return launch_gemm(a, EPI_STORE, cfg, st);
+}
+
+bool dims_ok(const s2vt_dims* d)
+{
+    return d && d->dim_image > 0 && d->n_words > 0 && d->word_dim > 0 && d->lstm_dim > 0 && d->n_video_lstm_step > 0 &&
+           d->n_caption_lstm_step > 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2vt_version(void) { return 100; }
+int s2vt_last_hip_error(void) { return g_last_hip.load(); }
+
+const char* s2vt_error_string(int code)
+{
+    switch (code) {
+        case S2VT_OK: return "ok";
+        case S2VT_E_BADARG: return "bad argument";
+        case S2VT_E_ALIGN: return "workspace not 256-byte aligned";
+        case S2VT_E_WORKSPACE: return "workspace too small";
+        case S2VT_E_HIP: return "HIP error (see s2vt_last_hip_error)";
+        default: return "unknown error";
+    }
+}
+
+int s2vt_math_eval(int fn, const float* x, float* y, int64_t n, s2vt_stream stream)
+{
+    if (!x || !y || n < 0 || fn < 0 || fn > 3) return S2VT_E_BADARG;
+    if (n == 0) return S2VT_OK;
+    hipLaunchKernelGGL(math_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), fn, x, y, n);
+    HIP_TRY(hipGetLastError());
+    return S2VT_OK;
+}
+
+int s2vt_gumbel_eval(uint64_t seed, int32_t video, int32_t sample, int32_t step, float* out, int32_t V, s2vt_stream stream)
+{
+    if (!out || V <= 0) return S2VT_E_BADARG;
+    hipLaunchKernelGGL(gumbel_eval_kernel, dim3((V + 255) / 256), dim3(256), 0, S(stream), (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (uint32_t)video, (uint32_t)sample, (uint32_t)step, out, V);
+    HIP_TRY(hipGetLastError());
+    return S2VT_OK;
+}
+
+int s2vt_gemm(const s2vt_operand* segs, int32_t nseg, const float* W, int32_t ldw, const float* bias, const float* Cinit,
+              int32_t ldcinit, float* C, int32_t ldc, int32_t M, int32_t N, int32_t act_tanh, int32_t tile_cfg,
+              s2vt_stream stream)
+{
+    if (!segs || nseg < 1 || nseg > 3 || !W || !C || M < 0 || N <= 0 || ldw < N || ldc < N) return S2VT_E_BADARG;
+    if (Cinit && ldcinit < N) return S2VT_E_BADARG;
+    ASeg a[3];
+    int kw = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (segs[i].k < 0 || (segs[i].ptr && segs[i].ld < segs[i].k)) return S2VT_E_BADARG;
+        seg_from_operand(a[i], &segs[i], kw);
+        kw += segs[i].k;
+    }
+    if (M == 0) return S2VT_OK;
+    HIP_TRY(store_call(a, nseg, W, ldw, bias, C, ldc, M, N, act_tanh ? 1 : 0, tile_cfg, S(stream), Cinit, ldcinit));
+    return S2VT_OK;
+}
+
+int s2vt_lstm_cell_fwd(const s2vt_operand* x0, const s2vt_operand* x1, const float* h_prev, const float* c_prev,
+                       int32_t state_rowmod, const float* W, const float* b, float* c_new, float* h_new, float* out,
+                       float* gates, int32_t M, int32_t H, float keep, uint64_t seed, const int32_t* video_id,
+                       const int32_t* sample_id, uint32_t drop_code, int32_t tile_cfg, s2vt_stream stream)
+{
+    if (!h_prev || !c_prev || !W || !b || !c_new || !h_new || M < 0 || H <= 0) return S2VT_E_BADARG;
+    if (keep < 1.0f && (!video_id || !sample_id || !out || !(keep > 0.0f))) return S2VT_E_BADARG;
+    ASeg a[3];
+    int kw = 0, n = 0;
+    const s2vt_operand* xs[2] = {x0, x1};
+    for (int i = 0; i < 2; ++i) {
+        if (!xs[i]) continue;
+        if (xs[i]->k < 0 || (xs[i]->ptr && xs[i]->ld < xs[i]->k)) return S2VT_E_BADARG;
+        seg_from_operand(a[n++], xs[i], kw);
+        kw += xs[i]->k;
+    }
+    a[n++] = make_seg(h_prev, H, H, kw, state_rowmod);
+    if (M == 0) return S2VT_OK;
+    NoiseIds ids{video_id, sample_id, seed};
+    HIP_TRY(lstm_call(a, n, W, b, c_prev, state_rowmod, c_new, h_new, out, gates, M, H, keep, ids, drop_code, tile_cfg,
+                      S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_vocab_pick(const float* out2, int32_t ld, const float* W, const float* b, int32_t M, int32_t H, int32_t V,
+                    const int32_t* video_id, const int32_t* sample_id, int32_t step, uint64_t seed,
+                    unsigned long long* packed, int32_t* tokens_out, float* logits_out, int32_t tile_cfg,
+                    s2vt_stream stream)
+{
+    if (!out2 || !W || !b || !video_id || !sample_id || !packed || M < 0 || H <= 0 || V <= 0 || ld < H)
+        return S2VT_E_BADARG;
+    if (M == 0) return S2VT_OK;
+    NoiseIds ids{video_id, sample_id, seed};
+    HIP_TRY(pick_call(out2, ld, W, b, M, H, V, ids, step, packed, logits_out, tile_cfg, S(stream)));
+    if (tokens_out) {
+        hipLaunchKernelGGL(unpack_ids_kernel, dim3((M + 255) / 256), dim3(256), 0, S(stream), packed, tokens_out, M, 1);
+        HIP_TRY(hipGetLastError());
+    }
+    return S2VT_OK;
+}
+
+int s2vt_frame_embed_fwd(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, float* emb,
+                         s2vt_stream stream)
+{
+    if (!dims_ok(d) || !p || !p->encode_image_W || !p->encode_image_b || !video || !emb || B < 0) return S2VT_E_BADARG;
+    if (B == 0) return S2VT_OK;
+    ASeg a = make_seg(video, d->dim_image, d->dim_image, 0);
+    HIP_TRY(store_call(&a, 1, p->encode_image_W, d->word_dim, p->encode_image_b, emb, d->word_dim,
+                       B * d->n_video_lstm_step, d->word_dim, 0, -1, S(stream)));
+    return S2VT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// samplers
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct SampleWs {
+    float *emb, *c1[2], *h1[2], *c2e[2], *h2e[2], *c2[2], *h2[2];
+    unsigned long long* packed;
+    int32_t *vid, *sid, *bos, *vid_b, *sid_b;
+};
+
+size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
+{
+    const size_t H = d->lstm_dim, E = d->word_dim, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
+    SampleWs t;
+    t.emb = c.take<float>((size_t)B * Tv * E);
+    for (int i = 0; i < 2; ++i) {
+        t.c1[i] = c.take<float>((size_t)B * H); t.h1[i] = c.take<float>((size_t)B * H);
+        t.c2e[i] = c.take<float>((size_t)B * H); t.h2e[i] = c.take<float>((size_t)B * H);
+        t.c2[i] = c.take<float>((size_t)R * H); t.h2[i] = c.take<float>((size_t)R * H);
+    }
+    t.packed = c.take<unsigned long long>((size_t)Tc * R);
+    t.vid = c.take<int32_t>(R); t.sid = c.take<int32_t>(R); t.bos = c.take<int32_t>(R);
+    t.vid_b = c.take<int32_t>(B); t.sid_b = c.take<int32_t>(B);
+    if (w) *w = t;
+    return c.off;
+}
+}  // namespace
+
+size_t s2vt_sample_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t K, int32_t with_greedy)
+{
+    if (!dims_ok(d) || B <= 0 || K < 0) return 0;
+    Carver c(nullptr, 0);
+    return carve_sample(c, d, B, (K + (with_greedy ? 1 : 0)) * B, nullptr);
+}
+
+int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t K, int32_t with_greedy,
+                uint64_t seed, int32_t video_base, int32_t* ids_out, void* workspace, size_t workspace_bytes,
+                s2vt_stream stream)
+{
+    if (!dims_ok(d) || !p || !video || !ids_out || !workspace || B <= 0 || K < 0 || (K == 0 && !with_greedy))
+        return S2VT_E_BADARG;
+    if (!p->Wemb || !p->encode_image_W || !p->encode_image_b || !p->lstm1_W || !p->lstm1_b || !p->lstm2_W ||
+        !p->lstm2_b || !p->embed_word_W || !p->embed_word_b)
+        return S2VT_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
+    const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
+    const int R = (K + (with_greedy ? 1 : 0)) * B;
+    Carver c(workspace, workspace_bytes);
+    SampleWs w;
+    carve_sample(c, d, B, R, &w);
+    if (!c.ok()) return S2VT_E_WORKSPACE;
+    hipStream_t st = S(stream);
+
+    // zero initial states (tf_s2vt.py:105-107) and the packed pick words
+    HIP_TRY(hipMemsetAsync(w.c1[0], 0, (size_t)B * H * 4, st));
+    HIP_TRY(hipMemsetAsync(w.h1[0], 0, (size_t)B * H * 4, st));
+    HIP_TRY(hipMemsetAsync(w.c2e[0], 0, (size_t)B * H * 4, st));
+    HIP_TRY(hipMemsetAsync(w.h2e[0], 0, (size_t)B * H * 4, st));
+    HIP_TRY(hipMemsetAsync(w.packed, 0, (size_t)Tc * R * 8, st));
+    hipLaunchKernelGGL(sampler_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.vid, w.sid, B, K, R, video_base);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.bos, 1, R);   // <bos> = 1
+    HIP_TRY(hipGetLastError());
+
+    int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
+    if (rc != S2VT_OK) return rc;
+
+    NoiseIds none{nullptr, nullptr, 0};
+    NoiseIds ids{w.vid, w.sid, seed};
+    int cur = 0;
+    // ---- encoding stage (tf_s2vt.py:113-122), M = B
+    for (int t = 0; t < Tv; ++t) {
+        const int nxt = cur ^ 1;
+        ASeg s1[2] = {make_seg(w.emb + (size_t)t * E, Tv * E, E, 0), make_seg(w.h1[cur], H, H, E)};
+        HIP_TRY(lstm_call(s1, 2, p->lstm1_W, p->lstm1_b, w.c1[cur], 0, w.c1[nxt], w.h1[nxt], nullptr, nullptr, B, H, 1.0f,
+                          none, 0, -1, st));
+        ASeg s2[2] = {make_seg(w.h1[nxt], H, H, 0), make_seg(w.h2e[cur], H, H, H + E)};
+        HIP_TRY(lstm_call(s2, 2, p->lstm2_W, p->lstm2_b, w.c2e[cur], 0, w.c2e[nxt], w.h2e[nxt], nullptr, nullptr, B, H,
+                          1.0f, none, 0, -1, st));
+        cur = nxt;
+    }
+    // ---- decoding stage (tf_s2vt.py:126-153 as specialised by the samplers).  LSTM1 sees only the
+    // zero padding and its own state, so its trajectory is per VIDEO: it runs at M = B and the R
+    // sample rows read it through row % B.  LSTM2 + vocab run at M = R.
+    int cur2 = 0;
+    for (int t = 0; t < Tc; ++t) {
+        const int nxt = cur ^ 1, nxt2 = cur2 ^ 1;
+        ASeg s1[1] = {make_seg(w.h1[cur], H, H, E)};
+        HIP_TRY(lstm_call(s1, 1, p->lstm1_W, p->lstm1_b, w.c1[cur], 0, w.c1[nxt], w.h1[nxt], nullptr, nullptr, B, H, 1.0f,
+                          none, 0, -1, st));
+        const float* h2p = t == 0 ? w.h2e[cur] : w.h2[cur2];
+        const float* c2p = t == 0 ? w.c2e[cur] : w.c2[cur2];
+        const int smod = t == 0 ? B : 0;
+        ASeg s2[3] = {make_seg(w.h1[nxt], H, H, 0, B),
+                      t == 0 ? make_seg(p->Wemb, E, E, H, 0, w.bos)
+                             : make_seg(p->Wemb, E, E, H, 0, nullptr, w.packed + (size_t)(t - 1) * R),
+                      make_seg(h2p, H, H, H + E, smod)};
+        HIP_TRY(lstm_call(s2, 3, p->lstm2_W, p->lstm2_b, c2p, smod, w.c2[nxt2], w.h2[nxt2], nullptr, nullptr, R, H, 1.0f,
+                          none, 0, -1, st));
+        HIP_TRY(pick_call(w.h2[nxt2], H, p->embed_word_W, p->embed_word_b, R, H, V, ids, t, w.packed + (size_t)t * R,
+                          nullptr, -1, st));
+        cur = nxt;
+        cur2 = nxt2;
+    }
+    hipLaunchKernelGGL(unpack_ids_kernel, dim3((R * Tc + 255) / 256), dim3(256), 0, st, w.packed, ids_out, R, Tc);
+    HIP_TRY(hipGetLastError());
+    return S2VT_OK;
+}
+
+}  // extern "C"

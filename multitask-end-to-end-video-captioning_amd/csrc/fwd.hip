@@ -1,0 +1,139 @@
+// fwd.hip -- instantiations + shape dispatch of the forward contraction kernel (gemm_mfma.h).
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+
+#include "internal.h"
+
+namespace s2vt {
+
+namespace {
+
+typedef void (*KernelFn)(const GemmArgs);
+
+struct CfgEntry {
+    const char* name;
+    KernelFn vec, scalar;   // 16-byte vector loads / scalar loads (unaligned or odd shapes)
+    int BM, CG, NT, lds_bytes;
+};
+
+template <int WM, int WN, int TM, int TN, int NG, int EPI>
+constexpr CfgEntry make_entry(const char* name)
+{
+    using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true>;
+    return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true>, gemm_kernel<WM, WN, TM, TN, NG, EPI, false>,
+                    C::BM, C::CG, C::NT, C::LDS_FLOATS * 4};
+}
+
+// name = BMxBN(wavesMxwavesN)
+const CfgEntry kStore[] = {
+    make_entry<4, 1, 1, 4, 1, EPI_STORE>("64x64(4x1)"),
+    make_entry<2, 2, 2, 4, 1, EPI_STORE>("64x128(2x2)"),
+    make_entry<2, 2, 4, 4, 1, EPI_STORE>("128x128(2x2)"),
+    make_entry<4, 1, 2, 2, 1, EPI_STORE>("128x32(4x1)"),
+    make_entry<2, 2, 1, 2, 1, EPI_STORE>("32x64(2x2)"),
+};
+const CfgEntry kLstm[] = {
+    make_entry<4, 1, 1, 4, 4, EPI_LSTM>("64x16u(4x1)"),
+    make_entry<4, 1, 2, 4, 4, EPI_LSTM>("128x16u(4x1)"),
+    make_entry<2, 2, 2, 4, 4, EPI_LSTM>("64x32u(2x2)"),
+    make_entry<2, 2, 3, 4, 4, EPI_LSTM>("96x32u(2x2)"),
+    make_entry<2, 1, 1, 4, 4, EPI_LSTM>("32x16u(2x1)"),
+};
+const CfgEntry kPick[] = {
+    make_entry<4, 1, 1, 4, 1, EPI_PICK>("64x64(4x1)"),
+    make_entry<2, 2, 6, 3, 1, EPI_PICK>("192x96(2x2)"),
+    make_entry<2, 2, 4, 4, 1, EPI_PICK>("128x128(2x2)"),
+    make_entry<2, 2, 2, 4, 1, EPI_PICK>("64x128(2x2)"),
+};
+
+const CfgEntry* table(int epi, int* n)
+{
+    switch (epi) {
+        case EPI_STORE: *n = sizeof(kStore) / sizeof(kStore[0]); return kStore;
+        case EPI_LSTM: *n = sizeof(kLstm) / sizeof(kLstm[0]); return kLstm;
+        default: *n = sizeof(kPick) / sizeof(kPick[0]); return kPick;
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+bool can_vec(const GemmArgs& a)
+{
+    if (!aligned16(a.W) || (a.ldw & 3) || (a.N & 3) || (a.gstride & 3)) return false;
+    for (int s = 0; s < a.nseg; ++s) {
+        const ASeg& sg = a.seg[s];
+        if (!sg.ptr || sg.k <= 0) continue;
+        if (!aligned16(sg.ptr) || (sg.ld & 3) || (sg.k & 3)) return false;
+    }
+    if (a.splits > 1 && (a.kper & 3)) return false;
+    return true;
+}
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Pick the configuration with the best estimated time on 256 CUs: work per workgroup times the
+// number of dispatch rounds, with a small penalty for thin tiles (more operand traffic per flop).
+int choose(const CfgEntry* t, int n, int M, int N)
+{
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < n; ++i) {
+        const long wgs = (long)ceil_div(M, t[i].BM) * ceil_div(N, t[i].CG);
+        const int per_cu = t[i].lds_bytes > 80 * 1024 ? 1 : 2;
+        const double rounds = (double)((wgs + 256L * per_cu - 1) / (256L * per_cu));
+        const double tile = (double)t[i].BM * t[i].CG;
+        const double traffic = 1.0 + 24.0 * (t[i].BM + t[i].CG) / tile;  // operand bytes per flop, relative
+        const double cost = rounds * per_cu * tile * traffic;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
+}
+
+std::once_flag g_attr_once;
+
+void set_lds_attrs()
+{
+    for (int epi = 0; epi < 3; ++epi) {
+        int n;
+        const CfgEntry* t = table(epi, &n);
+        for (int i = 0; i < n; ++i) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t[i].vec), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      t[i].lds_bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t[i].scalar),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, t[i].lds_bytes);
+        }
+    }
+}
+
+}  // namespace
+
+int gemm_num_cfgs(int epi)
+{
+    int n;
+    table(epi, &n);
+    return n;
+}
+
+const char* gemm_cfg_name(int epi, int cfg)
+{
+    int n;
+    const CfgEntry* t = table(epi, &n);
+    return (cfg >= 0 && cfg < n) ? t[cfg].name : "?";
+}
+
+hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
+{
+    std::call_once(g_attr_once, set_lds_attrs);
+    int n;
+    const CfgEntry* t = table(epi, &n);
+    if (cfg < 0 || cfg >= n) cfg = choose(t, n, a.M, a.N);
+    const CfgEntry& e = t[cfg];
+    if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    const dim3 grid((unsigned)(ceil_div(a.M, e.BM) * ceil_div(a.N, e.CG)), (unsigned)(a.splits > 1 ? a.splits : 1), 1);
+    KernelFn fn = can_vec(a) ? e.vec : e.scalar;
+    hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace s2vt

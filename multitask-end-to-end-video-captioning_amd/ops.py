@@ -1,0 +1,146 @@
+"""Thin torch-tensor wrappers over the C ABI (include/s2vt.h).  torch is plumbing here: device
+memory, the current HIP stream, dtype checks.  All compute happens in libs2vt_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Dims, Operand, Params, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32, "expected a CUDA float32 tensor"
+
+
+def make_dims(dim_image, n_words, word_dim, lstm_dim, n_video_lstm_step, n_caption_lstm_step, label_dim=0) -> Dims:
+    return Dims(dim_image, n_words, word_dim, lstm_dim, n_video_lstm_step, n_caption_lstm_step, label_dim, 0)
+
+
+def make_params(tensors: dict) -> Params:
+    """tensors: name -> CUDA fp32 tensor (names = _lib.PARAM_FIELDS; missing ones become NULL)."""
+    p = Params()
+    for n in _lib.PARAM_FIELDS:
+        t = tensors.get(n)
+        if t is not None:
+            _chk_f32(t)
+            assert t.is_contiguous()
+        setattr(p, n, None if t is None else t.data_ptr())
+    return p
+
+
+def operand(t, k=None, rowidx=None, rowmod=0, ld=None) -> Operand:
+    """A K-segment of a concatenated operand.  t=None -> zero input of width k."""
+    if t is None:
+        return Operand(None, None, 0, int(k), 0, 0)
+    _chk_f32(t)
+    assert t.dim() == 2 and t.stride(1) == 1
+    if rowidx is not None:
+        assert rowidx.is_cuda and rowidx.dtype == torch.int32 and rowidx.is_contiguous()
+    return Operand(t.data_ptr(), None if rowidx is None else rowidx.data_ptr(), int(ld if ld is not None else t.stride(0)),
+                   int(k if k is not None else t.shape[1]), int(rowmod), 0)
+
+
+def math_eval(fn: str, x):
+    _chk_f32(x)
+    y = torch.empty_like(x)
+    code = {"exp": 0, "log": 1, "tanh": 2, "sigmoid": 3}[fn]
+    check(lib().s2vt_math_eval(code, _ptr(x), _ptr(y), x.numel(), _stream()), "s2vt_math_eval")
+    return y
+
+
+def gumbel_eval(seed, video, sample, step, V, device="cuda"):
+    out = torch.empty(V, dtype=torch.float32, device=device)
+    check(lib().s2vt_gumbel_eval(seed, video, sample, step, _ptr(out), V, _stream()), "s2vt_gumbel_eval")
+    return out
+
+
+def gemm(segs, W, bias=None, M=None, cinit=None, act_tanh=False, tile_cfg=-1, out=None):
+    """C = act([seg0 ; seg1 ; seg2] @ W + bias), continuing the chain from cinit if given."""
+    _chk_f32(W, bias, cinit)
+    assert W.dim() == 2 and W.stride(1) == 1
+    N = W.shape[1]
+    arr = (Operand * len(segs))(*segs)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=W.device)
+    check(lib().s2vt_gemm(arr, len(segs), _ptr(W), W.stride(0), _ptr(bias), _ptr(cinit),
+                          0 if cinit is None else cinit.stride(0), _ptr(out), out.stride(0), M, N, int(act_tanh), tile_cfg,
+                          _stream()), "s2vt_gemm")
+    return out
+
+
+def lstm_cell_fwd(x0, x1, h_prev, c_prev, W, b, M, state_rowmod=0, keep=1.0, seed=0, video_id=None, sample_id=None,
+                  drop_code=0, want_gates=False, tile_cfg=-1):
+    _chk_f32(h_prev, c_prev, W, b)
+    H = W.shape[1] // 4
+    dev = W.device
+    c = torch.empty((M, H), dtype=torch.float32, device=dev)
+    h = torch.empty_like(c)
+    out = torch.empty_like(c)
+    gates = torch.empty((M, 4 * H), dtype=torch.float32, device=dev) if want_gates else None
+    check(lib().s2vt_lstm_cell_fwd(None if x0 is None else C.byref(x0), None if x1 is None else C.byref(x1), _ptr(h_prev),
+                                   _ptr(c_prev), state_rowmod, _ptr(W), _ptr(b), _ptr(c), _ptr(h), _ptr(out), _ptr(gates),
+                                   M, H, float(keep), seed, _ptr(video_id), _ptr(sample_id), drop_code, tile_cfg, _stream()),
+          "s2vt_lstm_cell_fwd")
+    return c, h, out, gates
+
+
+def vocab_pick(out2, W, b, video_id, sample_id, step, seed, want_logits=False, tile_cfg=-1):
+    _chk_f32(out2, W, b)
+    M, H = out2.shape
+    V = W.shape[1]
+    packed = torch.zeros(M, dtype=torch.int64, device=out2.device)
+    tok = torch.empty(M, dtype=torch.int32, device=out2.device)
+    logits = torch.empty((M, V), dtype=torch.float32, device=out2.device) if want_logits else None
+    check(lib().s2vt_vocab_pick(_ptr(out2), out2.stride(0), _ptr(W), _ptr(b), M, H, V, _ptr(video_id), _ptr(sample_id),
+                                step, seed, _ptr(packed), _ptr(tok), _ptr(logits), tile_cfg, _stream()), "s2vt_vocab_pick")
+    return tok, logits, packed
+
+
+def frame_embed_fwd(dims: Dims, params: Params, video):
+    _chk_f32(video)
+    B = video.shape[0]
+    emb = torch.empty((B * dims.n_video_lstm_step, dims.word_dim), dtype=torch.float32, device=video.device)
+    check(lib().s2vt_frame_embed_fwd(C.byref(dims), C.byref(params), _ptr(video), B, _ptr(emb), _stream()),
+          "s2vt_frame_embed_fwd")
+    return emb
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag="default"):
+    """A cached, 256-byte aligned device scratch buffer (torch owns the memory)."""
+    key = (tag, str(device))
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        assert t.data_ptr() % 256 == 0
+        _ws_cache[key] = t
+    return t
+
+
+def sample(dims: Dims, params: Params, video, K: int, seed: int, video_base: int = 0, with_greedy: bool = True):
+    """K multinomial captions per video (+ greedy).  Returns (sampled [K*B,Tc], greedy [B,Tc]) int32."""
+    _chk_f32(video)
+    assert video.is_contiguous()
+    B = video.shape[0]
+    g = 1 if with_greedy else 0
+    L = lib()
+    nbytes = L.s2vt_sample_workspace_bytes(C.byref(dims), B, K, g)
+    ws = workspace(nbytes, video.device, "sample")
+    ids = torch.empty(((K + g) * B, dims.n_caption_lstm_step), dtype=torch.int32, device=video.device)
+    check(L.s2vt_sample(C.byref(dims), C.byref(params), _ptr(video), B, K, g, seed, video_base, _ptr(ids), _ptr(ws),
+                        ws.numel(), _stream()), "s2vt_sample")
+    return ids[:K * B], (ids[K * B:] if with_greedy else None)
