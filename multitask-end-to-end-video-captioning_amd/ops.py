@@ -48,8 +48,10 @@ def operand(t, k=None, rowidx=None, rowmod=0, ld=None) -> Operand:
     assert t.dim() == 2 and t.stride(1) == 1
     if rowidx is not None:
         assert rowidx.is_cuda and rowidx.dtype == torch.int32 and rowidx.is_contiguous()
-    return Operand(t.data_ptr(), None if rowidx is None else rowidx.data_ptr(), int(ld if ld is not None else t.stride(0)),
-                   int(k if k is not None else t.shape[1]), int(rowmod), 0)
+    op = Operand(t.data_ptr(), None if rowidx is None else rowidx.data_ptr(), int(ld if ld is not None else t.stride(0)),
+                 int(k if k is not None else t.shape[1]), int(rowmod), 0)
+    op._keep = (t, rowidx)          # the struct holds raw pointers: keep the tensors alive with it
+    return op
 
 
 def math_eval(fn: str, x):
