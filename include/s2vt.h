@@ -133,6 +133,56 @@ int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, in
                 int32_t with_greedy, uint64_t seed, int32_t video_base, int32_t* ids_out, void* workspace,
                 size_t workspace_bytes, s2vt_stream stream);
 
+/* ---- teacher-forced unroll: build_model (tf_s2vt.py:90-153) / build_loss
+ * (reinforcement_multisampling_tf_s2vt.py:227-292) forward --------------------------------------
+ * video [B,Tv,d]; the N = rep*B rows are sample-major copies of the B videos (row n uses video
+ * n % B -- the reference tiles the feature block 8x on the host, :779-782; here it is never
+ * materialised).  caption int32 [N,Tc]; previous word = <bos> at t=0 else caption[:,t-1].
+ * Dropout-wrapped cells: keep < 1 draws the masks from the dropout Philox stream (seed; video_id,
+ * sample_id per row; code = layer*256 + step); keep >= 1 disables dropout.  logits_out
+ * [Tc*N, V] is TIME-MAJOR (row t*N + n).  Activations needed by s2vt_bptt_bwd stay in the workspace. */
+size_t s2vt_train_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t N);
+int s2vt_teacher_forced_fwd(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
+                            const int32_t* caption, float keep, uint64_t seed, const int32_t* video_id,
+                            const int32_t* sample_id, float* logits_out, void* workspace, size_t workspace_bytes,
+                            s2vt_stream stream);
+
+/* ---- softmax / NLL rows, forward + backward ----------------------------------------------------
+ * nll[r] = -sum_v q[v] * log_softmax(logits[r])[v],  q = onehot(target[r])*(1-s) + s/V
+ * (tf.losses.softmax_cross_entropy(label_smoothing=s), tf_s2vt.py:155; s = 0 gives the
+ * log-prob of the sampled word, reinforcement_multisampling_tf_s2vt.py:286-288), and
+ * logits[r,:] <- coef[r] * (softmax(logits[r]) - q)   (the gradient of sum_r coef[r]*nll[r]).
+ * XE: coef = the Q1 batch-mean weights; REINFORCE: coef[r] = (reward - baseline)[n] * mask[n,t]
+ * (:643-646) -- in both cases WITHOUT the 1/sum(mask) factor, which is applied after the
+ * data-parallel all-reduce by s2vt_grad_finalize.  lp_target (optional) = log-prob of target. */
+int s2vt_softmax_nll_fwd_bwd(float* logits, int32_t ld, int32_t R, int32_t V, const int32_t* target, const float* coef,
+                             float smoothing, float* nll, float* lp_target, s2vt_stream stream);
+
+/* ---- back-propagation through the unroll (what tf.gradients builds, :650) ---------------------
+ * dlogits [Tc*N, V] time-major (output of s2vt_softmax_nll_fwd_bwd); the workspace must still hold
+ * the activations of the matching s2vt_teacher_forced_fwd call (same d, B, N, keep, seed, ids).
+ * Gradients are ACCUMULATED into `grads` (same layout as the parameters; zero it first). */
+int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
+                  int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
+                  const int32_t* sample_id, void* workspace, size_t workspace_bytes, s2vt_stream stream);
+
+/* dWemb[idx[r], :] += dE[r, :]  -- gradient of tf.nn.embedding_lookup (tf_s2vt.py:128-134). */
+int s2vt_embed_scatter_add(const float* dE, int32_t ld, const int32_t* idx, int32_t R, int32_t E, float* dWemb,
+                           s2vt_stream stream);
+
+/* ---- gradient finalisation + tf.clip_by_global_norm + tf.train.AdamOptimizer ------------------
+ * (reinforcement_multisampling_tf_s2vt.py:638-652; tf_s2vt.py:163-166,445-448).
+ * s2vt_grad_finalize: g <- g * (*gscale) + weight_decay * theta over one flat range, and
+ *   *sumsq += sum g^2.  gscale (device scalar, may be NULL = 1) carries 1/sum(mask) computed after
+ *   the all-reduce; weight_decay implements decay_value * l2_loss for the decayed variables (Q3).
+ * s2vt_adam_tf: g' = g * clip_norm / max(sqrt(*sumsq), clip_norm) (clip_norm <= 0 or sumsq NULL:
+ *   no clipping), then TF-form Adam with step count `step` >= 1 (epsilon outside the bias
+ *   correction). */
+int s2vt_grad_finalize(float* g, const float* theta, int64_t n, const float* gscale, float weight_decay, float* sumsq,
+                       s2vt_stream stream);
+int s2vt_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
+                 float lr, int64_t step, float beta1, float beta2, float eps, s2vt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

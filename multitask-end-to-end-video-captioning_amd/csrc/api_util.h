@@ -1,0 +1,125 @@
+// api_util.h -- host-side helpers shared by the extern "C" translation units (api.hip, train.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstring>
+
+#include "../../include/s2vt.h"
+#include "internal.h"
+
+using namespace s2vt;
+
+namespace s2vt_api {
+
+extern std::atomic<int> g_last_hip;
+
+inline int hip_fail(hipError_t e)
+{
+    g_last_hip.store((int)e);
+    return S2VT_E_HIP;
+}
+
+#define HIP_TRY(expr)                               \
+    do {                                            \
+        hipError_t _e = (expr);                     \
+        if (_e != hipSuccess) return hip_fail(_e);  \
+    } while (0)
+
+inline hipStream_t S(s2vt_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// bump allocator over the caller's workspace (256-byte granules)
+struct Carver {
+    char* base;
+    size_t off = 0, cap;
+    Carver(void* p, size_t bytes) : base(static_cast<char*>(p)), cap(bytes) {}
+    template <typename T>
+    T* take(size_t n)
+    {
+        const size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += bytes;
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+inline void seg_from_operand(ASeg& s, const s2vt_operand* o, int kw)
+{
+    std::memset(&s, 0, sizeof(s));
+    if (!o) return;
+    s.ptr = o->ptr;
+    s.rowidx = o->rowidx;
+    s.ld = o->ld;
+    s.k = o->k;
+    s.kw = kw;
+    s.rowmod = o->rowmod;
+}
+
+inline ASeg make_seg(const float* ptr, int ld, int k, int kw, int rowmod = 0, const int* rowidx = nullptr,
+              const unsigned long long* rowkey = nullptr)
+{
+    ASeg s;
+    std::memset(&s, 0, sizeof(s));
+    s.ptr = ptr; s.ld = ld; s.k = k; s.kw = kw; s.rowmod = rowmod; s.rowidx = rowidx; s.rowkey = rowkey;
+    return s;
+}
+
+struct NoiseIds {
+    const int32_t* video_id;
+    const int32_t* sample_id;
+    uint64_t seed;
+};
+
+// One BasicLSTMCell call.  segs/nseg describe [x0 ; x1 ; h_prev] with their W row offsets.
+inline hipError_t lstm_call(const ASeg* segs, int nseg, const float* W, const float* b, const float* c_prev, int cprev_rowmod,
+                     float* c_new, float* h_new, float* out, float* gates, int M, int H, float keep, const NoiseIds& ids,
+                     uint32_t drop_code, int cfg, hipStream_t st)
+{
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
+    a.nseg = nseg;
+    a.W = W; a.ldw = 4 * H; a.M = M; a.N = H; a.gstride = H; a.bias = b;
+    a.c_prev = c_prev; a.cprev_rowmod = cprev_rowmod; a.c_new = c_new; a.h_new = h_new; a.out = out; a.gates = gates;
+    a.keep = keep; a.drop_code = drop_code;
+    a.video_id = ids.video_id; a.sample_id = ids.sample_id;
+    a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32);
+    return launch_gemm(a, EPI_LSTM, cfg, st);
+}
+
+inline hipError_t pick_call(const float* A, int lda, const float* W, const float* b, int M, int H, int V, const NoiseIds& ids,
+                     int step, unsigned long long* packed, float* logits_out, int cfg, hipStream_t st)
+{
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.seg[0] = make_seg(A, lda, H, 0);
+    a.nseg = 1;
+    a.W = W; a.ldw = V; a.M = M; a.N = V; a.gstride = 0; a.bias = b;
+    a.video_id = ids.video_id; a.sample_id = ids.sample_id;
+    a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32);
+    a.step = step; a.pick = packed; a.logits_out = logits_out; a.ldc = V;
+    return launch_gemm(a, EPI_PICK, cfg, st);
+}
+
+inline hipError_t store_call(const ASeg* segs, int nseg, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
+                      int N, int act, int cfg, hipStream_t st, const float* cinit = nullptr, int ldcinit = 0)
+{
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
+    a.nseg = nseg;
+    a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.gstride = 0; a.bias = bias;
+    a.cinit = cinit; a.ldcinit = ldcinit;
+    a.C = C; a.ldc = ldc; a.act = act;
+    return launch_gemm(a, EPI_STORE, cfg, st);
+}
+
+inline bool dims_ok(const s2vt_dims* d)
+{
+    return d && d->dim_image > 0 && d->n_words > 0 && d->word_dim > 0 && d->lstm_dim > 0 && d->n_video_lstm_step > 0 &&
+           d->n_caption_lstm_step > 0;
+}
+
+
+}  // namespace s2vt_api

@@ -1,0 +1,389 @@
+// aux.hip -- the HBM-bound kernels around the contractions: softmax/NLL rows, LSTM pointwise
+// backward, column sums, embedding scatter-add, transposes, gradient finalisation, TF-form Adam,
+// and the TN weight-gradient GEMM launcher.  All 64-lane-wave code, 16-byte accesses where the
+// layout allows, one pass over HBM per kernel.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+
+#include "detmath.h"
+#include "gemm_tn.h"
+#include "internal.h"
+
+namespace s2vt {
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <bool IS_MAX>
+__device__ __forceinline__ float block_reduce(float v, float* sh)
+{
+    v = IS_MAX ? wave_max(v) : wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < nw; ++i) r = IS_MAX ? fmaxf(r, sh[i]) : r + sh[i];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// caption [N,Tc] -> time-major previous-token and target arrays
+//   prev[t][n] = t == 0 ? <bos>=1 : caption[n][t-1]   (tf_s2vt.py:128-134)
+//   tgt [t][n] = caption[n][t]                         (tf_s2vt.py:150)
+// ---------------------------------------------------------------------------------------------
+__global__ void prep_caption_kernel(const int32_t* cap, int32_t* prev, int32_t* tgt, int N, int Tc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Tc) return;
+    const int t = i / N, n = i % N;
+    prev[i] = t == 0 ? 1 : cap[n * Tc + t - 1];
+    tgt[i] = cap[n * Tc + t];
+}
+
+hipError_t launch_prep_caption(const int32_t* cap, int32_t* prev, int32_t* tgt, int N, int Tc, hipStream_t st)
+{
+    hipLaunchKernelGGL(prep_caption_kernel, dim3((N * Tc + 255) / 256), dim3(256), 0, st, cap, prev, tgt, N, Tc);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax / NLL rows, forward + backward in one pass over the logits.
+//   lse = max + log(sum exp(l - max)); q = onehot*(1-s) + s/V; nll = -sum q*(l - lse)
+//   dlogits = coef[row] * (softmax - q)      (written in place over the logits)
+// XE (tf_s2vt.py:155-160): s = 0.05, coef from the Q1 batch-mean rule; PG
+// (reinforcement_multisampling_tf_s2vt.py:286-291,643-646): s = 0, coef = (r-b)*mask.
+// One workgroup per row; the row is re-read from L2 (48 KB at V=12k), HBM sees one read + one write.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_nll_kernel(float* logits, int ld, int V, const int32_t* target,
+                                                          const float* coef, float smoothing, float* nll, float* lp_t)
+{
+    __shared__ float sh[8];
+    const int row = blockIdx.x;
+    float* l = logits + (size_t)row * ld;
+    const int tid = threadIdx.x;
+    const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 15) == 0);
+    const int V4 = vec ? (V >> 2) : 0;
+
+    float mx = -INFINITY;
+    for (int i = tid; i < V4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(l)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int i = V4 * 4 + tid; i < V; i += 256) mx = fmaxf(mx, l[i]);
+    mx = block_reduce<true>(mx, sh);
+
+    float se = 0.f, sl = 0.f;   // sum exp(l-mx), sum l (for the smoothing term)
+    for (int i = tid; i < V4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(l)[i];
+        se += dm_expf(v.x - mx) + dm_expf(v.y - mx) + dm_expf(v.z - mx) + dm_expf(v.w - mx);
+        sl += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = V4 * 4 + tid; i < V; i += 256) { se += dm_expf(l[i] - mx); sl += l[i]; }
+    se = block_reduce<false>(se, sh);
+    sl = block_reduce<false>(sl, sh);
+    const float lse = mx + dm_logf(se);
+    const int tg = target[row];
+    const float lt = l[tg];
+    const float qoff = smoothing / (float)V;
+    if (tid == 0) {
+        // -sum q*(l-lse) = -(1-s)*(l_t - lse) - (s/V) * (sum l - V*lse)
+        const float v = -(1.0f - smoothing) * (lt - lse) - qoff * (sl - (float)V * lse);
+        if (nll) nll[row] = v;
+        if (lp_t) lp_t[row] = lt - lse;
+    }
+    const float cf = coef[row];
+    const float inv = 1.0f / se;
+    __syncthreads();   // everyone has read l[tg] before it is overwritten
+    for (int i = tid; i < V4; i += 256) {
+        float4 v = reinterpret_cast<const float4*>(l)[i];
+        v.x = cf * (dm_expf(v.x - mx) * inv - qoff);
+        v.y = cf * (dm_expf(v.y - mx) * inv - qoff);
+        v.z = cf * (dm_expf(v.z - mx) * inv - qoff);
+        v.w = cf * (dm_expf(v.w - mx) * inv - qoff);
+        const int b = i * 4;
+        if (tg >= b && tg < b + 4) {
+            const float d = cf * (1.0f - smoothing);
+            if (tg == b) v.x -= d; else if (tg == b + 1) v.y -= d; else if (tg == b + 2) v.z -= d; else v.w -= d;
+        }
+        reinterpret_cast<float4*>(l)[i] = v;
+    }
+    for (int i = V4 * 4 + tid; i < V; i += 256) {
+        float v = cf * (dm_expf(l[i] - mx) * inv - qoff);
+        if (i == tg) v -= cf * (1.0f - smoothing);
+        l[i] = v;
+    }
+}
+
+hipError_t launch_softmax_nll(float* logits, int ld, int R, int V, const int32_t* target, const float* coef,
+                              float smoothing, float* nll, float* lp_t, hipStream_t st)
+{
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(softmax_nll_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, nll, lp_t);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// BasicLSTMCell pointwise backward for one step (inverse of the EPI_LSTM epilogue):
+//   dh   = sum_s dh_rec[s] (split-K slabs of dz_{t+1} @ Whh^T) + dout_ext * keepmask / keep
+//   do~  = dh*tanh(c)*so*(1-so);  dc = dc_next + dh*so*(1-tanh(c)^2)
+//   di~  = dc*tj*si*(1-si); dj~ = dc*si*(1-tj^2); df~ = dc*c_prev*sf*(1-sf); dc_prev = dc*sf
+// gates = [si | tj | sf | so] saved by the forward.  dout_ext may be NULL (encode-stage LSTM2
+// output is discarded, tf_s2vt.py:122).
+// ---------------------------------------------------------------------------------------------
+struct LstmBwdArgs {
+    const float* gates; const float* c_new; const float* c_prev;   // c_prev == nullptr -> zeros (t = 0)
+    const float* dh_rec; int nslab; size_t slab_stride;             // nullptr at the last step
+    const float* dout_ext; int ld_ext;                              // gradient w.r.t. the DROPPED output
+    float* dc;                                                      // in: dc_next (or nullptr at last step) / out: dc_prev
+    const float* dc_in;
+    float* dz;                                                      // [M, 4H]
+    int M, H;
+    float keep; uint32_t seed_lo, seed_hi, drop_code;
+    const int32_t* video_id; const int32_t* sample_id;
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const LstmBwdArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.M * a.H) return;
+    const int m = i / a.H, u = i % a.H;
+    const int H = a.H;
+    float dh = 0.f;
+    if (a.dh_rec)
+        for (int s = 0; s < a.nslab; ++s) dh += a.dh_rec[(size_t)s * a.slab_stride + i];
+    if (a.dout_ext) {
+        float d = a.dout_ext[(size_t)m * a.ld_ext + u];
+        if (a.keep < 1.0f)
+            d = (d / a.keep) * dropout_keep01(a.seed_lo, a.seed_hi, (uint32_t)a.video_id[m], (uint32_t)a.sample_id[m],
+                                              a.drop_code, (uint32_t)u, a.keep);
+        dh += d;
+    }
+    const float* g = a.gates + (size_t)m * 4 * H + u;
+    const float si = g[0], tj = g[H], sf = g[2 * H], so = g[3 * H];
+    const float tc = dm_tanhf(a.c_new[i]);
+    const float cp = a.c_prev ? a.c_prev[i] : 0.f;
+    float dc = dh * so * (1.f - tc * tc);
+    if (a.dc_in) dc += a.dc_in[i];
+    float* z = a.dz + (size_t)m * 4 * H + u;
+    z[0] = dc * tj * si * (1.f - si);
+    z[H] = dc * si * (1.f - tj * tj);
+    z[2 * H] = dc * cp * sf * (1.f - sf);
+    z[3 * H] = dh * tc * so * (1.f - so);
+    a.dc[i] = dc * sf;
+}
+
+hipError_t launch_lstm_bwd_pointwise(const float* gates, const float* c_new, const float* c_prev, const float* dh_rec,
+                                     int nslab, size_t slab_stride, const float* dout_ext, int ld_ext, const float* dc_in,
+                                     float* dc_out, float* dz, int M, int H, float keep, uint64_t seed, uint32_t drop_code,
+                                     const int32_t* video_id, const int32_t* sample_id, hipStream_t st)
+{
+    LstmBwdArgs a;
+    a.gates = gates; a.c_new = c_new; a.c_prev = c_prev; a.dh_rec = dh_rec; a.nslab = nslab; a.slab_stride = slab_stride;
+    a.dout_ext = dout_ext; a.ld_ext = ld_ext; a.dc = dc_out; a.dc_in = dc_in; a.dz = dz; a.M = M; a.H = H; a.keep = keep;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code = drop_code;
+    a.video_id = video_id; a.sample_id = sample_id;
+    hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((M * H + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[n] += sum_m X[m, n]      (bias gradients).  64 columns x 256-row slabs per workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* X, int ld, int M, int N, float* out)
+{
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r0 = blockIdx.y * 256 + (threadIdx.x >> 6);
+    float s = 0.f;
+    if (c < N)
+        for (int r = r0; r < M && r < (int)(blockIdx.y + 1) * 256; r += 4) s += X[(size_t)r * ld + c];
+    sh[threadIdx.x >> 6][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < N) atomicAdd(out + c, (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]));
+}
+
+hipError_t launch_colsum(const float* X, int ld, int M, int N, float* out, hipStream_t st)
+{
+    if (M <= 0 || N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, (M + 255) / 256), dim3(256), 0, st, X, ld, M, N, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// dWemb[idx[r], :] += dE[r, :]   (gradient of tf.nn.embedding_lookup; one wave per row,
+// 256 contiguous bytes per atomic wave-instruction).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* dE, int ld, const int32_t* idx, int R, int E,
+                                                               float* dW, int ldw)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int row = idx[r];
+    for (int e = threadIdx.x & 63; e < E; e += 64) atomicAdd(dW + (size_t)row * ldw + e, dE[(size_t)r * ld + e]);
+}
+
+hipError_t launch_scatter_add_rows(const float* dE, int ld, const int32_t* idx, int R, int E, float* dW, int ldw,
+                                   hipStream_t st)
+{
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, st, dE, ld, idx, R, E, dW, ldw);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[c, r] = in[r, c]   (32x32 tiles through LDS, padded rows)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, int ldi, float* out, int ldo, int R, int Cc)
+{
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < Cc) t[j][tx] = in[(size_t)(r0 + j) * ldi + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < Cc && r0 + tx < R) out[(size_t)(c0 + j) * ldo + r0 + tx] = t[tx][j];
+}
+
+hipError_t launch_transpose(const float* in, int ldi, float* out, int ldo, int R, int Cc, hipStream_t st)
+{
+    if (R <= 0 || Cc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, st, in, ldi, out, ldo, R, Cc);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer (reinforcement_multisampling_tf_s2vt.py:638-652)
+//   finalize: g = g * (*gscale) + wd * theta  (per-segment wd), accumulate sum g^2 -> *sumsq
+//   adam    : s = clip / max(sqrt(*sumsq), clip);  g' = g*s;  m,v update;  theta -= lr_t*m/(sqrt(v)+eps)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_finalize_kernel(float* g, const float* theta, int64_t n, const float* gscale,
+                                                            float wd, float* sumsq)
+{
+    __shared__ float sh[8];
+    const float sc = gscale ? *gscale : 1.0f;
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float v = g[i] * sc;
+        if (wd != 0.f) v += wd * theta[i];
+        g[i] = v;
+        acc += v * v;
+    }
+    acc = block_reduce<false>(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(sumsq, acc);
+}
+
+hipError_t launch_grad_finalize(float* g, const float* theta, int64_t n, const float* gscale, float wd, float* sumsq,
+                                hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3(blocks), dim3(256), 0, st, g, theta, n, gscale, wd, sumsq);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void adam_tf_kernel(float* theta, const float* g, float* m, float* v, int64_t n,
+                                                      const float* sumsq, float clip, float lr_t, float b1, float b2,
+                                                      float eps)
+{
+    float s = 1.0f;
+    if (sumsq && clip > 0.f) {
+        const float nrm = sqrtf(*sumsq);
+        s = clip / fmaxf(nrm, clip);
+    }
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * s;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] = theta[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+hipError_t launch_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip,
+                          float lr_t, float b1, float b2, float eps, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(blocks), dim3(256), 0, st, theta, g, m, v, n, sumsq, clip, lr_t, b1, b2, eps);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN GEMM launcher
+// ---------------------------------------------------------------------------------------------
+namespace {
+typedef void (*TnFn)(const TnKArgs);
+struct TnCfg { TnFn vec, scalar; int BMo, BNo, NT, lds; };
+
+template <int WM, int WN, int TM, int TN>
+constexpr TnCfg tn_entry()
+{
+    constexpr int BMo = WM * TM * 16, BNo = WN * TN * 16;
+    constexpr int SAo = (BMo % 32 == 16) ? BMo : BMo + 16, SBo = (BNo % 32 == 16) ? BNo : BNo + 16;
+    return TnCfg{gemm_tn_kernel<WM, WN, TM, TN, true>, gemm_tn_kernel<WM, WN, TM, TN, false>, BMo, BNo, 64 * WM * WN,
+                 2 * 32 * (SAo + SBo) * 4};
+}
+const TnCfg kTn[] = {tn_entry<2, 2, 4, 4>() /*128x128*/, tn_entry<2, 2, 2, 4>() /*64x128*/, tn_entry<2, 2, 2, 2>() /*64x64*/};
+std::once_flag g_tn_once;
+}  // namespace
+
+hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
+{
+    std::call_once(g_tn_once, [] {
+        for (const TnCfg& c : kTn) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(c.vec), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(c.scalar), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
+        }
+    });
+    if (a.Mred <= 0 || a.Kout <= 0 || a.N <= 0) return hipSuccess;
+    auto tiles = [&](const TnCfg& c) { return (long)((a.Kout + c.BMo - 1) / c.BMo) * ((a.N + c.BNo - 1) / c.BNo); };
+    int ci = 0;
+    if (tiles(kTn[0]) < 200) ci = 1;
+    if (ci == 1 && tiles(kTn[1]) < 200) ci = 2;
+    const TnCfg& c = kTn[ci];
+    const long nt = tiles(c);
+    int splits = 1;
+    if (nt < 128) {
+        splits = (int)((256 + nt - 1) / nt);
+        const int maxs = (a.Mred + 255) / 256;
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+    }
+    TnKArgs k;
+    k.A = a.A; k.rowidx = a.rowidx; k.lda = a.lda; k.B = a.B; k.ldb = a.ldb; k.C = a.C; k.ldc = a.ldc;
+    k.Mred = a.Mred; k.Kout = a.Kout; k.N = a.N;
+    k.mper = ((a.Mred + splits - 1) / splits + 31) / 32 * 32;
+    splits = (a.Mred + k.mper - 1) / k.mper;
+    k.atomic = splits > 1 ? 1 : 0;
+    k.accumulate = a.accumulate;
+    if (k.atomic && !a.accumulate) {
+        hipError_t e = hipMemset2DAsync(a.C, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, a.Kout, st);
+        if (e != hipSuccess) return e;
+    }
+    const bool vec = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0 && (a.lda & 3) == 0 &&
+                     (a.ldb & 3) == 0 && (a.Kout & 3) == 0 && (a.N & 3) == 0;
+    hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
+    return hipGetLastError();
+}
+
+}  // namespace s2vt

@@ -23,6 +23,22 @@ struct TnArgs {
 };
 hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st);
 
+hipError_t launch_prep_caption(const int32_t* cap, int32_t* prev, int32_t* tgt, int N, int Tc, hipStream_t st);
+hipError_t launch_softmax_nll(float* logits, int ld, int R, int V, const int32_t* target, const float* coef,
+                              float smoothing, float* nll, float* lp_t, hipStream_t st);
+hipError_t launch_lstm_bwd_pointwise(const float* gates, const float* c_new, const float* c_prev, const float* dh_rec,
+                                     int nslab, size_t slab_stride, const float* dout_ext, int ld_ext, const float* dc_in,
+                                     float* dc_out, float* dz, int M, int H, float keep, uint64_t seed, uint32_t drop_code,
+                                     const int32_t* video_id, const int32_t* sample_id, hipStream_t st);
+hipError_t launch_colsum(const float* X, int ld, int M, int N, float* out, hipStream_t st);
+hipError_t launch_scatter_add_rows(const float* dE, int ld, const int32_t* idx, int R, int E, float* dW, int ldw,
+                                   hipStream_t st);
+hipError_t launch_transpose(const float* in, int ldi, float* out, int ldo, int R, int Cc, hipStream_t st);
+hipError_t launch_grad_finalize(float* g, const float* theta, int64_t n, const float* gscale, float wd, float* sumsq,
+                                hipStream_t st);
+hipError_t launch_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip,
+                          float lr_t, float b1, float b2, float eps, hipStream_t st);
+
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.
 struct NnBwdArgs {

@@ -1,0 +1,253 @@
+// train.hip -- extern "C" entry points of the update half of the step: teacher-forced unroll with
+// saved activations (build_model / build_loss), softmax-NLL forward+backward (XE and the
+// reward-scaled policy-gradient NLL), back-propagation through time, gradient finalisation,
+// global-norm clip + TF-form Adam.
+#include <hip/hip_runtime.h>
+
+#include "api_util.h"
+
+using namespace s2vt_api;
+
+namespace {
+
+__global__ void enc_index_kernel(int32_t* idx, int N, int B, int Tv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Tv) return;
+    const int t = i / N, n = i % N;
+    idx[i] = (n % B) * Tv + t;     // row of video[B*Tv, d] / emb[B*Tv, E] feeding (step t, row n)
+}
+
+// saved activations + backward scratch of one teacher-forced unroll, carved from the caller's buffer
+struct TrainWs {
+    float* emb;
+    int32_t *prev, *tgt, *encidx;
+    float *G1, *C1, *H1, *O1, *G2, *C2, *H2, *O2;
+    float *WoutT, *W2T, *W1T, *dO2, *dZ1, *dZ2, *dX2, *dX1, *slab, *dc;
+};
+
+constexpr int kSlabs = 4;
+
+size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
+{
+    const size_t H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
+    const size_t T = Tv + Tc, n = N;
+    TrainWs w;
+    w.emb = c.take<float>((size_t)B * Tv * E);
+    w.prev = c.take<int32_t>(Tc * n); w.tgt = c.take<int32_t>(Tc * n); w.encidx = c.take<int32_t>(Tv * n);
+    w.G1 = c.take<float>(T * n * 4 * H); w.C1 = c.take<float>((T + 1) * n * H); w.H1 = c.take<float>((T + 1) * n * H);
+    w.O1 = c.take<float>(T * n * H);
+    w.G2 = c.take<float>(T * n * 4 * H); w.C2 = c.take<float>((T + 1) * n * H); w.H2 = c.take<float>((T + 1) * n * H);
+    w.O2 = c.take<float>(T * n * H);
+    w.WoutT = c.take<float>(V * H); w.W2T = c.take<float>(4 * H * (2 * H + E)); w.W1T = c.take<float>(4 * H * (E + H));
+    w.dO2 = c.take<float>(Tc * n * H);
+    w.dZ1 = c.take<float>(T * n * 4 * H); w.dZ2 = c.take<float>(T * n * 4 * H);
+    w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * n * E);
+    w.slab = c.take<float>((size_t)kSlabs * n * H); w.dc = c.take<float>(n * H);
+    if (out) *out = w;
+    return c.off;
+}
+
+bool params_ok(const s2vt_params* p)
+{
+    return p && p->Wemb && p->encode_image_W && p->encode_image_b && p->lstm1_W && p->lstm1_b && p->lstm2_W && p->lstm2_b &&
+           p->embed_word_W && p->embed_word_b;
+}
+
+// order-free NN product for the backward data path: C[s] = A[:, Ks] @ W[Ks, :]  (split-K slabs)
+hipError_t nn_bwd(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int splits,
+                  size_t slab_stride, hipStream_t st)
+{
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.seg[0] = make_seg(A, lda, K, 0);
+    a.nseg = 1;
+    a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.C = C; a.ldc = ldc;
+    if (splits > 1) {
+        a.splits = splits;
+        a.kper = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+        a.splits = (K + a.kper - 1) / a.kper;
+        a.slab_stride = slab_stride;
+    }
+    return launch_gemm(a, EPI_STORE, -1, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t s2vt_train_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t N)
+{
+    if (!dims_ok(d) || B <= 0 || N <= 0 || N % B) return 0;
+    Carver c(nullptr, 0);
+    return carve_train(c, d, B, N, nullptr);
+}
+
+int s2vt_teacher_forced_fwd(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
+                            const int32_t* caption, float keep, uint64_t seed, const int32_t* video_id,
+                            const int32_t* sample_id, float* logits, void* workspace, size_t workspace_bytes,
+                            s2vt_stream stream)
+{
+    if (!dims_ok(d) || !params_ok(p) || !video || !caption || !logits || !workspace || B <= 0 || N <= 0 || N % B)
+        return S2VT_E_BADARG;
+    if (!(keep > 0.0f) || (keep < 1.0f && (!video_id || !sample_id))) return S2VT_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
+    const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
+    const int T = Tv + Tc;
+    Carver c(workspace, workspace_bytes);
+    TrainWs w;
+    carve_train(c, d, B, N, &w);
+    if (!c.ok()) return S2VT_E_WORKSPACE;
+    hipStream_t st = S(stream);
+    const size_t NH = (size_t)N * H;
+
+    HIP_TRY(launch_prep_caption(caption, w.prev, w.tgt, N, Tc, st));
+    hipLaunchKernelGGL(enc_index_kernel, dim3((N * Tv + 255) / 256), dim3(256), 0, st, w.encidx, N, B, Tv);
+    HIP_TRY(hipGetLastError());
+    // zero initial states (tf_s2vt.py:105-107): slot 0 of the state histories
+    HIP_TRY(hipMemsetAsync(w.C1, 0, NH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.H1, 0, NH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.C2, 0, NH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.H2, 0, NH * 4, st));
+    int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
+    if (rc != S2VT_OK) return rc;
+
+    NoiseIds ids{video_id, sample_id, seed};
+    for (int t = 0; t < T; ++t) {
+        // LSTM1 (tf_s2vt.py:119 encode, :140 decode with the zero padding input)
+        ASeg s1[2];
+        int n1 = 0;
+        if (t < Tv) s1[n1++] = make_seg(w.emb + (size_t)t * E, Tv * E, E, 0, B);
+        s1[n1++] = make_seg(w.H1 + t * NH, H, H, E);
+        HIP_TRY(lstm_call(s1, n1, p->lstm1_W, p->lstm1_b, w.C1 + t * NH, 0, w.C1 + (t + 1) * NH, w.H1 + (t + 1) * NH,
+                          w.O1 + t * NH, w.G1 + (size_t)t * 4 * NH, N, H, keep, ids, 256u + (uint32_t)t, -1, st));
+        // LSTM2 (tf_s2vt.py:122 encode with the zero padding, :143 decode with the previous word)
+        ASeg s2[3];
+        int n2 = 0;
+        s2[n2++] = make_seg(w.O1 + t * NH, H, H, 0);
+        if (t >= Tv) s2[n2++] = make_seg(p->Wemb, E, E, H, 0, w.prev + (size_t)(t - Tv) * N);
+        s2[n2++] = make_seg(w.H2 + t * NH, H, H, H + E);
+        HIP_TRY(lstm_call(s2, n2, p->lstm2_W, p->lstm2_b, w.C2 + t * NH, 0, w.C2 + (t + 1) * NH, w.H2 + (t + 1) * NH,
+                          w.O2 + t * NH, w.G2 + (size_t)t * 4 * NH, N, H, keep, ids, 512u + (uint32_t)t, -1, st));
+    }
+    // vocab logits for all Tc steps at once (tf_s2vt.py:153): rows t*N + n
+    ASeg so = make_seg(w.O2 + (size_t)Tv * NH, H, H, 0);
+    HIP_TRY(store_call(&so, 1, p->embed_word_W, V, p->embed_word_b, logits, V, Tc * N, V, 0, -1, st));
+    return S2VT_OK;
+}
+
+int s2vt_softmax_nll_fwd_bwd(float* logits, int32_t ld, int32_t R, int32_t V, const int32_t* target, const float* coef,
+                             float smoothing, float* nll, float* lp_target, s2vt_stream stream)
+{
+    if (!logits || !target || !coef || R < 0 || V <= 0 || ld < V) return S2VT_E_BADARG;
+    HIP_TRY(launch_softmax_nll(logits, ld, R, V, target, coef, smoothing, nll, lp_target, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
+                  int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
+                  const int32_t* sample_id, void* workspace, size_t workspace_bytes, s2vt_stream stream)
+{
+    if (!dims_ok(d) || !params_ok(p) || !params_ok(grads) || !video || !dlogits || !workspace || B <= 0 || N <= 0 || N % B)
+        return S2VT_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
+    const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, D = d->dim_image, Tv = d->n_video_lstm_step,
+              Tc = d->n_caption_lstm_step;
+    const int T = Tv + Tc;
+    Carver c(workspace, workspace_bytes);
+    TrainWs w;
+    carve_train(c, d, B, N, &w);
+    if (!c.ok()) return S2VT_E_WORKSPACE;
+    hipStream_t st = S(stream);
+    const size_t NH = (size_t)N * H;
+    const int K2 = 2 * H + E, K1 = E + H;
+
+    // transposed weight copies for the data-gradient products
+    HIP_TRY(launch_transpose(p->embed_word_W, V, w.WoutT, H, H, V, st));
+    HIP_TRY(launch_transpose(p->lstm2_W, 4 * H, w.W2T, K2, K2, 4 * H, st));
+    HIP_TRY(launch_transpose(p->lstm1_W, 4 * H, w.W1T, K1, K1, 4 * H, st));
+
+    // ---- vocab projection
+    {
+        TnArgs a{w.O2 + (size_t)Tv * NH, nullptr, H, dlogits, V, grads->embed_word_W, V, Tc * N, H, V, 1};
+        HIP_TRY(launch_gemm_tn(a, st));
+        HIP_TRY(launch_colsum(dlogits, V, Tc * N, V, grads->embed_word_b, st));
+        HIP_TRY(nn_bwd(dlogits, V, w.WoutT, H, w.dO2, H, Tc * N, H, V, 1, 0, st));
+    }
+    // ---- LSTM2 back through time
+    const int kper = ((4 * H + kSlabs - 1) / kSlabs + BK - 1) / BK * BK;
+    const int nslab = (4 * H + kper - 1) / kper;     // what nn_bwd(..., kSlabs, ...) produces
+    for (int t = T - 1; t >= 0; --t) {
+        HIP_TRY(launch_lstm_bwd_pointwise(w.G2 + (size_t)t * 4 * NH, w.C2 + (t + 1) * NH, w.C2 + t * NH,
+                                          t == T - 1 ? nullptr : w.slab, nslab, NH,
+                                          t >= Tv ? w.dO2 + (size_t)(t - Tv) * NH : nullptr, H, t == T - 1 ? nullptr : w.dc,
+                                          w.dc, w.dZ2 + (size_t)t * 4 * NH, N, H, keep, seed, 512u + (uint32_t)t, video_id,
+                                          sample_id, st));
+        if (t > 0) {
+            HIP_TRY(nn_bwd(w.dZ2 + (size_t)t * 4 * NH, 4 * H, w.W2T + (H + E), K2, w.slab, H, N, H, 4 * H, kSlabs, NH, st));
+        }
+    }
+    // d[out1 ; embed] for every step at once
+    HIP_TRY(nn_bwd(w.dZ2, 4 * H, w.W2T, K2, w.dX2, H + E, T * N, H + E, 4 * H, 1, 0, st));
+    // ---- LSTM1 back through time
+    for (int t = T - 1; t >= 0; --t) {
+        HIP_TRY(launch_lstm_bwd_pointwise(w.G1 + (size_t)t * 4 * NH, w.C1 + (t + 1) * NH, w.C1 + t * NH,
+                                          t == T - 1 ? nullptr : w.slab, nslab, NH, w.dX2 + (size_t)t * N * (H + E), H + E,
+                                          t == T - 1 ? nullptr : w.dc, w.dc, w.dZ1 + (size_t)t * 4 * NH, N, H, keep, seed,
+                                          256u + (uint32_t)t, video_id, sample_id, st));
+        if (t > 0) HIP_TRY(nn_bwd(w.dZ1 + (size_t)t * 4 * NH, 4 * H, w.W1T + E, K1, w.slab, H, N, H, 4 * H, kSlabs, NH, st));
+    }
+    HIP_TRY(nn_bwd(w.dZ1, 4 * H, w.W1T, K1, w.dX1, E, Tv * N, E, 4 * H, 1, 0, st));
+
+    // ---- weight gradients: one contraction over all unrolled steps per weight block
+    {
+        TnArgs a{w.O1, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W, 4 * H, T * N, H, 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(a, st));
+        TnArgs b{p->Wemb, w.prev, E, w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, grads->lstm2_W + (size_t)H * 4 * H, 4 * H, Tc * N, E,
+                 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(b, st));
+        TnArgs e{w.H2, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, T * N, H, 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(e, st));
+        HIP_TRY(launch_colsum(w.dZ2, 4 * H, T * N, 4 * H, grads->lstm2_b, st));
+        TnArgs f{w.emb, w.encidx, E, w.dZ1, 4 * H, grads->lstm1_W, 4 * H, Tv * N, E, 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(f, st));
+        TnArgs g{w.H1, nullptr, H, w.dZ1, 4 * H, grads->lstm1_W + (size_t)E * 4 * H, 4 * H, T * N, H, 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(g, st));
+        HIP_TRY(launch_colsum(w.dZ1, 4 * H, T * N, 4 * H, grads->lstm1_b, st));
+        // embedding rows (gradient of tf.nn.embedding_lookup): scatter-add of the embed slice of dX2
+        HIP_TRY(launch_scatter_add_rows(w.dX2 + (size_t)Tv * N * (H + E) + H, H + E, w.prev, Tc * N, E, grads->Wemb, E, st));
+        // frame embedding
+        TnArgs h{video, w.encidx, D, w.dX1, E, grads->encode_image_W, E, Tv * N, D, E, 1};
+        HIP_TRY(launch_gemm_tn(h, st));
+        HIP_TRY(launch_colsum(w.dX1, E, Tv * N, E, grads->encode_image_b, st));
+    }
+    return S2VT_OK;
+}
+
+int s2vt_embed_scatter_add(const float* dE, int32_t ld, const int32_t* idx, int32_t R, int32_t E, float* dWemb,
+                           s2vt_stream stream)
+{
+    if (!dE || !idx || !dWemb || R < 0 || E <= 0 || ld < E) return S2VT_E_BADARG;
+    HIP_TRY(launch_scatter_add_rows(dE, ld, idx, R, E, dWemb, E, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_grad_finalize(float* g, const float* theta, int64_t n, const float* gscale, float weight_decay, float* sumsq,
+                       s2vt_stream stream)
+{
+    if (!g || !sumsq || n < 0 || (weight_decay != 0.0f && !theta)) return S2VT_E_BADARG;
+    HIP_TRY(launch_grad_finalize(g, theta, n, gscale, weight_decay, sumsq, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
+                 float lr, int64_t step, float beta1, float beta2, float eps, s2vt_stream stream)
+{
+    if (!theta || !g || !m || !v || n < 0 || step < 1) return S2VT_E_BADARG;
+    // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t), epsilon outside the bias correction
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    HIP_TRY(launch_adam_tf(theta, g, m, v, n, sumsq, clip_norm, (float)lr_t, beta1, beta2, eps, S(stream)));
+    return S2VT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+"""Host-side mirror of the reference's model class and training steps.
+
+``Video_Caption_Generator`` keeps the constructor and the ``build_*`` surface of the reference
+(tf_s2vt.py:53-266, reinforcement_multisampling_tf_s2vt.py:63-466).  The reference's methods emit
+a TF graph and return placeholders + output tensors that ``sess.run`` later evaluates; here they
+return the same tuples of lightweight handles, and ``Session.run(fetches, feed_dict)`` evaluates
+them by calling libs2vt_hip.so -- so a ``train()`` written against the reference keeps its shape
+(see INTEGRATION.md).  All arithmetic is in the HIP library; torch supplies device memory,
+streams and ``torch.distributed`` (RCCL).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import PARAM_FIELDS
+
+# TF-1.1 variable names of the reference checkpoints (optimistic_restore matches by name + shape,
+# reinforcement_multisampling_tf_s2vt.py:47-61)
+TF_NAMES = {
+    "Wemb": "Wemb", "encode_image_W": "encode_image_W", "encode_image_b": "encode_image_b",
+    "embed_word_W": "embed_word_W", "embed_word_b": "embed_word_b",
+    "lstm1_W": "s2vt/LSTM1/basic_lstm_cell/weights", "lstm1_b": "s2vt/LSTM1/basic_lstm_cell/biases",
+    "lstm2_W": "s2vt/LSTM2/basic_lstm_cell/weights", "lstm2_b": "s2vt/LSTM2/basic_lstm_cell/biases",
+    "attr_W": "attr_W", "attr_b": "attr_b",
+}
+# flat layout: variables with weight decay first (tf_s2vt.py:163: every name without 'bias' --
+# which keeps encode_image_b / embed_word_b IN), the two LSTM `biases` last
+DECAYED = ("Wemb", "encode_image_W", "encode_image_b", "lstm1_W", "lstm2_W", "embed_word_W", "embed_word_b", "attr_W", "attr_b")
+UNDECAYED = ("lstm1_b", "lstm2_b")
+
+
+def param_shapes(dim_image, n_words, word_dim, lstm_dim, label_dim=0):
+    E, H, V, D = word_dim, lstm_dim, n_words, dim_image
+    s = {"Wemb": (V, E), "encode_image_W": (D, E), "encode_image_b": (E,), "lstm1_W": (E + H, 4 * H), "lstm1_b": (4 * H,),
+         "lstm2_W": (2 * H + E, 4 * H), "lstm2_b": (4 * H,), "embed_word_W": (H, V), "embed_word_b": (V,)}
+    if label_dim:
+        s["attr_W"] = (D, label_dim)
+        s["attr_b"] = (label_dim,)
+    return s
+
+
+class ParamStore:
+    """All variables in ONE flat fp32 buffer (+ same-shaped grad / Adam m / Adam v buffers), each
+    tensor a 256-byte aligned view: the optimizer and the RCCL all-reduce run over one range."""
+
+    def __init__(self, shapes: dict, device):
+        self.shapes = shapes
+        dec = [n for n in DECAYED if n in shapes]
+        self.names = dec + [n for n in UNDECAYED if n in shapes]
+        self.offsets = {}
+        off = 0
+        for n in self.names:
+            if n == UNDECAYED[0]:
+                self.n_decayed = off
+            self.offsets[n] = off
+            off += (int(np.prod(shapes[n])) + 63) // 64 * 64
+        self.numel = off
+        # one spare slot block at the end of the gradient buffer carries sum(mask) through the all-reduce
+        self.theta = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off + 64, dtype=torch.float32, device=device)
+        self.m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.p = {n: self._view(self.theta, n) for n in self.names}
+        self.g = {n: self._view(self.grad, n) for n in self.names}
+        self.params = ops.make_params(self.p)
+        self.grads = ops.make_params(self.g)
+
+    def _view(self, flat, n):
+        k = int(np.prod(self.shapes[n]))
+        return flat[self.offsets[n]:self.offsets[n] + k].view(*self.shapes[n])
+
+    def load(self, arrays: dict):
+        for n, a in arrays.items():
+            if n in self.p:
+                self.p[n].copy_(torch.as_tensor(np.asarray(a)).to(self.p[n].device))
+
+    def state_dict(self):
+        """Checkpoint with the reference's TF variable names."""
+        return {TF_NAMES[n]: self.p[n].detach().cpu().numpy() for n in self.names}
+
+    def load_state_dict(self, sd: dict):
+        """optimistic_restore: load every variable whose NAME and SHAPE match, ignore the rest."""
+        inv = {v: k for k, v in TF_NAMES.items()}
+        loaded = []
+        for name, arr in sd.items():
+            n = inv.get(name, name)
+            if n in self.p and tuple(np.shape(arr)) == tuple(self.shapes[n]):
+                self.p[n].copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(self.p[n].device))
+                loaded.append(name)
+        return loaded
+
+
+def init_reference(store: ParamStore, seed: int = 1234):
+    """The reference initialisers (tf_s2vt.py:69-84): U(-0.1, 0.1) for Wemb / encode_image_W /
+    embed_word_W / attr_W, TF-default Glorot-uniform for the BasicLSTMCell kernels, zero biases."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for n in store.names:
+        shp = store.shapes[n]
+        if n.endswith("_b"):
+            store.p[n].zero_()
+            continue
+        a = 0.1 if not n.startswith("lstm") else math.sqrt(6.0 / (shp[0] + shp[1]))
+        store.p[n].copy_(((torch.rand(shp, generator=g) * 2 - 1) * a).to(store.p[n].device))
+
+
+# ---------------------------------------------------------------------------------------------
+# graph handles + session shim
+# ---------------------------------------------------------------------------------------------
+class Placeholder:
+    def __init__(self, name, shape, dtype):
+        self.name, self.shape, self.dtype = name, shape, dtype
+
+    def __repr__(self):
+        return f"<placeholder {self.name} {self.shape}>"
+
+
+class Output:
+    """A fetchable value: evaluated by Session.run from the fed placeholders."""
+
+    def __init__(self, name, fn, inputs):
+        self.name, self.fn, self.inputs = name, fn, inputs
+
+    def __repr__(self):
+        return f"<output {self.name}>"
+
+
+class Session:
+    """Plays sess.run(fetches, feed_dict): groups fetches by the graph call that produces them so one
+    library call serves all outputs of the same build_* graph."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def run(self, fetches, feed_dict=None):
+        single = not isinstance(fetches, (list, tuple))
+        fl = [fetches] if single else list(fetches)
+        feed = feed_dict or {}
+        cache = {}
+        out = []
+        for f in fl:
+            key = id(f.fn)
+            if key not in cache:
+                cache[key] = f.fn(*[feed[p] for p in f.inputs])
+            out.append(cache[key][f.name])
+        return out[0] if single else out
+
+
+@dataclass
+class StepStats:
+    loss: torch.Tensor          # device scalar
+    grad_sumsq: torch.Tensor    # device scalar (global norm squared, before clipping)
+    mask_sum: torch.Tensor
+
+
+class Video_Caption_Generator:
+    """Same constructor as the reference (tf_s2vt.py:54-66); `device`, `seed`, `label_dim`, `alpha`
+    are additions (the multitask scripts add label_dim / alpha, reinforce_multitask_e2e_attribute_loss.py:71-80)."""
+
+    def __init__(self, dim_image, n_words, word_dim, lstm_dim, batch_size, n_lstm_steps, n_video_lstm_step,
+                 n_caption_lstm_step, bias_init_vector=None, loss_weight=1, decay_value=0.00005, dropout_rate=0.9,
+                 label_dim=0, alpha=0.0, device="cuda", seed=1234, multisample=8):
+        self.dim_image, self.n_words, self.word_dim, self.lstm_dim = dim_image, n_words, word_dim, lstm_dim
+        self.batch_size, self.n_lstm_steps = batch_size, n_lstm_steps
+        self.n_video_lstm_step, self.n_caption_lstm_step = n_video_lstm_step, n_caption_lstm_step
+        self.loss_weight, self.decay_value, self.dropout_rate = loss_weight, decay_value, dropout_rate
+        self.label_dim, self.alpha = label_dim, alpha
+        self.multisample = multisample          # the reference hard-codes batch_size*8 in build_loss (:228)
+        self.device = torch.device(device)
+        self.dims = ops.make_dims(dim_image, n_words, word_dim, lstm_dim, n_video_lstm_step, n_caption_lstm_step, label_dim)
+        self.store = ParamStore(param_shapes(dim_image, n_words, word_dim, lstm_dim, label_dim), self.device)
+        init_reference(self.store, seed)
+        if bias_init_vector is not None:
+            self.store.p["embed_word_b"].copy_(torch.as_tensor(np.asarray(bias_init_vector, np.float32)).to(self.device))
+        self.global_step = 0
+        self.sample_seed = seed
+        self.dropout_seed = seed + 1
+        self.world_size = 1
+        self.rank = 0
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+
+    # -------------------------------------------------------------------------------- utilities
+    def _dev(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
+
+    def _row_ids(self, B, rep, video_base):
+        vid = (torch.arange(B, dtype=torch.int32, device=self.device) + video_base).repeat(rep)
+        sid = torch.arange(rep, dtype=torch.int32, device=self.device).repeat_interleave(B)
+        return vid.contiguous(), sid.contiguous()
+
+    # -------------------------------------------------------------------------------- samplers
+    def sample(self, video, K, with_greedy=True, seed=None, video_base=0):
+        """K multinomial captions per video (+ the greedy caption): (sampled [K*B,Tc], greedy [B,Tc])
+        int32 device tensors, sample-major rows.  One encode, no host round trip per step."""
+        video = self._dev(video, torch.float32)
+        return ops.sample(self.dims, self.store.params, video, K, self.sample_seed if seed is None else seed, video_base,
+                          with_greedy)
+
+    def build_sampler(self):
+        """Greedy sampler (tf_s2vt.py:217-266): returns (sampled_captions, video)."""
+        video = Placeholder("video", (None, self.n_video_lstm_step, self.dim_image), np.float32)
+
+        def fn(v):
+            _, g = self.sample(v, 0, True)
+            return {"sampled_captions": g.cpu().numpy().astype(np.int64)}
+        return Output("sampled_captions", fn, [video]), video
+
+    def build_multinomial_sampler(self):
+        """One multinomial caption per video (reinforcement_multisampling_tf_s2vt.py:294-339).
+        Every run draws from a fresh Philox stream (the TF op is stateful too)."""
+        video = Placeholder("video", (self.batch_size, self.n_video_lstm_step, self.dim_image), np.float32)
+        state = {"calls": 0}
+
+        def fn(v):
+            state["calls"] += 1
+            s, _ = self.sample(v, 1, False, seed=self.sample_seed + 7919 * state["calls"])
+            return {"sampled_captions": s.cpu().numpy().astype(np.int64)}
+        return Output("sampled_captions", fn, [video]), video
+
+    def build_generator(self, beam_size=1, length_normalization_factor=0.5):
+        """B=1 greedy generator (tf_s2vt.py:169-214): (video, sentence, probs) where sentence is a
+        list of Tc scalar fetches (the reference's `break` at :212 never fires)."""
+        video = Placeholder("video", (1, self.n_video_lstm_step, self.dim_image), np.float32)
+
+        def fn(v):
+            _, g = self.sample(v, 0, True)
+            ids = g.cpu().numpy().astype(np.int64)[0]
+            return {f"word_{t}": ids[t] for t in range(self.n_caption_lstm_step)}
+        sentence = [Output(f"word_{t}", fn, [video]) for t in range(self.n_caption_lstm_step)]
+        return video, sentence, []
+
+    # -------------------------------------------------------------------------------- training graphs
+    def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep):
+        """Teacher-forced forward + softmax-NLL fwd/bwd.  caption [N,Tc] int32 device, coef_tm
+        time-major [Tc*N].  Leaves dlogits + activations ready for backward()."""
+        B = video.shape[0]
+        N = caption.shape[0]
+        vid, sid = self._row_ids(B, rep, video_base)
+        seed = self.dropout_seed + 104729 * self.global_step
+        logits, ws = ops.teacher_forced_fwd(self.dims, self.store.params, video, caption, N, keep, seed, vid, sid)
+        target = caption.t().contiguous().view(-1)
+        nll, lp = ops.softmax_nll_fwd_bwd(logits, target, coef_tm, smoothing)
+        self._ctx = (video, N, logits, ws, keep, seed, vid, sid)
+        return nll, lp
+
+    def backward(self):
+        video, N, dlogits, ws, keep, seed, vid, sid = self._ctx
+        self.store.grad.zero_()
+        ops.bptt_bwd(self.dims, self.store.params, self.store.grads, video, N, dlogits, ws, keep, seed, vid, sid)
+
+    def apply_gradients(self, mask_sum, lr, clip_norm, weight_decay=0.0):
+        """All-reduce (RCCL, one flat bucket + sum(mask) in its tail), 1/sum(mask), weight decay,
+        tf.clip_by_global_norm, TF-form Adam (reinforcement_multisampling_tf_s2vt.py:643-652)."""
+        st = self.store
+        st.grad[st.numel] = mask_sum
+        if self.world_size > 1:
+            torch.distributed.all_reduce(st.grad)
+        torch.reciprocal(st.grad[st.numel:st.numel + 1], out=self._gscale)
+        self._sumsq.zero_()
+        nd = st.n_decayed
+        ops.grad_finalize(st.grad[:nd], st.theta[:nd], self._gscale, weight_decay, self._sumsq)
+        ops.grad_finalize(st.grad[nd:st.numel], st.theta[nd:], self._gscale, 0.0, self._sumsq)
+        self.global_step += 1
+        ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, self._sumsq, clip_norm, lr, self.global_step)
+
+    def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None):
+        """build_loss + the REINFORCE objective and train_op of train()
+        (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc],
+        rewards / baseline [N], rows sample-major over the B videos."""
+        video = self._dev(video, torch.float32)
+        cap = self._dev(sampled, torch.int32)
+        mask = self._dev(mask, torch.float32)
+        adv = self._dev(rewards, torch.float32) - self._dev(baseline, torch.float32)
+        rep = cap.shape[0] // video.shape[0]
+        coef = (mask * adv[:, None]).t().contiguous().view(-1)
+        keep = self.dropout_rate if keep is None else keep
+        nll, _ = self._forward_loss(video, cap, coef, 0.0, rep, video_base, keep)
+        msum = mask.sum()
+        loss_local = torch.dot(coef, nll)
+        self.backward()
+        self.apply_gradients(msum, lr, clip_norm)
+        return StepStats(loss_local / msum, self._sumsq.clone(), msum)
+
+    def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, q1=True, smoothing=0.05, video_base=0, keep=None):
+        """build_model + train_op of tf_s2vt.py:90-167,445-448 (label smoothing 0.05, Q1 batch-mean
+        semantics, weight decay on the non-'bias' variables, clip 10)."""
+        video = self._dev(video, torch.float32)
+        cap = self._dev(caption, torch.int32)
+        mask = self._dev(caption_mask, torch.float32)
+        N = cap.shape[0]
+        colsum = mask.sum(0)
+        n_glob = float(N * self.world_size)
+        if q1:
+            if self.world_size > 1:
+                torch.distributed.all_reduce(colsum)
+            coef = (colsum[:, None] / n_glob).expand(-1, N) * self.loss_weight
+        else:
+            coef = mask.t() * self.loss_weight
+        coef = coef.contiguous().view(-1)
+        keep = self.dropout_rate if keep is None else keep
+        nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep)
+        msum = mask.sum()
+        loss_local = torch.dot(coef, nll)
+        self.backward()
+        self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value)
+        return StepStats(loss_local / msum, self._sumsq.clone(), msum)
+
+    def build_model(self):
+        """(loss, video, caption, caption_mask, probs) as tf_s2vt.py:90-167.  Fetching `loss`
+        evaluates the forward only; `train_op` (see make_train_op) also updates the variables."""
+        B, Tc = self.batch_size, self.n_caption_lstm_step
+        video = Placeholder("video", (B, self.n_video_lstm_step, self.dim_image), np.float32)
+        caption = Placeholder("caption", (B, Tc), np.int32)
+        caption_mask = Placeholder("caption_mask", (B, Tc), np.float32)
+
+        def fn(v, c, m):
+            v = self._dev(v, torch.float32); c = self._dev(c, torch.int32); m = self._dev(m, torch.float32)
+            coef = ((m.sum(0)[:, None] / float(c.shape[0])).expand(-1, c.shape[0]) * self.loss_weight).contiguous().view(-1)
+            vid, sid = self._row_ids(v.shape[0], 1, 0)
+            seed = self.dropout_seed + 104729 * self.global_step
+            logits, _ = ops.teacher_forced_fwd(self.dims, self.store.params, v, c, c.shape[0], self.dropout_rate, seed, vid, sid)
+            probs = logits.view(Tc, c.shape[0], -1).clone()
+            nll, _ = ops.softmax_nll_fwd_bwd(logits, c.t().contiguous().view(-1), coef, 0.05)
+            wd = sum(0.5 * float((self.store.p[n] ** 2).sum()) for n in self.store.names if n not in UNDECAYED)
+            loss = float(torch.dot(coef, nll) / m.sum()) + self.decay_value * wd
+            return {"loss": loss, "probs": probs.cpu().numpy()}
+        return Output("loss", fn, [video, caption, caption_mask]), video, caption, caption_mask, Output("probs", fn, [video, caption, caption_mask])
+
+    def build_loss(self):
+        """(loss, video, caption, caption_mask) as reinforcement_multisampling_tf_s2vt.py:227-292.
+        The reference returns the dense [N,Tc,V] tensor log_softmax*onehot*mask; it has one non-zero
+        per (n,t), so the fetch here is the [N,Tc] array of those values (lp * mask)."""
+        N, Tc = self.batch_size * self.multisample, self.n_caption_lstm_step
+        video = Placeholder("video", (N, self.n_video_lstm_step, self.dim_image), np.float32)
+        caption = Placeholder("caption", (N, Tc), np.int32)
+        caption_mask = Placeholder("caption_mask", (N, Tc), np.float32)
+
+        def fn(v, c, m):
+            v = self._dev(v, torch.float32); c = self._dev(c, torch.int32); m = self._dev(m, torch.float32)
+            B = v.shape[0] // self.multisample if v.shape[0] == c.shape[0] else v.shape[0]
+            v = v[:B].contiguous()                                  # rows k*B+j repeat video j (:779-782)
+            vid, sid = self._row_ids(B, c.shape[0] // B, 0)
+            seed = self.dropout_seed + 104729 * self.global_step
+            logits, _ = ops.teacher_forced_fwd(self.dims, self.store.params, v, c, c.shape[0], self.dropout_rate, seed, vid, sid)
+            zero = torch.zeros(logits.shape[0], dtype=torch.float32, device=self.device)
+            _, lp = ops.softmax_nll_fwd_bwd(logits, c.t().contiguous().view(-1), zero, 0.0)
+            return {"loss": (lp.view(Tc, -1).t() * m).cpu().numpy()}
+        return Output("loss", fn, [video, caption, caption_mask]), video, caption, caption_mask

@@ -146,3 +146,57 @@ def sample(dims: Dims, params: Params, video, K: int, seed: int, video_base: int
     check(L.s2vt_sample(C.byref(dims), C.byref(params), _ptr(video), B, K, g, seed, video_base, _ptr(ids), _ptr(ws),
                         ws.numel(), _stream()), "s2vt_sample")
     return ids[:K * B], (ids[K * B:] if with_greedy else None)
+
+
+def train_workspace(dims: Dims, B: int, N: int, device):
+    nbytes = lib().s2vt_train_workspace_bytes(C.byref(dims), B, N)
+    assert nbytes > 0, "bad dims / B / N (N must be a multiple of B)"
+    return workspace(nbytes, device, "train")
+
+
+def teacher_forced_fwd(dims: Dims, params: Params, video, caption, N: int, keep=1.0, seed=0, video_id=None,
+                       sample_id=None, ws=None, logits=None):
+    """Teacher-forced unroll on N = rep*B sample-major rows.  Returns time-major logits [Tc*N, V]."""
+    _chk_f32(video)
+    assert caption.is_cuda and caption.dtype == torch.int32 and caption.is_contiguous() and caption.shape[0] == N
+    B = video.shape[0]
+    if ws is None:
+        ws = train_workspace(dims, B, N, video.device)
+    if logits is None:
+        logits = torch.empty((dims.n_caption_lstm_step * N, dims.n_words), dtype=torch.float32, device=video.device)
+    check(lib().s2vt_teacher_forced_fwd(C.byref(dims), C.byref(params), _ptr(video), B, N, _ptr(caption), float(keep), seed,
+                                        _ptr(video_id), _ptr(sample_id), _ptr(logits), _ptr(ws), ws.numel(), _stream()),
+          "s2vt_teacher_forced_fwd")
+    return logits, ws
+
+
+def softmax_nll_fwd_bwd(logits, target, coef, smoothing=0.0):
+    """In place: logits <- coef * (softmax - q).  Returns (nll [R], lp_target [R])."""
+    _chk_f32(logits, coef)
+    R, V = logits.shape
+    assert target.dtype == torch.int32 and target.is_cuda and target.numel() == R and coef.numel() == R
+    nll = torch.empty(R, dtype=torch.float32, device=logits.device)
+    lp = torch.empty_like(nll)
+    check(lib().s2vt_softmax_nll_fwd_bwd(_ptr(logits), logits.stride(0), R, V, _ptr(target), _ptr(coef), float(smoothing),
+                                         _ptr(nll), _ptr(lp), _stream()), "s2vt_softmax_nll_fwd_bwd")
+    return nll, lp
+
+
+def bptt_bwd(dims: Dims, params: Params, grads: Params, video, N: int, dlogits, ws, keep=1.0, seed=0, video_id=None,
+             sample_id=None):
+    _chk_f32(video, dlogits)
+    check(lib().s2vt_bptt_bwd(C.byref(dims), C.byref(params), C.byref(grads), _ptr(video), video.shape[0], N, _ptr(dlogits),
+                              float(keep), seed, _ptr(video_id), _ptr(sample_id), _ptr(ws), ws.numel(), _stream()),
+          "s2vt_bptt_bwd")
+
+
+def grad_finalize(g, theta, gscale, weight_decay, sumsq):
+    _chk_f32(g, theta, gscale, sumsq)
+    check(lib().s2vt_grad_finalize(_ptr(g), _ptr(theta), g.numel(), _ptr(gscale), float(weight_decay), _ptr(sumsq), _stream()),
+          "s2vt_grad_finalize")
+
+
+def adam_tf(theta, g, m, v, sumsq, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    _chk_f32(theta, g, m, v, sumsq)
+    check(lib().s2vt_adam_tf(_ptr(theta), _ptr(g), _ptr(m), _ptr(v), theta.numel(), _ptr(sumsq), float(clip_norm), float(lr),
+                             int(step), beta1, beta2, eps, _stream()), "s2vt_adam_tf")
