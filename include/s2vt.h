@@ -71,6 +71,23 @@ int s2vt_version(void);
 int s2vt_last_hip_error(void);
 const char* s2vt_error_string(int code);
 
+/* ---- launch profiler (measurement only; bench.py's roofline leg) ---------------------------------
+ * While enabled, every contraction launch is bracketed by two hipEvents recorded on the stream the
+ * kernel is launched on and tallied per (kernel class, tile configuration) with its flops
+ * (2*M*K*N of that launch, structural-zero segments excluded).  Call s2vt_prof_collect only after
+ * synchronising the stream(s); it returns the number of rows written and resets the tally.
+ * kernel_class: 0 = STORE contraction, 1 = fused LSTM cell, 2 = vocab logits + pick, 3 = TN weight grad. */
+typedef struct s2vt_prof_row {
+    int32_t kernel_class;
+    int32_t tile_cfg;
+    int64_t launches;
+    double total_ms;
+    double total_flops;
+    char name[32];
+} s2vt_prof_row;
+int s2vt_prof_enable(int on);
+int s2vt_prof_collect(s2vt_prof_row* rows, int max_rows);
+
 /* ---- test hook: evaluate the contract's scalar functions on the device --------------------
  * fn: 0 exp, 1 log, 2 tanh, 3 sigmoid.  y[i] = fn(x[i]).  (Bitwise comparison with the oracle.) */
 int s2vt_math_eval(int fn, const float* x, float* y, int64_t n, s2vt_stream stream);

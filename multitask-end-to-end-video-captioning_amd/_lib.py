@@ -26,6 +26,11 @@ class Params(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
 
 
+class ProfRow(C.Structure):
+    _fields_ = [("kernel_class", C.c_int32), ("tile_cfg", C.c_int32), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("total_flops", C.c_double), ("name", C.c_char * 32)]
+
+
 class Operand(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("rowidx", C.c_void_p), ("ld", C.c_int32), ("k", C.c_int32), ("rowmod", C.c_int32),
                 ("reserved", C.c_int32)]
@@ -43,6 +48,8 @@ SIGNATURES = {
     "s2vt_version": (C.c_int, []),
     "s2vt_last_hip_error": (C.c_int, []),
     "s2vt_error_string": (C.c_char_p, [C.c_int]),
+    "s2vt_prof_enable": (C.c_int, [C.c_int]),
+    "s2vt_prof_collect": (C.c_int, [C.POINTER(ProfRow), C.c_int]),
     "s2vt_math_eval": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp]),
     "s2vt_gumbel_eval": (C.c_int, [_u64, _i32, _i32, _i32, _vp, _i32, _vp]),
     "s2vt_gemm": (C.c_int, [_OP, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

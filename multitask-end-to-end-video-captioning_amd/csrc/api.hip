@@ -70,6 +70,26 @@ const char* s2vt_error_string(int code)
     }
 }
 
+int s2vt_prof_enable(int on)
+{
+    prof_enable(on != 0);
+    return S2VT_OK;
+}
+
+int s2vt_prof_collect(s2vt_prof_row* rows, int max_rows)
+{
+    if (!rows || max_rows <= 0) return S2VT_E_BADARG;
+    ProfRow tmp[64];
+    const int n = prof_collect(tmp, max_rows < 64 ? max_rows : 64);
+    for (int i = 0; i < n; ++i) {
+        rows[i].kernel_class = tmp[i].cls; rows[i].tile_cfg = tmp[i].cfg; rows[i].launches = tmp[i].launches;
+        rows[i].total_ms = tmp[i].ms; rows[i].total_flops = tmp[i].flops;
+        std::strncpy(rows[i].name, tmp[i].name, sizeof(rows[i].name) - 1);
+        rows[i].name[sizeof(rows[i].name) - 1] = 0;
+    }
+    return n;
+}
+
 int s2vt_math_eval(int fn, const float* x, float* y, int64_t n, s2vt_stream stream)
 {
     if (!x || !y || n < 0 || fn < 0 || fn > 3) return S2VT_E_BADARG;

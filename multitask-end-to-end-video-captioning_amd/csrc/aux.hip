@@ -382,7 +382,18 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     }
     const bool vec = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0 && (a.lda & 3) == 0 &&
                      (a.ldb & 3) == 0 && (a.Kout & 3) == 0 && (a.N & 3) == 0;
+    if (!prof_on()) {
+        hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
+        return hipGetLastError();
+    }
+    hipEvent_t e0, e1;
+    hipError_t pe = prof_events(&e0, &e1);
+    if (pe != hipSuccess) return pe;
+    static const char* names[] = {"tn128x128(2x2)", "tn64x128(2x2)", "tn64x64(2x2)"};
+    (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
+    (void)hipEventRecord(e1, st);
+    prof_record(3, ci, names[ci], 2.0 * a.Mred * (double)a.Kout * a.N, e0, e1);
     return hipGetLastError();
 }
 

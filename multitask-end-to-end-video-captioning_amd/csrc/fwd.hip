@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <vector>
 
 #include "internal.h"
 
@@ -92,6 +93,13 @@ int choose(const CfgEntry* t, int n, int M, int N)
 
 std::once_flag g_attr_once;
 
+// ---- launch profiler state
+struct Pending { int cls, cfg; const char* name; double flops; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_event_pool;
+
 void set_lds_attrs()
 {
     for (int epi = 0; epi < 3; ++epi) {
@@ -107,6 +115,59 @@ void set_lds_attrs()
 }
 
 }  // namespace
+
+void prof_enable(bool on)
+{
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    g_prof_on = on;
+}
+bool prof_on() { return g_prof_on; }
+
+hipError_t prof_events(hipEvent_t* e0, hipEvent_t* e1)
+{
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    hipEvent_t* out[2] = {e0, e1};
+    for (int i = 0; i < 2; ++i) {
+        if (!g_event_pool.empty()) {
+            *out[i] = g_event_pool.back();
+            g_event_pool.pop_back();
+        } else {
+            hipError_t e = hipEventCreate(out[i]);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+void prof_record(int cls, int cfg, const char* name, double flops, hipEvent_t e0, hipEvent_t e1)
+{
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    g_pending.push_back(Pending{cls, cfg, name, flops, e0, e1});
+}
+
+int prof_collect(ProfRow* rows, int max_rows)
+{
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    int n = 0;
+    for (const Pending& p : g_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) ms = 0.f;
+        int i = 0;
+        for (; i < n; ++i)
+            if (rows[i].cls == p.cls && rows[i].cfg == p.cfg) break;
+        if (i == n) {
+            if (n == max_rows) continue;
+            rows[n++] = ProfRow{p.cls, p.cfg, 0, 0.0, 0.0, p.name};
+        }
+        rows[i].launches += 1;
+        rows[i].ms += ms;
+        rows[i].flops += p.flops;
+        g_event_pool.push_back(p.e0);
+        g_event_pool.push_back(p.e1);
+    }
+    g_pending.clear();
+    return n;
+}
 
 int gemm_num_cfgs(int epi)
 {
@@ -132,7 +193,21 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     const dim3 grid((unsigned)(ceil_div(a.M, e.BM) * ceil_div(a.N, e.CG)), (unsigned)(a.splits > 1 ? a.splits : 1), 1);
     KernelFn fn = can_vec(a) ? e.vec : e.scalar;
+    if (!g_prof_on) {
+        hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a);
+        return hipGetLastError();
+    }
+    hipEvent_t e0, e1;
+    hipError_t pe = prof_events(&e0, &e1);
+    if (pe != hipSuccess) return pe;
+    double ksum = 0.0;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].ptr && a.seg[s].k > 0) ksum += a.seg[s].k;
+    const double cols = (double)a.N * (epi == EPI_LSTM ? 4 : 1);
+    (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a);
+    (void)hipEventRecord(e1, st);
+    prof_record(epi, cfg, e.name, 2.0 * a.M * ksum * cols, e0, e1);
     return hipGetLastError();
 }
 

@@ -10,6 +10,16 @@ namespace s2vt {
 // forward contraction (exact ascending-k chain); epi in {EPI_STORE, EPI_LSTM, EPI_PICK}.
 // cfg < 0: pick a tile configuration from the shape; >= 0 forces table entry `cfg` (tests, tuning).
 hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st);
+
+// ---- in-library launch profiler (bench.py's roofline leg): when enabled, every contraction launch
+// is bracketed by two hipEvents ON ITS OWN STREAM and tallied per (class, tile cfg) with its flops.
+// class: 0 STORE, 1 LSTM, 2 PICK, 3 TN.  Collect only after the stream has been synchronised.
+struct ProfRow { int cls, cfg; long launches; double ms, flops; const char* name; };
+void prof_enable(bool on);
+bool prof_on();
+void prof_record(int cls, int cfg, const char* name, double flops, hipEvent_t e0, hipEvent_t e1);
+hipError_t prof_events(hipEvent_t* e0, hipEvent_t* e1);
+int prof_collect(ProfRow* rows, int max_rows);
 int gemm_num_cfgs(int epi);
 const char* gemm_cfg_name(int epi, int cfg);
 

@@ -200,3 +200,17 @@ def adam_tf(theta, g, m, v, sumsq, clip_norm, lr, step, beta1=0.9, beta2=0.999, 
     _chk_f32(theta, g, m, v, sumsq)
     check(lib().s2vt_adam_tf(_ptr(theta), _ptr(g), _ptr(m), _ptr(v), theta.numel(), _ptr(sumsq), float(clip_norm), float(lr),
                              int(step), beta1, beta2, eps, _stream()), "s2vt_adam_tf")
+
+
+def prof_enable(on: bool):
+    check(lib().s2vt_prof_enable(1 if on else 0), "s2vt_prof_enable")
+
+
+def prof_collect():
+    """Rows of the launch profiler (call after torch.cuda.synchronize())."""
+    rows = (_lib.ProfRow * 64)()
+    n = lib().s2vt_prof_collect(rows, 64)
+    if n < 0:
+        check(n, "s2vt_prof_collect")
+    return [dict(kernel_class=r.kernel_class, tile_cfg=r.tile_cfg, launches=r.launches, total_ms=r.total_ms,
+                 total_flops=r.total_flops, name=r.name.decode()) for r in rows[:n]]
