@@ -200,6 +200,30 @@ int s2vt_grad_finalize(float* g, const float* theta, int64_t n, const float* gsc
 int s2vt_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
                  float lr, int64_t step, float beta1, float beta2, float eps, s2vt_stream stream);
 
+/* ---- temporal attention, one decode step (original_attention.py:106-128) ----------------------
+ * Inputs: hWa [B,H] = h_prev @ embed_att_Wa (s2vt_gemm); P [Tv,B,H] = Vt @ embed_att_Ua + ba (hoisted,
+ * :107); Vt [Tv,B,H] frame embeddings; w [H] = embed_att_w.
+ *   scores[t,b] = sum_h tanh(hWa[b,h] + P[t,b,h]) * w[h]            (:113-115)
+ *   alpha[t,b]  = exp(scores) / (sum_t exp(scores) (+1 if that sum is 0))   (:116-121, no max shift)
+ *   ctx[b,h]    = sum_t alpha[t,b] * Vt[t,b,h]                       (:127-128)
+ * Backward: given dctx [B,H] returns dhWa [B,H], dP [Tv,B,H], dVt [Tv,B,H] (the context path only;
+ * add dP @ Ua^T upstream) and ACCUMULATES dw [H].  de_scratch: [Tv*B] floats. */
+int s2vt_attention_fwd(const float* hWa, const float* P, const float* Vt, const float* w, float* scores, float* alpha,
+                       float* ctx, int32_t Tv, int32_t B, int32_t H, s2vt_stream stream);
+int s2vt_attention_bwd(const float* hWa, const float* P, const float* Vt, const float* w, const float* alpha,
+                       const float* dctx, float* de_scratch, float* dhWa, float* dP, float* dVt, float* dw, int32_t Tv,
+                       int32_t B, int32_t H, s2vt_stream stream);
+
+/* ---- multitask attribute head (reinforce_multitask_e2e_attribute_loss.py:375-380, 606-626) -----
+ * mean_feat[b,:] = mean_t video[b,t,:]; z = mean_feat @ attr_W + attr_b;
+ * bce = max(z,0) - z*y + log(1+exp(-|z|))  (tf.nn.sigmoid_cross_entropy_with_logits); labels/bce optional.
+ * Backward: dz = scale * (sigmoid(z) - y); d_attr_W += mean_feat^T dz; d_attr_b += colsum(dz)
+ * (scale = alpha / (A * B_global) for the normalised multilabel loss at :379,957). */
+int s2vt_attr_head_fwd(const float* video, int32_t B, int32_t Tv, int32_t D, const float* attr_W, const float* attr_b,
+                       int32_t A, const float* labels, float* mean_feat, float* z, float* bce, s2vt_stream stream);
+int s2vt_attr_head_bwd(const float* mean_feat, const float* z, const float* labels, int32_t B, int32_t D, int32_t A,
+                       float scale, float* dz_scratch, float* d_attr_W, float* d_attr_b, s2vt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

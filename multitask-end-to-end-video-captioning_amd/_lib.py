@@ -66,6 +66,10 @@ SIGNATURES = {
     "s2vt_embed_scatter_add": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "s2vt_grad_finalize": (C.c_int, [_vp, _vp, _i64, _vp, _f32, _vp, _vp]),
     "s2vt_adam_tf": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _i64, _f32, _f32, _f32, _vp]),
+    "s2vt_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "s2vt_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "s2vt_attr_head_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "s2vt_attr_head_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -1,0 +1,36 @@
+"""Data-parallel plumbing (NEW capability; the reference is single-GPU).
+
+One process per GPU, full parameter replica.  Videos are the independent units: rank r takes
+videos [r*B_loc, (r+1)*B_loc) and keeps its K samples local; the noise counters carry GLOBAL video
+indices so 1 GPU x B and n GPUs x B/n draw the same tokens.  The only exchange per step is ONE
+all-reduce (RCCL over xGMI when the backend is "nccl") of the flat, UNNORMALISED gradient bucket
+with sum(mask) riding in its tail slot; every rank then applies 1/sum(mask), weight decay, the
+global-norm clip and Adam identically, so no broadcast is needed.  These helpers are pure torch:
+they are exercised on CPU with the gloo backend in tests/test_dp_gloo.py.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_videos: int, rank: int, world: int):
+    """Contiguous shard of the global batch for this rank (requires n_videos % world == 0)."""
+    assert n_videos % world == 0, "global batch must divide evenly over the ranks"
+    per = n_videos // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_bucket(grad_flat: torch.Tensor, n_params: int, local_mask_sum, group=None):
+    """In place: grad_flat[:n_params] <- sum over ranks, returns the GLOBAL sum(mask) as a 1-element
+    view of the bucket's tail slot (so one collective carries both)."""
+    grad_flat[n_params] = local_mask_sum
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(grad_flat, op=dist.ReduceOp.SUM, group=group)
+    return grad_flat[n_params:n_params + 1]
+
+
+def allreduce_small(t: torch.Tensor, group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

@@ -16,6 +16,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
+from . import dist as dp
 from . import ops
 from ._lib import PARAM_FIELDS
 
@@ -183,6 +184,7 @@ class Video_Caption_Generator:
         self.rank = 0
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+        self._ascale = torch.ones(1, dtype=torch.float32, device=self.device)
 
     # -------------------------------------------------------------------------------- utilities
     def _dev(self, a, dtype):
@@ -255,38 +257,59 @@ class Video_Caption_Generator:
         self.store.grad.zero_()
         ops.bptt_bwd(self.dims, self.store.params, self.store.grads, video, N, dlogits, ws, keep, seed, vid, sid)
 
-    def apply_gradients(self, mask_sum, lr, clip_norm, weight_decay=0.0):
+    def apply_gradients(self, mask_sum, lr, clip_norm, weight_decay=0.0, attr_scale=None):
         """All-reduce (RCCL, one flat bucket + sum(mask) in its tail), 1/sum(mask), weight decay,
-        tf.clip_by_global_norm, TF-form Adam (reinforcement_multisampling_tf_s2vt.py:643-652)."""
+        tf.clip_by_global_norm, TF-form Adam (reinforcement_multisampling_tf_s2vt.py:643-652).
+        attr_scale: constant normaliser of the attribute-head gradients (their range of the bucket is
+        touched by the multilabel loss only, so it is finalised with its own scale)."""
         st = self.store
-        st.grad[st.numel] = mask_sum
-        if self.world_size > 1:
-            torch.distributed.all_reduce(st.grad)
-        torch.reciprocal(st.grad[st.numel:st.numel + 1], out=self._gscale)
+        gsum = dp.allreduce_bucket(st.grad, st.numel, mask_sum)
+        torch.reciprocal(gsum, out=self._gscale)
         self._sumsq.zero_()
         nd = st.n_decayed
-        ops.grad_finalize(st.grad[:nd], st.theta[:nd], self._gscale, weight_decay, self._sumsq)
+        a0 = st.offsets.get("attr_W", nd)
+        ops.grad_finalize(st.grad[:a0], st.theta[:a0], self._gscale, weight_decay, self._sumsq)
+        if a0 < nd:
+            self._ascale.fill_(1.0 if attr_scale is None else float(attr_scale))
+            ops.grad_finalize(st.grad[a0:nd], st.theta[a0:nd], self._ascale, weight_decay, self._sumsq)
         ops.grad_finalize(st.grad[nd:st.numel], st.theta[nd:], self._gscale, 0.0, self._sumsq)
         self.global_step += 1
         ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, self._sumsq, clip_norm, lr, self.global_step)
 
-    def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None):
+    def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
+                         true_labels=None):
         """build_loss + the REINFORCE objective and train_op of train()
         (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc],
-        rewards / baseline [N], rows sample-major over the B videos."""
+        rewards / baseline [N], rows sample-major over the B videos.
+        With true_labels [B, label_dim] the multitask objective of
+        reinforce_multitask_e2e_attribute_loss.py:957 is used instead:
+            -(1-alpha) * PG / sum(mask) + alpha * sum(bce) / (label_dim * B)."""
         video = self._dev(video, torch.float32)
         cap = self._dev(sampled, torch.int32)
         mask = self._dev(mask, torch.float32)
         adv = self._dev(rewards, torch.float32) - self._dev(baseline, torch.float32)
         rep = cap.shape[0] // video.shape[0]
-        coef = (mask * adv[:, None]).t().contiguous().view(-1)
+        multitask = true_labels is not None and self.label_dim > 0
+        pg_w = (1.0 - self.alpha) if multitask else 1.0
+        coef = (mask * (adv * pg_w)[:, None]).t().contiguous().view(-1)
         keep = self.dropout_rate if keep is None else keep
         nll, _ = self._forward_loss(video, cap, coef, 0.0, rep, video_base, keep)
         msum = mask.sum()
         loss_local = torch.dot(coef, nll)
         self.backward()
-        self.apply_gradients(msum, lr, clip_norm)
-        return StepStats(loss_local / msum, self._sumsq.clone(), msum)
+        attr_scale = None
+        attr_loss = None
+        if multitask:
+            y = self._dev(true_labels, torch.float32)
+            Bg = video.shape[0] * self.world_size
+            mean, z, bce = ops.attr_head_fwd(video, self.store.p["attr_W"], self.store.p["attr_b"], y)
+            ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
+            attr_scale = self.alpha / float(self.label_dim * Bg)
+            attr_loss = bce.sum() * attr_scale
+        self.apply_gradients(msum, lr, clip_norm, attr_scale=attr_scale)
+        st = StepStats(loss_local / msum, self._sumsq.clone(), msum)
+        st.attr_loss = attr_loss
+        return st
 
     def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, q1=True, smoothing=0.05, video_base=0, keep=None):
         """build_model + train_op of tf_s2vt.py:90-167,445-448 (label smoothing 0.05, Q1 batch-mean
@@ -298,8 +321,7 @@ class Video_Caption_Generator:
         colsum = mask.sum(0)
         n_glob = float(N * self.world_size)
         if q1:
-            if self.world_size > 1:
-                torch.distributed.all_reduce(colsum)
+            dp.allreduce_small(colsum)
             coef = (colsum[:, None] / n_glob).expand(-1, N) * self.loss_weight
         else:
             coef = mask.t() * self.loss_weight

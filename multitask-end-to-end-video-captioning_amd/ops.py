@@ -214,3 +214,48 @@ def prof_collect():
         check(n, "s2vt_prof_collect")
     return [dict(kernel_class=r.kernel_class, tile_cfg=r.tile_cfg, launches=r.launches, total_ms=r.total_ms,
                  total_flops=r.total_flops, name=r.name.decode()) for r in rows[:n]]
+
+
+def attention_fwd(hWa, P, Vt, w):
+    """One attention step.  hWa [B,H], P/Vt [Tv,B,H], w [H] -> (scores [Tv,B], alpha [Tv,B], ctx [B,H])."""
+    _chk_f32(hWa, P, Vt, w)
+    Tv, B, H = P.shape
+    sc = torch.empty((Tv, B), dtype=torch.float32, device=P.device)
+    al = torch.empty_like(sc)
+    ctx = torch.empty((B, H), dtype=torch.float32, device=P.device)
+    check(lib().s2vt_attention_fwd(_ptr(hWa), _ptr(P), _ptr(Vt), _ptr(w), _ptr(sc), _ptr(al), _ptr(ctx), Tv, B, H, _stream()),
+          "s2vt_attention_fwd")
+    return sc, al, ctx
+
+
+def attention_bwd(hWa, P, Vt, w, alpha, dctx, dw):
+    """Returns (dhWa, dP, dVt); accumulates into dw [H]."""
+    _chk_f32(hWa, P, Vt, w, alpha, dctx, dw)
+    Tv, B, H = P.shape
+    de = torch.empty((Tv, B), dtype=torch.float32, device=P.device)
+    dh = torch.empty_like(hWa); dP = torch.empty_like(P); dV = torch.empty_like(Vt)
+    check(lib().s2vt_attention_bwd(_ptr(hWa), _ptr(P), _ptr(Vt), _ptr(w), _ptr(alpha), _ptr(dctx), _ptr(de), _ptr(dh), _ptr(dP),
+                                   _ptr(dV), _ptr(dw), Tv, B, H, _stream()), "s2vt_attention_bwd")
+    return dh, dP, dV
+
+
+def attr_head_fwd(video, attr_W, attr_b, labels=None):
+    _chk_f32(video, attr_W, attr_b, labels)
+    B, Tv, D = video.shape
+    A = attr_W.shape[1]
+    mean = torch.empty((B, D), dtype=torch.float32, device=video.device)
+    z = torch.empty((B, A), dtype=torch.float32, device=video.device)
+    bce = torch.empty_like(z) if labels is not None else None
+    check(lib().s2vt_attr_head_fwd(_ptr(video), B, Tv, D, _ptr(attr_W), _ptr(attr_b), A, _ptr(labels), _ptr(mean), _ptr(z),
+                                   _ptr(bce), _stream()), "s2vt_attr_head_fwd")
+    return mean, z, bce
+
+
+def attr_head_bwd(mean, z, labels, scale, d_attr_W, d_attr_b):
+    _chk_f32(mean, z, labels, d_attr_W, d_attr_b)
+    B, D = mean.shape
+    A = z.shape[1]
+    dz = torch.empty_like(z)
+    check(lib().s2vt_attr_head_bwd(_ptr(mean), _ptr(z), _ptr(labels), B, D, A, float(scale), _ptr(dz), _ptr(d_attr_W),
+                                   _ptr(d_attr_b), _stream()), "s2vt_attr_head_bwd")
+    return dz
