@@ -1,0 +1,64 @@
+"""BASELINE-size checks (B=64, K=5, Tc=20, d=1536, E=500, H=1000, |V|=12000) through size-independent
+properties, plus an oracle spot check made affordable by batch-composition independence."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+B, K, TC, TV, D, E, H, V = 64, 5, 20, 5, 1536, 500, 1000, 12000
+
+
+@pytest.fixture(scope="module")
+def full(gpu):
+    import torch
+    from s2vt_amd import model as M
+    mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, seed=1234)
+    g = torch.Generator().manual_seed(1)
+    video = (torch.randn(B, TV, D, generator=g) * 0.5).abs().cuda()
+    return mdl, video
+
+
+def test_sampler_determinism_and_shard_independence(full, oracle):
+    import torch
+    mdl, video = full
+    s1, g1 = mdl.sample(video, K, True, seed=99)
+    s2, g2 = mdl.sample(video, K, True, seed=99)
+    assert torch.equal(s1, s2) and torch.equal(g1, g2)                          # pure function of (weights, video, seed)
+    s3, g3 = mdl.sample(video, K, True, seed=100)
+    assert torch.equal(g1, g3) and not torch.equal(s1, s3)                      # greedy ignores the noise stream
+    assert int(s1.min()) >= 0 and int(s1.max()) < V and s1.shape == (K * B, TC)
+    # rank r of an 8-GPU run holds videos [8r, 8r+8): same tokens as the 1-GPU batch (global counters)
+    lo, hi = 24, 32
+    ss, gs = mdl.sample(video[lo:hi].contiguous(), K, True, seed=99, video_base=lo)
+    full_rows = s1.view(K, B, TC)[:, lo:hi].reshape(-1, TC)
+    assert torch.equal(ss, full_rows) and torch.equal(gs, g1[lo:hi])
+    # oracle spot check on two videos of the full batch
+    p = {n: mdl.store.p[n].cpu().numpy() for n in mdl.store.names}
+    d = oracle.Dims(D, V, E, H, TV, TC, 0)
+    rs, rg = oracle.sample_captions(p, d, video[10:12].cpu().numpy(), K, seed=99, video_base=10)
+    assert np.array_equal(s1.view(K, B, TC)[:, 10:12].reshape(-1, TC).cpu().numpy(), rs)
+    assert np.array_equal(g1[10:12].cpu().numpy(), rg)
+
+
+def test_update_linearity_and_mask_normalisation(full):
+    """The objective is linear in (r - b): gradients scale with it; dlogits rows sum to zero; scaling
+    the mask-sum normaliser is exact.  lr = 0 keeps the variables fixed."""
+    import torch
+    mdl, video = full
+    s, _ = mdl.sample(video, K, True, seed=5)
+    is_eos = (s == 0)
+    mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()
+    g = torch.Generator().manual_seed(2)
+    r = (torch.rand(K * B, generator=g) * 2).cuda(); b = (torch.rand(B, generator=g) * 2).repeat(K).cuda()
+    step0 = mdl.global_step
+    st1 = mdl.reinforce_update(video, s, mask, r, b, lr=0.0, clip_norm=5.0)
+    g1 = mdl.store.grad[:mdl.store.numel].clone()
+    dl = mdl._ctx[2]
+    assert float(dl.sum(1).abs().max()) < 1e-4
+    mdl.global_step = step0                                                     # same dropout masks
+    st2 = mdl.reinforce_update(video, s, mask, 2 * r, 2 * b, lr=0.0, clip_norm=5.0)
+    g2 = mdl.store.grad[:mdl.store.numel]
+    assert torch.allclose(g2, 2 * g1, rtol=1e-3, atol=1e-7 * float(g1.abs().max()) + 1e-12)
+    assert abs(float(st2.loss) - 2 * float(st1.loss)) < 1e-4 * abs(float(st1.loss)) + 1e-6
+    assert abs(float(st2.grad_sumsq) - 4 * float(st1.grad_sumsq)) < 1e-2 * float(st1.grad_sumsq)
+    assert float(st1.mask_sum) == float(mask.sum()) and float(mask[:, 0].min()) == 1.0
+    mdl.global_step = step0
