@@ -37,7 +37,7 @@ class Operand(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libs2vt_hip.so")
+    return os.environ.get("S2VT_LIB") or os.path.join(_HERE, "libs2vt_hip.so")   # S2VT_LIB: dev A/B builds only
 
 
 _vp, _i32, _i64, _u32, _u64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t

@@ -1,6 +1,7 @@
 // fwd.hip -- instantiations + shape dispatch of the forward contraction kernel (gemm_mfma.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -32,7 +33,7 @@ const CfgEntry kStore[] = {
     make_entry<2, 2, 2, 4, 1, EPI_STORE>("64x128(2x2)"),
     make_entry<2, 2, 4, 4, 1, EPI_STORE>("128x128(2x2)"),
     make_entry<4, 1, 2, 2, 1, EPI_STORE>("128x32(4x1)"),
-    make_entry<2, 2, 1, 2, 1, EPI_STORE>("32x64(2x2)"),
+    make_entry<4, 1, 1, 2, 1, EPI_STORE>("64x32(4x1)"),
 };
 const CfgEntry kLstm[] = {
     make_entry<4, 1, 1, 4, 4, EPI_LSTM>("64x16u(4x1)"),
@@ -191,10 +192,14 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     if (cfg < 0 || cfg >= n) cfg = choose(t, n, a.M, a.N);
     const CfgEntry& e = t[cfg];
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
-    const dim3 grid((unsigned)(ceil_div(a.M, e.BM) * ceil_div(a.N, e.CG)), (unsigned)(a.splits > 1 ? a.splits : 1), 1);
+    const int mt = ceil_div(a.M, e.BM), nt = ceil_div(a.N, e.CG);
+    GemmArgs a2 = a;
+    a2.xcd_map = (mt <= 16 && nt >= 8) ? 1 : 0;
+    const unsigned gx = a2.xcd_map ? (unsigned)(mt * ceil_div(nt, 8) * 8) : (unsigned)(mt * nt);
+    const dim3 grid(gx, (unsigned)(a.splits > 1 ? a.splits : 1), 1);
     KernelFn fn = can_vec(a) ? e.vec : e.scalar;
     if (!g_prof_on) {
-        hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a);
+        hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a2);
         return hipGetLastError();
     }
     hipEvent_t e0, e1;
@@ -205,7 +210,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
         if (a.seg[s].ptr && a.seg[s].k > 0) ksum += a.seg[s].k;
     const double cols = (double)a.N * (epi == EPI_LSTM ? 4 : 1);
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a);
+    hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a2);
     (void)hipEventRecord(e1, st);
     prof_record(epi, cfg, e.name, 2.0 * a.M * ksum * cols, e0, e1);
     return hipGetLastError();

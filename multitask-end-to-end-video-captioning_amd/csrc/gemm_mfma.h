@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "detmath.h"
 
 namespace s2vt {
@@ -57,6 +59,7 @@ struct GemmArgs {
     float* C;
     int ldc;
     int act;             // 0 none, 1 tanh
+    int xcd_map;         // 1: XCD-aware tile order (set by the launcher for skinny-M shapes)
     int splits;          // >1: order-free split-K over blockIdx.y (backward data path only, nseg == 1)
     int kper;            //     K range per split (multiple of BK)
     size_t slab_stride;  //     floats between the partial-sum slabs of consecutive splits
@@ -78,6 +81,20 @@ struct GemmArgs {
     float* logits_out;          // optional [M, ldc]
 };
 
+// ---- loads the compiler does not schedule (cdna_hip_programming.md §5.7): hipcc sinks ordinary prefetch
+// loads next to their first use and drains them with vmcnt(0); issued as asm they stay where they are
+// written, and the ring is drained with a hand-counted s_waitcnt below.
+__device__ __forceinline__ void gload16(f32x4& d, const float* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC>
 struct GemmCfg {
     static constexpr int NT = 64 * WM * WN;
@@ -89,6 +106,14 @@ struct GemmCfg {
     static constexpr int A4 = (BM * (BK / 4) + NT - 1) / NT;   // float4 per thread per chunk
     static constexpr int B4 = (BK * (BN / 4) + NT - 1) / NT;
     static constexpr int LDS_FLOATS = 2 * (BM * SA + BK * SB);
+    // prefetch ring depth (chunks in flight per thread): the skinny-M kernels are bound by operand bytes
+    // in flight per CU (measured: ~3500-cycle loaded latency), so the ring is as deep as ~96 staging
+    // VGPRs allow, between 2 and 6 slots.
+#ifndef S2VT_PF_BUDGET
+#define S2VT_PF_BUDGET 48
+#endif
+    static constexpr int PF_RAW = S2VT_PF_BUDGET / (4 * (A4 + B4));
+    static constexpr int PF = PF_RAW < 2 ? 2 : (PF_RAW > 6 ? 6 : PF_RAW);
     static_assert(TN % NG == 0, "TN must split evenly over the column groups");
 };
 
@@ -98,6 +123,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, TNG = Cfg::TNG, CG = Cfg::CG, SB = Cfg::SB;
     constexpr int A4 = Cfg::A4, B4 = Cfg::B4;
+    constexpr int PF = Cfg::PF;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][BM][SA]
@@ -109,11 +135,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    // blockIdx.x walks the column tiles fastest, so workgroups that share an A row-block are launched
-    // together, and the 8 XCD L2s each see every 8th column tile of the weight matrix.
+    // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the blocks that share
+    // an L2).  For skinny-M shapes (few row tiles) every row tile of one COLUMN tile is placed on the
+    // same XCD, back to back: the weight panel W[:, tile] -- the big operand, read once per row tile --
+    // is then fetched from HBM / Infinity Cache into ONE L2 instead of into up to 8 (measured: L2 miss
+    // traffic 400 MB -> 70 MB per LSTM2 launch).  Placement is a speed choice only.
     const int ntile_n = (g.N + CG - 1) / CG;
-    const int tile_n = blockIdx.x % ntile_n;
-    const int tile_m = blockIdx.x / ntile_n;
+    const int ntile_m = (g.M + BM - 1) / BM;
+    int tile_m, tile_n;
+    if (g.xcd_map) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        tile_m = slot % ntile_m;
+        tile_n = (slot / ntile_m) * 8 + xcd;
+        if (tile_n >= ntile_n) return;
+    } else {
+        tile_n = blockIdx.x % ntile_n;
+        tile_m = blockIdx.x / ntile_n;
+    }
     const int m0 = tile_m * BM;
     const int n0 = tile_n * CG;             // within-group column offset
 
@@ -139,130 +177,170 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             acc[i][j] = v;
         }
 
-    // per-thread staging slots
-    float4 ra[A4], rb[B4];
-    const float* arow[A4];
+    // per-thread staging ring: PF chunks in flight between HBM/L2 and the LDS double buffer
+    f32x4 ra[PF][A4], rb[PF][B4];
+    unsigned pa[PF], pb[PF];       // validity bits of the ring slots (zero-fill happens when a chunk lands)
+    constexpr int LPC = A4 + B4;                                   // asm-issued loads per chunk per thread
+    constexpr int WAITN = ((PF - 1) * LPC > 63) ? 63 : (PF - 1) * LPC;
 
+    // ---- wave-uniform description of the K walk: chunk c -> (segment, offset) by scalar arithmetic
     const int kbeg = g.splits > 1 ? (int)blockIdx.y * g.kper : 0;
-    auto seg_len = [&](int sidx) {
-        const int k = g.seg[sidx].k - kbeg;
-        return g.splits > 1 ? (k < g.kper ? k : g.kper) : k;
-    };
+    int slen[3], nch[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int k = 0;
+        if (i < g.nseg && g.seg[i].ptr != nullptr) {
+            k = g.seg[i].k - kbeg;
+            if (g.splits > 1 && k > g.kper) k = g.kper;
+            if (k < 0) k = 0;
+        }
+        slen[i] = k;
+        nch[i] = (k + BK - 1) / BK;
+    }
+    const int cum0 = nch[0], cum1 = nch[0] + nch[1], nchunks = nch[0] + nch[1] + nch[2];
 
-    int s = 0;
-    while (s < g.nseg && (g.seg[s].ptr == nullptr || seg_len(s) <= 0)) ++s;
-    int kc = 0;  // chunk offset inside segment s
-
-    auto seg_rows = [&](int sidx) {
+    // Row offsets of this thread's A slots for every segment, resolved ONCE (gather / broadcast index
+    // loads happen here, never inside the pipelined loop).  -1 marks a row beyond M / an absent segment.
+    int aoff0[A4], aoff1[A4], aoff2[A4];
+    auto row_offsets = [&](int sidx, int (&ao)[A4]) {
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
             const int idx = tid + i * NT;
-            const int r = idx / (BK / 4);
-            int m = m0 + r;
-            const ASeg& sg = g.seg[sidx];
-            const float* p = nullptr;
-            if (idx < BM * (BK / 4) && m < g.M) {
+            int m = m0 + idx / (BK / 4);
+            int off = -1;
+            if (slen[sidx] > 0 && idx < BM * (BK / 4) && m < g.M) {
+                const ASeg& sg = g.seg[sidx];
                 if (sg.rowmod > 0) m %= sg.rowmod;
                 if (sg.rowidx) m = sg.rowidx[m];
                 if (sg.rowkey) m = (int)(~(uint32_t)sg.rowkey[m]);
-                p = sg.ptr + (size_t)m * sg.ld + kbeg;
+                off = m * sg.ld + kbeg;
             }
-            arow[i] = p;
+            ao[i] = off;
         }
     };
+    row_offsets(0, aoff0);
+    row_offsets(1, aoff1);
+    row_offsets(2, aoff2);
 
-    auto load_chunk = [&](int sidx, int koff) {
-        const ASeg& sg = g.seg[sidx];
-        const int sk = seg_len(sidx);
+    // Issue the global loads of chunk c into a ring slot.  UNCONDITIONAL and always safe: addresses are
+    // clamped into the segment; the validity bits zero the out-of-range elements when the chunk lands.
+    // A chunk index beyond the walk yields an all-zero chunk.
+    auto issue = [&](int c, f32x4 (&qa)[A4], f32x4 (&qb)[B4], unsigned& ma, unsigned& mb) {
+        const int cc_ = c < nchunks ? c : nchunks - 1;
+        const int sidx = (cc_ >= cum0 ? 1 : 0) + (cc_ >= cum1 ? 1 : 0);
+        const int cstart = sidx == 0 ? 0 : (sidx == 1 ? cum0 : cum1);
+        const int koff = (c - cstart) * BK;
+        const float* abase = sidx == 0 ? g.seg[0].ptr : (sidx == 1 ? g.seg[1].ptr : g.seg[2].ptr);
+        const int sk = sidx == 0 ? slen[0] : (sidx == 1 ? slen[1] : slen[2]);
+        const int kw = (sidx == 0 ? g.seg[0].kw : (sidx == 1 ? g.seg[1].kw : g.seg[2].kw)) + kbeg;
+        unsigned va = 0, vb = 0;
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
             const int idx = tid + i * NT;
             const int k = koff + (idx % (BK / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (arow[i]) {
-                if (VEC) {
-                    if (k < sk) v = *reinterpret_cast<const float4*>(arow[i] + k);
-                } else {
-                    if (k + 0 < sk) v.x = arow[i][k + 0];
-                    if (k + 1 < sk) v.y = arow[i][k + 1];
-                    if (k + 2 < sk) v.z = arow[i][k + 2];
-                    if (k + 3 < sk) v.w = arow[i][k + 3];
+            const int ro = sidx == 0 ? aoff0[i] : (sidx == 1 ? aoff1[i] : aoff2[i]);
+            if constexpr (VEC) {
+                const bool ok = ro >= 0 && k < sk;
+                gload16(qa[i], abase + (ok ? ro + k : 0));
+                va |= (ok ? 1u : 0u) << i;
+            } else {   // odd shapes (tests): ordinary compiler-scheduled loads, zero-filled right here
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = ro >= 0 && k + e < sk;
+                    const float x = abase[ok ? ro + k + e : 0];
+                    v[e] = ok ? x : 0.f;
                 }
+                qa[i] = v;
             }
-            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
             const int idx = tid + i * NT;
             const int kr = idx / (BN / 4);
-            const int c = (idx % (BN / 4)) * 4;
-            const int grp = c / CG, cc = n0 + c % CG;
+            const int col = (idx % (BN / 4)) * 4;
+            const int grp = col / CG, cc = n0 + col % CG;
             const int k = koff + kr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < BK * (BN / 4) && k < sk) {
-                const float* wp = g.W + (size_t)(sg.kw + kbeg + k) * g.ldw + grp * g.gstride + cc;
-                if (VEC) {
-                    if (cc < g.N) v = *reinterpret_cast<const float4*>(wp);
-                } else {
-                    if (cc + 0 < g.N) v.x = wp[0];
-                    if (cc + 1 < g.N) v.y = wp[1];
-                    if (cc + 2 < g.N) v.z = wp[2];
-                    if (cc + 3 < g.N) v.w = wp[3];
+            const bool kok = (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4)) && k < sk;
+            const float* wrow = g.W + (size_t)(kw + (kok ? k : 0)) * g.ldw + grp * g.gstride;
+            if constexpr (VEC) {
+                const bool ok = kok && cc < g.N;
+                gload16(qb[i], wrow + (ok ? cc : 0));
+                vb |= (ok ? 1u : 0u) << i;
+            } else {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = kok && cc + e < g.N;
+                    const float x = wrow[ok ? cc + e : 0];
+                    v[e] = ok ? x : 0.f;
                 }
+                qb[i] = v;
             }
-            rb[i] = v;
         }
+        ma = va;
+        mb = vb;
     };
 
-    auto store_chunk = [&](int buf) {
+    // Land a ring slot in an LDS buffer.  The caller has already waited (hand-counted vmcnt) for this
+    // slot's loads; pin() keeps every consumer below that wait.
+    auto land = [&](int buf, f32x4 (&qa)[A4], f32x4 (&qb)[B4], unsigned ma, unsigned mb) {
         float* a = As + buf * BM * SA;
         float* b = Bs + buf * BK * SB;
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
+            if constexpr (VEC) pin(qa[i]);
+            f32x4 v = qa[i];
+            if constexpr (VEC)
+                if (!((ma >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
             const int idx = tid + i * NT;
-            if (idx < BM * (BK / 4)) {
+            if (A4 * NT == BM * (BK / 4) || idx < BM * (BK / 4)) {
                 float* d = a + (idx / (BK / 4)) * SA + (idx % (BK / 4)) * 4;
-                *reinterpret_cast<float2*>(d) = make_float2(ra[i].x, ra[i].y);
-                *reinterpret_cast<float2*>(d + 2) = make_float2(ra[i].z, ra[i].w);
+                *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
             }
         }
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
+            if constexpr (VEC) pin(qb[i]);
+            f32x4 v = qb[i];
+            if constexpr (VEC)
+                if (!((mb >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
             const int idx = tid + i * NT;
-            if (idx < BK * (BN / 4)) {
+            if (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4)) {
                 float* d = b + (idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4;
-                *reinterpret_cast<float4*>(d) = rb[i];
+                *reinterpret_cast<f32x4*>(d) = v;
             }
         }
     };
 
-    auto advance = [&](int& sidx, int& koff) {  // next chunk position; returns via refs
-        koff += BK;
-        if (koff >= seg_len(sidx)) {
-            koff = 0;
-            ++sidx;
-            while (sidx < g.nseg && (g.seg[sidx].ptr == nullptr || seg_len(sidx) <= 0)) ++sidx;
-        }
-    };
-
-    if (s < g.nseg) {
-        seg_rows(s);
-        load_chunk(s, 0);
-        store_chunk(0);
-    }
-    __syncthreads();
-
-    int buf = 0;
-    while (s < g.nseg) {
-        int ns = s, nk = kc;
-        advance(ns, nk);
-        const bool more = ns < g.nseg;
-        if (more) {
-            if (ns != s) seg_rows(ns);
-            load_chunk(ns, nk);
-        }
+#ifndef S2VT_ALLREADS
+#define S2VT_ALLREADS 0
+#endif
+    // MFMAs of one chunk.  S2VT_ALLREADS=1: all fragment reads of the chunk first (8*(TM+TN) VGPRs), then
+    // the MFMAs back to back; 0: hipcc's own interleave (fewer registers, higher occupancy).
+    auto compute = [&](int buf) {
         const float* a = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
         const float* b = Bs + buf * BK * SB + lq * SB + l15;
+#if S2VT_ALLREADS
+        float av[BK / 4][TM], bv[BK / 4][TN];
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[ks][i] = a[i * 16 * SA + ks * 4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[ks][j] = b[ks * 4 * SB + (j / TNG) * CG + (wn * TNG + j % TNG) * 16];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             float av[TM], bv[TN];
@@ -276,11 +354,40 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_chunk(buf ^ 1);
+#endif
+    };
+
+    if (nchunks > 0) {
+        // prologue: chunk 0 -> LDS[0]; chunks 1 .. PF-1 in flight in ring slots 1 .. PF-1
+        issue(0, ra[0], rb[0], pa[0], pb[0]);
+        if constexpr (VEC) wait_vmcnt<0>();
+        land(0, ra[0], rb[0], pa[0], pb[0]);
+#pragma unroll
+        for (int j = 1; j < PF; ++j) issue(j, ra[j], rb[j], pa[j], pb[j]);
         __syncthreads();
-        buf ^= 1;
-        s = ns;
-        kc = nk;
+
+        // Steady state: iteration c has LDS[c&1] = chunk c and ring slot (c+i)%PF = chunk c+i in flight
+        // (i = 1..PF-1).  It issues chunk c+PF into the slot chunk c came from, computes chunk c, waits
+        // until all but the youngest (PF-1) chunks' loads have returned (vmcnt is in-order), lands chunk
+        // c+1 in the other LDS buffer, one barrier.  Unrolled by PF so ring slots are compile-time
+        // constants; the only branch is the wave-uniform loop exit.
+        int c = 0;
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                if (more) {
+                    issue(c + PF, ra[j], rb[j], pa[j], pb[j]);
+                    compute(c & 1);
+                    if constexpr (VEC) wait_vmcnt<WAITN>();
+                    land((c + 1) & 1, ra[(j + 1) % PF], rb[(j + 1) % PF], pa[(j + 1) % PF], pb[(j + 1) % PF]);
+                    __syncthreads();
+                    ++c;
+                    more = c < nchunks;
+                }
+            }
+        }
+        if constexpr (VEC) wait_vmcnt<0>();     // the ring's last PF-1 (all-zero, beyond-the-walk) chunks: drain before the epilogue
     }
 
     // ------------------------------------------------------------------ epilogues
