@@ -183,24 +183,25 @@ int s2vt_frame_embed_fwd(const s2vt_dims* d, const s2vt_params* p, const float* 
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct SampleWs {
-    float *emb, *c1[2], *h1[2], *c2e[2], *h2e[2], *c2[2], *h2[2];
+    float *emb, *Xp1, *c1, *h1, *P2, *c2e[2], *h2e[2], *c2[2], *h2[2];
     unsigned long long* packed;
-    int32_t *vid, *sid, *bos, *vid_b, *sid_b;
+    int32_t *vid, *sid, *bos;
 };
 
 size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
 {
-    const size_t H = d->lstm_dim, E = d->word_dim, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
+    const size_t H = d->lstm_dim, E = d->word_dim, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step, T = Tv + Tc;
     SampleWs t;
     t.emb = c.take<float>((size_t)B * Tv * E);
+    t.Xp1 = c.take<float>((size_t)B * Tv * 4 * H);
+    t.c1 = c.take<float>((T + 1) * B * H); t.h1 = c.take<float>((T + 1) * B * H);     // LSTM1 state history, slot 0 = zeros
+    t.P2 = c.take<float>(T * B * 4 * H);                                                // h1[t+1] @ W2[0:H] for every step
     for (int i = 0; i < 2; ++i) {
-        t.c1[i] = c.take<float>((size_t)B * H); t.h1[i] = c.take<float>((size_t)B * H);
         t.c2e[i] = c.take<float>((size_t)B * H); t.h2e[i] = c.take<float>((size_t)B * H);
         t.c2[i] = c.take<float>((size_t)R * H); t.h2[i] = c.take<float>((size_t)R * H);
     }
     t.packed = c.take<unsigned long long>((size_t)Tc * R);
     t.vid = c.take<int32_t>(R); t.sid = c.take<int32_t>(R); t.bos = c.take<int32_t>(R);
-    t.vid_b = c.take<int32_t>(B); t.sid_b = c.take<int32_t>(B);
     if (w) *w = t;
     return c.off;
 }
@@ -232,10 +233,12 @@ int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, in
     hipStream_t st = S(stream);
 
     // zero initial states (tf_s2vt.py:105-107) and the packed pick words
-    HIP_TRY(hipMemsetAsync(w.c1[0], 0, (size_t)B * H * 4, st));
-    HIP_TRY(hipMemsetAsync(w.h1[0], 0, (size_t)B * H * 4, st));
-    HIP_TRY(hipMemsetAsync(w.c2e[0], 0, (size_t)B * H * 4, st));
-    HIP_TRY(hipMemsetAsync(w.h2e[0], 0, (size_t)B * H * 4, st));
+    const int T = Tv + Tc;
+    const size_t BH = (size_t)B * H;
+    HIP_TRY(hipMemsetAsync(w.c1, 0, BH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.h1, 0, BH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.c2e[0], 0, BH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.h2e[0], 0, BH * 4, st));
     HIP_TRY(hipMemsetAsync(w.packed, 0, (size_t)Tc * R * 8, st));
     hipLaunchKernelGGL(sampler_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.vid, w.sid, B, K, R, video_base);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.bos, 1, R);   // <bos> = 1
@@ -246,39 +249,49 @@ int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, in
 
     NoiseIds none{nullptr, nullptr, 0};
     NoiseIds ids{w.vid, w.sid, seed};
+    // Each cell product is the ascending-k chain of concat([x, h]) @ W (tf_s2vt.py:119-143).  The rows of W
+    // that multiply inputs known before the step are consumed first, batched over time; the per-step
+    // launch continues the chain from that partial with the rows whose inputs the step produces.
+    // ---- LSTM1: sees the frames, then only the zero padding and its own state -- never a sampled word,
+    // so its whole trajectory (Tv + Tc steps) is per VIDEO and runs first, on B rows.
+    {
+        ASeg sx = make_seg(w.emb, E, E, 0);
+        HIP_TRY(store_call(&sx, 1, p->lstm1_W, 4 * H, nullptr, w.Xp1, 4 * H, B * Tv, 4 * H, 0, -1, st));
+    }
+    for (int t = 0; t < T; ++t) {
+        ASeg s1 = make_seg(w.h1 + t * BH, H, H, E);
+        HIP_TRY(lstm_call(&s1, 1, p->lstm1_W, p->lstm1_b, w.c1 + t * BH, 0, w.c1 + (t + 1) * BH, w.h1 + (t + 1) * BH, nullptr,
+                          nullptr, B, H, 1.0f, none, 0, -1, st, t < Tv ? w.Xp1 + (size_t)t * 4 * H : nullptr, Tv * 4 * H, 0));
+    }
+    // ---- the out1 rows of W2 for every step at once (M = T*B)
+    {
+        ASeg so = make_seg(w.h1 + BH, H, H, 0);
+        HIP_TRY(store_call(&so, 1, p->lstm2_W, 4 * H, nullptr, w.P2, 4 * H, T * B, 4 * H, 0, -1, st));
+    }
+    // ---- LSTM2 encoding stage (tf_s2vt.py:122: word slot = zero padding), M = B
     int cur = 0;
-    // ---- encoding stage (tf_s2vt.py:113-122), M = B
     for (int t = 0; t < Tv; ++t) {
         const int nxt = cur ^ 1;
-        ASeg s1[2] = {make_seg(w.emb + (size_t)t * E, Tv * E, E, 0), make_seg(w.h1[cur], H, H, E)};
-        HIP_TRY(lstm_call(s1, 2, p->lstm1_W, p->lstm1_b, w.c1[cur], 0, w.c1[nxt], w.h1[nxt], nullptr, nullptr, B, H, 1.0f,
-                          none, 0, -1, st));
-        ASeg s2[2] = {make_seg(w.h1[nxt], H, H, 0), make_seg(w.h2e[cur], H, H, H + E)};
-        HIP_TRY(lstm_call(s2, 2, p->lstm2_W, p->lstm2_b, w.c2e[cur], 0, w.c2e[nxt], w.h2e[nxt], nullptr, nullptr, B, H,
-                          1.0f, none, 0, -1, st));
+        ASeg s2 = make_seg(w.h2e[cur], H, H, H + E);
+        HIP_TRY(lstm_call(&s2, 1, p->lstm2_W, p->lstm2_b, w.c2e[cur], 0, w.c2e[nxt], w.h2e[nxt], nullptr, nullptr, B, H, 1.0f,
+                          none, 0, -1, st, w.P2 + (size_t)t * 4 * BH, 4 * H, 0));
         cur = nxt;
     }
-    // ---- decoding stage (tf_s2vt.py:126-153 as specialised by the samplers).  LSTM1 sees only the
-    // zero padding and its own state, so its trajectory is per VIDEO: it runs at M = B and the R
-    // sample rows read it through row % B.  LSTM2 + vocab run at M = R.
+    // ---- decoding stage (tf_s2vt.py:126-153 as specialised by the samplers): LSTM2 + vocab at M = R rows;
+    // the R sample rows of a video share its out1 partial (row % B).
     int cur2 = 0;
     for (int t = 0; t < Tc; ++t) {
-        const int nxt = cur ^ 1, nxt2 = cur2 ^ 1;
-        ASeg s1[1] = {make_seg(w.h1[cur], H, H, E)};
-        HIP_TRY(lstm_call(s1, 1, p->lstm1_W, p->lstm1_b, w.c1[cur], 0, w.c1[nxt], w.h1[nxt], nullptr, nullptr, B, H, 1.0f,
-                          none, 0, -1, st));
+        const int nxt2 = cur2 ^ 1;
         const float* h2p = t == 0 ? w.h2e[cur] : w.h2[cur2];
         const float* c2p = t == 0 ? w.c2e[cur] : w.c2[cur2];
         const int smod = t == 0 ? B : 0;
-        ASeg s2[3] = {make_seg(w.h1[nxt], H, H, 0, B),
-                      t == 0 ? make_seg(p->Wemb, E, E, H, 0, w.bos)
+        ASeg s2[2] = {t == 0 ? make_seg(p->Wemb, E, E, H, 0, w.bos)
                              : make_seg(p->Wemb, E, E, H, 0, nullptr, w.packed + (size_t)(t - 1) * R),
                       make_seg(h2p, H, H, H + E, smod)};
-        HIP_TRY(lstm_call(s2, 3, p->lstm2_W, p->lstm2_b, c2p, smod, w.c2[nxt2], w.h2[nxt2], nullptr, nullptr, R, H, 1.0f,
-                          none, 0, -1, st));
+        HIP_TRY(lstm_call(s2, 2, p->lstm2_W, p->lstm2_b, c2p, smod, w.c2[nxt2], w.h2[nxt2], nullptr, nullptr, R, H, 1.0f,
+                          none, 0, -1, st, w.P2 + (size_t)(Tv + t) * 4 * BH, 4 * H, B));
         HIP_TRY(pick_call(w.h2[nxt2], H, p->embed_word_W, p->embed_word_b, R, H, V, ids, t, w.packed + (size_t)t * R,
                           nullptr, -1, st));
-        cur = nxt;
         cur2 = nxt2;
     }
     hipLaunchKernelGGL(unpack_ids_kernel, dim3((R * Tc + 255) / 256), dim3(256), 0, st, w.packed, ids_out, R, Tc);

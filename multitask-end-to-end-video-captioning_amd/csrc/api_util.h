@@ -74,7 +74,8 @@ struct NoiseIds {
 // One BasicLSTMCell call.  segs/nseg describe [x0 ; x1 ; h_prev] with their W row offsets.
 inline hipError_t lstm_call(const ASeg* segs, int nseg, const float* W, const float* b, const float* c_prev, int cprev_rowmod,
                      float* c_new, float* h_new, float* out, float* gates, int M, int H, float keep, const NoiseIds& ids,
-                     uint32_t drop_code, int cfg, hipStream_t st)
+                     uint32_t drop_code, int cfg, hipStream_t st, const float* cinit = nullptr, int ldcinit = 0,
+                     int cinit_rowmod = 0)
 {
     GemmArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -85,6 +86,7 @@ inline hipError_t lstm_call(const ASeg* segs, int nseg, const float* W, const fl
     a.keep = keep; a.drop_code = drop_code;
     a.video_id = ids.video_id; a.sample_id = ids.sample_id;
     a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32);
+    a.cinit = cinit; a.ldcinit = ldcinit; a.cinit_rowmod = cinit_rowmod;   // a carried partial chain (hoisted input products)
     return launch_gemm(a, EPI_LSTM, cfg, st);
 }
 

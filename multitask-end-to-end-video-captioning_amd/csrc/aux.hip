@@ -201,6 +201,71 @@ hipError_t launch_lstm_bwd_pointwise(const float* gates, const float* c_new, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// DropoutWrapper output of a cell whose clean state trajectory is shared by the rep sample rows of a
+// video (LSTM1 in build_loss sees the same frames in every one of the K tiled copies,
+// reinforcement_multisampling_tf_s2vt.py:779-782, so its state is computed once per video), and the
+// adjoint reduction.  Same expression as the EPI_LSTM epilogue: (h / keep) * floor(keep + u).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_dropout_kernel(const float* h, float* out, int T, int B, int N, int H,
+                                                             float keep, uint32_t seed_lo, uint32_t seed_hi,
+                                                             uint32_t code_base, const int32_t* video_id,
+                                                             const int32_t* sample_id)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * N * H) return;
+    const int u = (int)(i % H);
+    const size_t tn = i / H;
+    const int n = (int)(tn % N), t = (int)(tn / N);
+    float v = h[((size_t)t * B + n % B) * H + u];
+    if (keep < 1.0f)
+        v = (v / keep) * dropout_keep01(seed_lo, seed_hi, (uint32_t)video_id[n], (uint32_t)sample_id[n], code_base + (uint32_t)t,
+                                        (uint32_t)u, keep);
+    out[i] = v;
+}
+
+hipError_t launch_expand_dropout(const float* h, float* out, int T, int B, int N, int H, float keep, uint64_t seed,
+                                 uint32_t code_base, const int32_t* video_id, const int32_t* sample_id, hipStream_t st)
+{
+    const size_t n = (size_t)T * N * H;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h, out, T, B, N, H, keep,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), code_base, video_id, sample_id);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void reduce_dropout_kernel(const float* dout, int ld_out, float* dh, int T, int B, int N,
+                                                             int H, float keep, uint32_t seed_lo, uint32_t seed_hi,
+                                                             uint32_t code_base, const int32_t* video_id,
+                                                             const int32_t* sample_id)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * B * H) return;
+    const int u = (int)(i % H);
+    const size_t tj = i / H;
+    const int j = (int)(tj % B), t = (int)(tj / B);
+    float acc = 0.f;
+    for (int n = j; n < N; n += B) {
+        float d = dout[((size_t)t * N + n) * ld_out + u];
+        if (keep < 1.0f)
+            d = (d / keep) * dropout_keep01(seed_lo, seed_hi, (uint32_t)video_id[n], (uint32_t)sample_id[n],
+                                            code_base + (uint32_t)t, (uint32_t)u, keep);
+        acc += d;
+    }
+    dh[i] = acc;
+}
+
+hipError_t launch_reduce_dropout(const float* dout, int ld_out, float* dh, int T, int B, int N, int H, float keep,
+                                 uint64_t seed, uint32_t code_base, const int32_t* video_id, const int32_t* sample_id,
+                                 hipStream_t st)
+{
+    const size_t n = (size_t)T * B * H;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, ld_out, dh, T, B, N, H,
+                       keep, (uint32_t)seed, (uint32_t)(seed >> 32), code_base, video_id, sample_id);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // out[n] += sum_m X[m, n]      (bias gradients).  64 columns x 256-row slabs per workgroup.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* X, int ld, int M, int N, float* out)

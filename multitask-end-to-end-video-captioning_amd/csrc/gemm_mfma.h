@@ -109,6 +109,9 @@ struct GemmCfg {
     // prefetch ring depth (chunks in flight per thread): the skinny-M kernels are bound by operand bytes
     // in flight per CU (measured: ~3500-cycle loaded latency), so the ring is as deep as ~96 staging
     // VGPRs allow, between 2 and 6 slots.
+#ifndef S2VT_LAND_AT
+#define S2VT_LAND_AT 8   /* k-steps of a chunk computed before the next chunk is landed in LDS (8 = after all) */
+#endif
 #ifndef S2VT_PF_BUDGET
 #define S2VT_PF_BUDGET 48
 #endif
@@ -314,35 +317,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         }
     };
 
-#ifndef S2VT_ALLREADS
-#define S2VT_ALLREADS 0
-#endif
-    // MFMAs of one chunk.  S2VT_ALLREADS=1: all fragment reads of the chunk first (8*(TM+TN) VGPRs), then
-    // the MFMAs back to back; 0: hipcc's own interleave (fewer registers, higher occupancy).
-    auto compute = [&](int buf) {
+    // MFMAs of k-steps [KS0, KS1) of one chunk (hipcc interleaves the fragment reads with the MFMAs).
+    auto compute = [&](int buf, auto ks0_, auto ks1_) {
+        constexpr int KS0 = decltype(ks0_)::value, KS1 = decltype(ks1_)::value;
         const float* a = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
         const float* b = Bs + buf * BK * SB + lq * SB + l15;
-#if S2VT_ALLREADS
-        float av[BK / 4][TM], bv[BK / 4][TN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[ks][i] = a[i * 16 * SA + ks * 4];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[ks][j] = b[ks * 4 * SB + (j / TNG) * CG + (wn * TNG + j % TNG) * 16];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][i], bv[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#else
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
+        for (int ks = KS0; ks < KS1; ++ks) {
             float av[TM], bv[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * SA + ks * 4];
@@ -354,8 +335,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-#endif
     };
+    using K0 = std::integral_constant<int, 0>;
+    using KH = std::integral_constant<int, S2VT_LAND_AT>;
+    using K8 = std::integral_constant<int, BK / 4>;
 
     if (nchunks > 0) {
         // prologue: chunk 0 -> LDS[0]; chunks 1 .. PF-1 in flight in ring slots 1 .. PF-1
@@ -367,10 +350,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         __syncthreads();
 
         // Steady state: iteration c has LDS[c&1] = chunk c and ring slot (c+i)%PF = chunk c+i in flight
-        // (i = 1..PF-1).  It issues chunk c+PF into the slot chunk c came from, computes chunk c, waits
-        // until all but the youngest (PF-1) chunks' loads have returned (vmcnt is in-order), lands chunk
-        // c+1 in the other LDS buffer, one barrier.  Unrolled by PF so ring slots are compile-time
-        // constants; the only branch is the wave-uniform loop exit.
+        // (i = 1..PF-1).  It issues chunk c+PF into the slot chunk c came from, computes the first
+        // S2VT_LAND_AT k-steps of chunk c, waits until all but the youngest (PF-1) chunks' loads have
+        // returned (vmcnt is in-order), lands chunk c+1 in the OTHER LDS buffer (nobody reads it between
+        // the previous barrier and the next one) so that the LDS stores retire under the remaining MFMAs,
+        // computes the rest, one barrier.  Unrolled by PF so ring slots are compile-time constants; the
+        // only branch is the wave-uniform loop exit.
         int c = 0;
         bool more = true;
         while (more) {
@@ -378,9 +363,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             for (int j = 0; j < PF; ++j) {
                 if (more) {
                     issue(c + PF, ra[j], rb[j], pa[j], pb[j]);
-                    compute(c & 1);
+                    compute(c & 1, K0{}, KH{});
                     if constexpr (VEC) wait_vmcnt<WAITN>();
                     land((c + 1) & 1, ra[(j + 1) % PF], rb[(j + 1) % PF], pa[(j + 1) % PF], pb[(j + 1) % PF]);
+                    compute(c & 1, KH{}, K8{});
                     __syncthreads();
                     ++c;
                     more = c < nchunks;

@@ -40,6 +40,14 @@ hipError_t launch_lstm_bwd_pointwise(const float* gates, const float* c_new, con
                                      int nslab, size_t slab_stride, const float* dout_ext, int ld_ext, const float* dc_in,
                                      float* dc_out, float* dz, int M, int H, float keep, uint64_t seed, uint32_t drop_code,
                                      const int32_t* video_id, const int32_t* sample_id, hipStream_t st);
+// out[t][n][u] = keep < 1 ? (h[t][n % B][u] / keep) * mask(n, t, u) : h[...]   (DropoutWrapper output of a cell whose
+// state trajectory is shared by the rep = N / B sample rows of a video); code = code_base + t
+hipError_t launch_expand_dropout(const float* h, float* out, int T, int B, int N, int H, float keep, uint64_t seed,
+                                 uint32_t code_base, const int32_t* video_id, const int32_t* sample_id, hipStream_t st);
+// dh[t][j][u] = sum_k (dout[t][k*B + j][u] / keep) * mask(k*B + j, t, u)   (adjoint of the above; dout rows ld_out apart)
+hipError_t launch_reduce_dropout(const float* dout, int ld_out, float* dh, int T, int B, int N, int H, float keep,
+                                 uint64_t seed, uint32_t code_base, const int32_t* video_id, const int32_t* sample_id,
+                                 hipStream_t st);
 hipError_t launch_colsum(const float* X, int ld, int M, int N, float* out, hipStream_t st);
 hipError_t launch_scatter_add_rows(const float* dE, int ld, const int32_t* idx, int R, int E, float* dW, int ldw,
                                    hipStream_t st);

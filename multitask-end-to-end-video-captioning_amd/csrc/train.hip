@@ -10,20 +10,23 @@ using namespace s2vt_api;
 
 namespace {
 
-__global__ void enc_index_kernel(int32_t* idx, int N, int B, int Tv)
+__global__ void enc_index_kernel(int32_t* idx, int B, int Tv)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * Tv) return;
-    const int t = i / N, n = i % N;
-    idx[i] = (n % B) * Tv + t;     // row of video[B*Tv, d] / emb[B*Tv, E] feeding (step t, row n)
+    if (i >= B * Tv) return;
+    const int t = i / B, j = i % B;
+    idx[i] = j * Tv + t;     // row of video[B*Tv, d] / emb[B*Tv, E] feeding (step t, video j)
 }
 
-// saved activations + backward scratch of one teacher-forced unroll, carved from the caller's buffer
+// Saved activations + backward scratch of one teacher-forced unroll, carved from the caller's buffer.
+// LSTM1 never sees the caption (its input is the frame embedding, then the zero padding), so its clean
+// state trajectory is per VIDEO: it is computed and back-propagated on B rows, and only its
+// dropout-wrapped output O1 is expanded to the N = rep*B sample rows.
 struct TrainWs {
-    float* emb;
+    float *emb, *Xp1;
     int32_t *prev, *tgt, *encidx;
     float *G1, *C1, *H1, *O1, *G2, *C2, *H2, *O2;
-    float *WoutT, *W2T, *W1T, *dO2, *dZ1, *dZ2, *dX2, *dX1, *slab, *dc;
+    float *WoutT, *W2T, *W1T, *dO2, *dZ1, *dZ2, *dX2, *dX1, *dH1, *slab, *dc;
 };
 
 constexpr int kSlabs = 4;
@@ -31,18 +34,19 @@ constexpr int kSlabs = 4;
 size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
 {
     const size_t H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
-    const size_t T = Tv + Tc, n = N;
+    const size_t T = Tv + Tc, n = N, b = B;
     TrainWs w;
-    w.emb = c.take<float>((size_t)B * Tv * E);
-    w.prev = c.take<int32_t>(Tc * n); w.tgt = c.take<int32_t>(Tc * n); w.encidx = c.take<int32_t>(Tv * n);
-    w.G1 = c.take<float>(T * n * 4 * H); w.C1 = c.take<float>((T + 1) * n * H); w.H1 = c.take<float>((T + 1) * n * H);
+    w.emb = c.take<float>(b * Tv * E);
+    w.Xp1 = c.take<float>(b * Tv * 4 * H);
+    w.prev = c.take<int32_t>(Tc * n); w.tgt = c.take<int32_t>(Tc * n); w.encidx = c.take<int32_t>(Tv * b);
+    w.G1 = c.take<float>(T * b * 4 * H); w.C1 = c.take<float>((T + 1) * b * H); w.H1 = c.take<float>((T + 1) * b * H);
     w.O1 = c.take<float>(T * n * H);
     w.G2 = c.take<float>(T * n * 4 * H); w.C2 = c.take<float>((T + 1) * n * H); w.H2 = c.take<float>((T + 1) * n * H);
     w.O2 = c.take<float>(T * n * H);
     w.WoutT = c.take<float>(V * H); w.W2T = c.take<float>(4 * H * (2 * H + E)); w.W1T = c.take<float>(4 * H * (E + H));
     w.dO2 = c.take<float>(Tc * n * H);
-    w.dZ1 = c.take<float>(T * n * 4 * H); w.dZ2 = c.take<float>(T * n * 4 * H);
-    w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * n * E);
+    w.dZ1 = c.take<float>(T * b * 4 * H); w.dZ2 = c.take<float>(T * n * 4 * H);
+    w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * b * E); w.dH1 = c.take<float>(T * b * H);
     w.slab = c.take<float>((size_t)kSlabs * n * H); w.dc = c.take<float>(n * H);
     if (out) *out = w;
     return c.off;
@@ -99,36 +103,52 @@ int s2vt_teacher_forced_fwd(const s2vt_dims* d, const s2vt_params* p, const floa
     carve_train(c, d, B, N, &w);
     if (!c.ok()) return S2VT_E_WORKSPACE;
     hipStream_t st = S(stream);
-    const size_t NH = (size_t)N * H;
 
     HIP_TRY(launch_prep_caption(caption, w.prev, w.tgt, N, Tc, st));
-    hipLaunchKernelGGL(enc_index_kernel, dim3((N * Tv + 255) / 256), dim3(256), 0, st, w.encidx, N, B, Tv);
+    hipLaunchKernelGGL(enc_index_kernel, dim3((B * Tv + 255) / 256), dim3(256), 0, st, w.encidx, B, Tv);
     HIP_TRY(hipGetLastError());
+    const size_t NH = (size_t)N * H, BH = (size_t)B * H;
     // zero initial states (tf_s2vt.py:105-107): slot 0 of the state histories
-    HIP_TRY(hipMemsetAsync(w.C1, 0, NH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.H1, 0, NH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.C1, 0, BH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.H1, 0, BH * 4, st));
     HIP_TRY(hipMemsetAsync(w.C2, 0, NH * 4, st));
     HIP_TRY(hipMemsetAsync(w.H2, 0, NH * 4, st));
     int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
     if (rc != S2VT_OK) return rc;
 
+    NoiseIds none{nullptr, nullptr, 0};
     NoiseIds ids{video_id, sample_id, seed};
+    // Every contraction below is the SAME ascending-k chain as concat([x, h]) @ W (tf_s2vt.py:119-143):
+    // the rows of W that multiply non-recurrent inputs are consumed first, for all time steps in one
+    // batched launch; the per-step launch then continues each chain from that partial with the
+    // recurrent rows.
+    // ---- LSTM1: input rows of W1 for the Tv frames (row j*Tv + t of emb), then the recurrence on B rows
+    {
+        ASeg sx = make_seg(w.emb, E, E, 0);
+        HIP_TRY(store_call(&sx, 1, p->lstm1_W, 4 * H, nullptr, w.Xp1, 4 * H, B * Tv, 4 * H, 0, -1, st));
+    }
     for (int t = 0; t < T; ++t) {
-        // LSTM1 (tf_s2vt.py:119 encode, :140 decode with the zero padding input)
-        ASeg s1[2];
-        int n1 = 0;
-        if (t < Tv) s1[n1++] = make_seg(w.emb + (size_t)t * E, Tv * E, E, 0, B);
-        s1[n1++] = make_seg(w.H1 + t * NH, H, H, E);
-        HIP_TRY(lstm_call(s1, n1, p->lstm1_W, p->lstm1_b, w.C1 + t * NH, 0, w.C1 + (t + 1) * NH, w.H1 + (t + 1) * NH,
-                          w.O1 + t * NH, w.G1 + (size_t)t * 4 * NH, N, H, keep, ids, 256u + (uint32_t)t, -1, st));
-        // LSTM2 (tf_s2vt.py:122 encode with the zero padding, :143 decode with the previous word)
-        ASeg s2[3];
-        int n2 = 0;
-        s2[n2++] = make_seg(w.O1 + t * NH, H, H, 0);
-        if (t >= Tv) s2[n2++] = make_seg(p->Wemb, E, E, H, 0, w.prev + (size_t)(t - Tv) * N);
-        s2[n2++] = make_seg(w.H2 + t * NH, H, H, H + E);
-        HIP_TRY(lstm_call(s2, n2, p->lstm2_W, p->lstm2_b, w.C2 + t * NH, 0, w.C2 + (t + 1) * NH, w.H2 + (t + 1) * NH,
-                          w.O2 + t * NH, w.G2 + (size_t)t * 4 * NH, N, H, keep, ids, 512u + (uint32_t)t, -1, st));
+        // tf_s2vt.py:119 (encode) / :140 (decode, zero padding input: only the recurrent rows remain)
+        ASeg s1 = make_seg(w.H1 + t * BH, H, H, E);
+        HIP_TRY(lstm_call(&s1, 1, p->lstm1_W, p->lstm1_b, w.C1 + t * BH, 0, w.C1 + (t + 1) * BH, w.H1 + (t + 1) * BH, nullptr,
+                          w.G1 + (size_t)t * 4 * BH, B, H, 1.0f, none, 0, -1, st, t < Tv ? w.Xp1 + (size_t)t * 4 * H : nullptr,
+                          Tv * 4 * H, 0));
+    }
+    // DropoutWrapper(LSTM1) output for the N sample rows (tf_s2vt.py:75; code = 256 + t)
+    HIP_TRY(launch_expand_dropout(w.H1 + BH, w.O1, T, B, N, H, keep, seed, 256u, video_id, sample_id, st));
+    // ---- LSTM2: rows of W2 for [out1 ; embed(prev word)] for all steps at once, written where the
+    // step's activated gates will go (the step kernel reads its partial, then overwrites it)
+    {
+        ASeg se = make_seg(w.O1, H, H, 0);                                       // encode: the word slot is the zero padding (:122)
+        HIP_TRY(store_call(&se, 1, p->lstm2_W, 4 * H, nullptr, w.G2, 4 * H, Tv * N, 4 * H, 0, -1, st));
+        ASeg sd[2] = {make_seg(w.O1 + (size_t)Tv * NH, H, H, 0), make_seg(p->Wemb, E, E, H, 0, w.prev)};   // decode (:143)
+        HIP_TRY(store_call(sd, 2, p->lstm2_W, 4 * H, nullptr, w.G2 + (size_t)Tv * 4 * NH, 4 * H, Tc * N, 4 * H, 0, -1, st));
+    }
+    for (int t = 0; t < T; ++t) {
+        ASeg s2 = make_seg(w.H2 + t * NH, H, H, H + E);
+        float* g2 = w.G2 + (size_t)t * 4 * NH;
+        HIP_TRY(lstm_call(&s2, 1, p->lstm2_W, p->lstm2_b, w.C2 + t * NH, 0, w.C2 + (t + 1) * NH, w.H2 + (t + 1) * NH,
+                          w.O2 + t * NH, g2, N, H, keep, ids, 512u + (uint32_t)t, -1, st, g2, 4 * H, 0));
     }
     // vocab logits for all Tc steps at once (tf_s2vt.py:153): rows t*N + n
     ASeg so = make_seg(w.O2 + (size_t)Tv * NH, H, H, 0);
@@ -189,15 +209,18 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
     }
     // d[out1 ; embed] for every step at once
     HIP_TRY(nn_bwd(w.dZ2, 4 * H, w.W2T, K2, w.dX2, H + E, T * N, H + E, 4 * H, 1, 0, st));
-    // ---- LSTM1 back through time
+    // ---- LSTM1 back through time, on the B per-video rows: the gradient w.r.t. its dropped output is
+    // first reduced over the rep sample rows of each video (with their dropout masks)
+    const size_t BH = (size_t)B * H;
+    HIP_TRY(launch_reduce_dropout(w.dX2, H + E, w.dH1, T, B, N, H, keep, seed, 256u, video_id, sample_id, st));
     for (int t = T - 1; t >= 0; --t) {
-        HIP_TRY(launch_lstm_bwd_pointwise(w.G1 + (size_t)t * 4 * NH, w.C1 + (t + 1) * NH, w.C1 + t * NH,
-                                          t == T - 1 ? nullptr : w.slab, nslab, NH, w.dX2 + (size_t)t * N * (H + E), H + E,
-                                          t == T - 1 ? nullptr : w.dc, w.dc, w.dZ1 + (size_t)t * 4 * NH, N, H, keep, seed,
-                                          256u + (uint32_t)t, video_id, sample_id, st));
-        if (t > 0) HIP_TRY(nn_bwd(w.dZ1 + (size_t)t * 4 * NH, 4 * H, w.W1T + E, K1, w.slab, H, N, H, 4 * H, kSlabs, NH, st));
+        HIP_TRY(launch_lstm_bwd_pointwise(w.G1 + (size_t)t * 4 * BH, w.C1 + (t + 1) * BH, w.C1 + t * BH,
+                                          t == T - 1 ? nullptr : w.slab, nslab, BH, w.dH1 + t * BH, H,
+                                          t == T - 1 ? nullptr : w.dc, w.dc, w.dZ1 + (size_t)t * 4 * BH, B, H, 1.0f, seed, 0u,
+                                          nullptr, nullptr, st));
+        if (t > 0) HIP_TRY(nn_bwd(w.dZ1 + (size_t)t * 4 * BH, 4 * H, w.W1T + E, K1, w.slab, H, B, H, 4 * H, kSlabs, BH, st));
     }
-    HIP_TRY(nn_bwd(w.dZ1, 4 * H, w.W1T, K1, w.dX1, E, Tv * N, E, 4 * H, 1, 0, st));
+    HIP_TRY(nn_bwd(w.dZ1, 4 * H, w.W1T, K1, w.dX1, E, Tv * B, E, 4 * H, 1, 0, st));
 
     // ---- weight gradients: one contraction over all unrolled steps per weight block
     {
@@ -209,17 +232,17 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
         TnArgs e{w.H2, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, T * N, H, 4 * H, 1};
         HIP_TRY(launch_gemm_tn(e, st));
         HIP_TRY(launch_colsum(w.dZ2, 4 * H, T * N, 4 * H, grads->lstm2_b, st));
-        TnArgs f{w.emb, w.encidx, E, w.dZ1, 4 * H, grads->lstm1_W, 4 * H, Tv * N, E, 4 * H, 1};
+        TnArgs f{w.emb, w.encidx, E, w.dZ1, 4 * H, grads->lstm1_W, 4 * H, Tv * B, E, 4 * H, 1};
         HIP_TRY(launch_gemm_tn(f, st));
-        TnArgs g{w.H1, nullptr, H, w.dZ1, 4 * H, grads->lstm1_W + (size_t)E * 4 * H, 4 * H, T * N, H, 4 * H, 1};
+        TnArgs g{w.H1, nullptr, H, w.dZ1, 4 * H, grads->lstm1_W + (size_t)E * 4 * H, 4 * H, T * B, H, 4 * H, 1};
         HIP_TRY(launch_gemm_tn(g, st));
-        HIP_TRY(launch_colsum(w.dZ1, 4 * H, T * N, 4 * H, grads->lstm1_b, st));
+        HIP_TRY(launch_colsum(w.dZ1, 4 * H, T * B, 4 * H, grads->lstm1_b, st));
         // embedding rows (gradient of tf.nn.embedding_lookup): scatter-add of the embed slice of dX2
         HIP_TRY(launch_scatter_add_rows(w.dX2 + (size_t)Tv * N * (H + E) + H, H + E, w.prev, Tc * N, E, grads->Wemb, E, st));
         // frame embedding
-        TnArgs h{video, w.encidx, D, w.dX1, E, grads->encode_image_W, E, Tv * N, D, E, 1};
+        TnArgs h{video, w.encidx, D, w.dX1, E, grads->encode_image_W, E, Tv * B, D, E, 1};
         HIP_TRY(launch_gemm_tn(h, st));
-        HIP_TRY(launch_colsum(w.dX1, E, Tv * N, E, grads->encode_image_b, st));
+        HIP_TRY(launch_colsum(w.dX1, E, Tv * B, E, grads->encode_image_b, st));
     }
     return S2VT_OK;
 }

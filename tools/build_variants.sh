@@ -1,8 +1,10 @@
 #!/bin/bash
 # dev: build A/B variants of the library side by side (variants/*.so, shipped to the GPU box by gpurun)
+# usage: build_variants.sh name1:"-DFLAG=.. -DFLAG2=.." name2:"..." ...
 set -e
 cd "$(dirname "$0")/../multitask-end-to-end-video-captioning_amd/csrc"
 mkdir -p ../../variants
+rm -f ../../variants/*.so
 build() { # name flags...
   local name=$1; shift
   local d=/tmp/var_$name; mkdir -p $d
@@ -11,10 +13,8 @@ build() { # name flags...
   done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so $d/*.o
 }
-build pf24_c0 -DS2VT_PF_BUDGET=32 -DS2VT_ALLREADS=0 &
-build pf48_c0 -DS2VT_PF_BUDGET=48 -DS2VT_ALLREADS=0 &
-wait
-build pf64_c0 -DS2VT_PF_BUDGET=64 -DS2VT_ALLREADS=0 &
-build pf48_c1 -DS2VT_PF_BUDGET=48 -DS2VT_ALLREADS=1 &
-wait
+for spec in "$@"; do
+  name=${spec%%:*}; flags=${spec#*:}
+  build $name $flags
+done
 ls -la ../../variants
