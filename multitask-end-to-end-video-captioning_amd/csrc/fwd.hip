@@ -19,11 +19,11 @@ struct CfgEntry {
     int BM, CG, NT, lds_bytes;
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, int NBUF = 2>
 constexpr CfgEntry make_entry(const char* name)
 {
-    using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true>;
-    return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true>, gemm_kernel<WM, WN, TM, TN, NG, EPI, false>,
+    using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true, NBUF>;
+    return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true, NBUF>, gemm_kernel<WM, WN, TM, TN, NG, EPI, false, NBUF>,
                     C::BM, C::CG, C::NT, C::LDS_FLOATS * 4};
 }
 
@@ -36,17 +36,26 @@ const CfgEntry kStore[] = {
     make_entry<4, 1, 1, 2, 1, EPI_STORE>("64x32(4x1)"),
 };
 const CfgEntry kLstm[] = {
+    // all four gates of 16 (32) units in one wave
     make_entry<4, 1, 1, 4, 4, EPI_LSTM>("64x16u(4x1)"),
-    make_entry<4, 1, 2, 4, 4, EPI_LSTM>("128x16u(4x1)"),
     make_entry<2, 2, 2, 4, 4, EPI_LSTM>("64x32u(2x2)"),
-    make_entry<2, 2, 3, 4, 4, EPI_LSTM>("96x32u(2x2)"),
     make_entry<2, 1, 1, 4, 4, EPI_LSTM>("32x16u(2x1)"),
+    // gate-per-wave: rows x 16 units per workgroup, (row groups x 4 gate waves); p3 = fragment-pipelined, 3 LDS stages
+    make_entry<1, 4, 1, 1, 4, EPI_LSTM_GW>("gw16x16u(1x4)"),
+    make_entry<1, 4, 2, 1, 4, EPI_LSTM_GW>("gw32x16u(1x4)"),
+    make_entry<1, 4, 3, 1, 4, EPI_LSTM_GW>("gw48x16u(1x4)"),
+    make_entry<1, 4, 4, 1, 4, EPI_LSTM_GW>("gw64x16u(1x4)"),
+    make_entry<1, 4, 5, 1, 4, EPI_LSTM_GW>("gw80x16u(1x4)"),
+    make_entry<2, 4, 3, 1, 4, EPI_LSTM_GW>("gw96x16u(2x4)"),
+    make_entry<2, 4, 3, 1, 4, EPI_LSTM_GW, 3>("gw96x16u(2x4)p3"),
 };
+constexpr int kLstmGwFirst = 3;      // index of gw16x16u; the gw entries follow in order of rows
 const CfgEntry kPick[] = {
     make_entry<4, 1, 1, 4, 1, EPI_PICK>("64x64(4x1)"),
-    make_entry<2, 2, 6, 3, 1, EPI_PICK>("192x96(2x2)"),
     make_entry<2, 2, 4, 4, 1, EPI_PICK>("128x128(2x2)"),
     make_entry<2, 2, 2, 4, 1, EPI_PICK>("64x128(2x2)"),
+    make_entry<2, 4, 3, 3, 1, EPI_PICK>("96x192(2x4)"),
+    make_entry<2, 4, 3, 3, 1, EPI_PICK, 3>("96x192(2x4)p3"),
 };
 
 const CfgEntry* table(int epi, int* n)
@@ -90,6 +99,16 @@ int choose(const CfgEntry* t, int n, int M, int N)
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
     return best;
+}
+
+// LSTM step: the gate-per-wave tile whose row count cuts M into ~4 row tiles, so that 4 x ceil(H/16) workgroups
+// (~one per CU at H = 1000) cover the launch with one wave per SIMD each; measured on MI355X at H = 1000:
+// M = 64: 21 us (64x16u: 39), M = 320: 98 us at K = 2500 (64x16u: 125), M = 384: 102 us (137).
+int choose_lstm(int M)
+{
+    const int rows = ceil_div(ceil_div(M, 4), 16) * 16;       // 16, 32, ... rows per workgroup
+    const int step = rows / 16;                                // 1..6 -> gw16 .. gw96
+    return kLstmGwFirst + (step < 1 ? 0 : (step > 6 ? 5 : step - 1));
 }
 
 std::once_flag g_attr_once;
@@ -189,12 +208,15 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     std::call_once(g_attr_once, set_lds_attrs);
     int n;
     const CfgEntry* t = table(epi, &n);
-    if (cfg < 0 || cfg >= n) cfg = choose(t, n, a.M, a.N);
+    if (cfg < 0 || cfg >= n) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : choose(t, n, a.M, a.N);
     const CfgEntry& e = t[cfg];
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     const int mt = ceil_div(a.M, e.BM), nt = ceil_div(a.N, e.CG);
     GemmArgs a2 = a;
     a2.xcd_map = (mt <= 16 && nt >= 8) ? 1 : 0;
+#ifdef S2VT_ABLATE
+    { const char* e_ = getenv("S2VT_DBG"); a2.dbg = e_ ? atoi(e_) : 0; }
+#endif
     const unsigned gx = a2.xcd_map ? (unsigned)(mt * ceil_div(nt, 8) * 8) : (unsigned)(mt * nt);
     const dim3 grid(gx, (unsigned)(a.splits > 1 ? a.splits : 1), 1);
     KernelFn fn = can_vec(a) ? e.vec : e.scalar;

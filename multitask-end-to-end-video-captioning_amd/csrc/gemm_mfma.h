@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int SA = BK + 2;
 
-enum { EPI_STORE = 0, EPI_LSTM = 1, EPI_PICK = 2 };
+enum { EPI_STORE = 0, EPI_LSTM = 1, EPI_PICK = 2, EPI_LSTM_GW = 3 };
 
 struct ASeg {
     const float* ptr;    // [rows, ld] row-major; nullptr = segment absent
@@ -60,6 +60,7 @@ struct GemmArgs {
     int ldc;
     int act;             // 0 none, 1 tanh
     int xcd_map;         // 1: XCD-aware tile order (set by the launcher for skinny-M shapes)
+    int dbg;             // S2VT_ABLATE builds only: timing ablation bits (1 no MFMA, 2 no LDS stores, 4 no global loads, 8 no barrier, 16 no fragment reads)
     int splits;          // >1: order-free split-K over blockIdx.y (backward data path only, nseg == 1)
     int kper;            //     K range per split (multiple of BK)
     size_t slab_stride;  //     floats between the partial-sum slabs of consecutive splits
@@ -94,43 +95,73 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+// a wave-uniform value as an opaque SGPR value (v_readfirstlane): the optimizer cannot look through it
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const float* uniform(const float* p)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+}
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2>
 struct GemmCfg {
     static constexpr int NT = 64 * WM * WN;
     static constexpr int BM = WM * TM * 16;
     static constexpr int BN = WN * TN * 16;
-    static constexpr int TNG = TN / NG;            // subtiles per group per wave
-    static constexpr int CG = WN * TNG * 16;       // tile columns per group
+    // EPI_LSTM_GW ("gate per wave"): the four waves along N each take ONE gate column group of the same
+    // TN*16 hidden units (WN == 4 == NG), so a workgroup is BM rows x TN*16 units and the grid can be cut
+    // to ~one workgroup per CU for any M; the gates of a unit meet through LDS in the epilogue.
+    static constexpr bool GW = (EPI == EPI_LSTM_GW);
+    static constexpr int TNG = GW ? TN : TN / NG;            // subtiles per group per wave
+    static constexpr int CG = GW ? TN * 16 : WN * TNG * 16;  // tile columns per group
+    static constexpr int ZS = 4 * CG + 4;                    // GW gate-exchange image: floats per row
     static constexpr int SB = (BN % 32 == 16) ? BN : BN + 16;
     static constexpr int A4 = (BM * (BK / 4) + NT - 1) / NT;   // float4 per thread per chunk
     static constexpr int B4 = (BK * (BN / 4) + NT - 1) / NT;
-    static constexpr int LDS_FLOATS = 2 * (BM * SA + BK * SB);
-    // prefetch ring depth (chunks in flight per thread): the skinny-M kernels are bound by operand bytes
-    // in flight per CU (measured: ~3500-cycle loaded latency), so the ring is as deep as ~96 staging
-    // VGPRs allow, between 2 and 6 slots.
+    static constexpr int LOOP_FLOATS = NBUF * (BM * SA + BK * SB);
+    static constexpr int LDS_FLOATS = (GW && BM * ZS > LOOP_FLOATS) ? BM * ZS : LOOP_FLOATS;
+    // Prefetch ring depth (chunks in flight per thread).  The skinny-M kernels are bound by operand bytes in
+    // flight per CU: a chunk of a small tile is computed in ~0.2 us while a load takes ~2 us under load, so the
+    // ring must hold ~10 chunks to cover it (measured: 16x16u tile, 4 chunks in flight: the loads cost 30 of
+    // 71 us).  Small tiles have the registers for that (few accumulators); big tiles run two workgroups per CU
+    // and keep the shallow ring.
 #ifndef S2VT_LAND_AT
-#define S2VT_LAND_AT 8   /* k-steps of a chunk computed before the next chunk is landed in LDS (8 = after all) */
+#define S2VT_LAND_AT 4   /* k-steps of a chunk computed before the next chunk is landed in LDS (8 = after all) */
 #endif
 #ifndef S2VT_PF_BUDGET
 #define S2VT_PF_BUDGET 48
 #endif
-    static constexpr int PF_RAW = S2VT_PF_BUDGET / (4 * (A4 + B4));
-    static constexpr int PF = PF_RAW < 2 ? 2 : (PF_RAW > 6 ? 6 : PF_RAW);
-    static_assert(TN % NG == 0, "TN must split evenly over the column groups");
+#ifndef S2VT_PF_BUDGET_SKINNY
+#define S2VT_PF_BUDGET_SKINNY 48
+#endif
+#ifndef S2VT_PF_MAX_SKINNY
+#define S2VT_PF_MAX_SKINNY 6
+#endif
+    static constexpr bool SKINNY = TM * TN <= 6;
+    static constexpr int PF_RAW = (SKINNY ? S2VT_PF_BUDGET_SKINNY : S2VT_PF_BUDGET) / (4 * (A4 + B4));
+    static constexpr int PF_CAP = SKINNY ? S2VT_PF_MAX_SKINNY : 6;
+    static constexpr int PF2 = PF_RAW < 2 ? 2 : (PF_RAW > PF_CAP ? PF_CAP : PF_RAW);
+    // NBUF == 3 (fragment-pipelined loop): the ring depth is even so that the fragment register set of a
+    // chunk (chunk & 1) is a compile-time index inside the loop unrolled by PF
+    static constexpr int PF = NBUF == 3 ? (PF2 & ~1) : PF2;
+    static_assert(NBUF == 2 || NBUF == 3, "two or three LDS stages");
+    static_assert(GW || TN % NG == 0, "TN must split evenly over the column groups");
+    static_assert(!GW || (WN == 4 && NG == 4), "gate-per-wave needs four waves along N");
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
 {
-    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC>;
+    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, NBUF>;
     constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, TNG = Cfg::TNG, CG = Cfg::CG, SB = Cfg::SB;
     constexpr int A4 = Cfg::A4, B4 = Cfg::B4;
     constexpr int PF = Cfg::PF;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BM][SA]
-    float* Bs = smem + 2 * BM * SA;         // [2][BK][SB]
+    float* As = smem;                       // [NBUF][BM][SA]
+    float* Bs = smem + NBUF * BM * SA;      // [NBUF][BK][SB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -166,8 +197,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         for (int j = 0; j < TN; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (g.cinit) {
-                const int col = (j / TNG) * g.gstride + n0 + (wn * TNG + j % TNG) * 16 + l15;
-                const bool cok = n0 + (wn * TNG + j % TNG) * 16 + l15 < g.N;
+                const int cu = Cfg::GW ? n0 + j * 16 + l15 : n0 + (wn * TNG + j % TNG) * 16 + l15;   // column within its group
+                const int col = (Cfg::GW ? wn : j / TNG) * g.gstride + cu;
+                const bool cok = cu < g.N;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int m = m0 + (wm * TM + i) * 16 + lq * 4 + r;
@@ -188,60 +220,69 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
 
     // ---- wave-uniform description of the K walk: chunk c -> (segment, offset) by scalar arithmetic
     const int kbeg = g.splits > 1 ? (int)blockIdx.y * g.kper : 0;
-    int slen[3], nch[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    // The three segment descriptors as named scalars: a run-time index into the by-value argument struct
+    // makes hipcc copy the struct to scratch, and scratch loads share vmcnt with the ring (measured: every
+    // chunk then drains the whole prefetch ring, 2.2 us per chunk).
+    auto seg_len = [&](const float* ptr, int sk, int i) __attribute__((always_inline)) {
         int k = 0;
-        if (i < g.nseg && g.seg[i].ptr != nullptr) {
-            k = g.seg[i].k - kbeg;
+        if (i < g.nseg && ptr != nullptr) {
+            k = sk - kbeg;
             if (g.splits > 1 && k > g.kper) k = g.kper;
             if (k < 0) k = 0;
         }
-        slen[i] = k;
-        nch[i] = (k + BK - 1) / BK;
-    }
-    const int cum0 = nch[0], cum1 = nch[0] + nch[1], nchunks = nch[0] + nch[1] + nch[2];
+        return k;
+    };
+    // (uniform() makes each field an opaque SGPR value: left alone, hipcc turns "sidx == 0 ? seg[0].f : ..."
+    // into a load through a selected ADDRESS, which forces the by-value argument struct into scratch)
+    const float* const sp0 = uniform(g.seg[0].ptr);
+    const float* const sp1 = uniform(g.seg[1].ptr);
+    const float* const sp2 = uniform(g.seg[2].ptr);
+    const int skw0 = uniform(g.seg[0].kw), skw1 = uniform(g.seg[1].kw), skw2 = uniform(g.seg[2].kw);
+    const int slen0 = uniform(seg_len(sp0, g.seg[0].k, 0)), slen1 = uniform(seg_len(sp1, g.seg[1].k, 1)),
+              slen2 = uniform(seg_len(sp2, g.seg[2].k, 2));
+    const int nch0 = (slen0 + BK - 1) / BK, nch1 = (slen1 + BK - 1) / BK, nch2 = (slen2 + BK - 1) / BK;
+    const int cum0 = nch0, cum1 = nch0 + nch1, nchunks = nch0 + nch1 + nch2;
 
     // Row offsets of this thread's A slots for every segment, resolved ONCE (gather / broadcast index
     // loads happen here, never inside the pipelined loop).  -1 marks a row beyond M / an absent segment.
     int aoff0[A4], aoff1[A4], aoff2[A4];
-    auto row_offsets = [&](int sidx, int (&ao)[A4]) {
+    auto row_offsets = [&](int sl, int rowmod, const int* rowidx, const unsigned long long* rowkey, int ld, int (&ao)[A4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
             const int idx = tid + i * NT;
             int m = m0 + idx / (BK / 4);
             int off = -1;
-            if (slen[sidx] > 0 && idx < BM * (BK / 4) && m < g.M) {
-                const ASeg& sg = g.seg[sidx];
-                if (sg.rowmod > 0) m %= sg.rowmod;
-                if (sg.rowidx) m = sg.rowidx[m];
-                if (sg.rowkey) m = (int)(~(uint32_t)sg.rowkey[m]);
-                off = m * sg.ld + kbeg;
+            if (sl > 0 && idx < BM * (BK / 4) && m < g.M) {
+                if (rowmod > 0) m %= rowmod;
+                if (rowidx) m = rowidx[m];
+                if (rowkey) m = (int)(~(uint32_t)rowkey[m]);
+                off = m * ld + kbeg;
             }
             ao[i] = off;
         }
     };
-    row_offsets(0, aoff0);
-    row_offsets(1, aoff1);
-    row_offsets(2, aoff2);
+    row_offsets(slen0, g.seg[0].rowmod, g.seg[0].rowidx, g.seg[0].rowkey, g.seg[0].ld, aoff0);
+    row_offsets(slen1, g.seg[1].rowmod, g.seg[1].rowidx, g.seg[1].rowkey, g.seg[1].ld, aoff1);
+    row_offsets(slen2, g.seg[2].rowmod, g.seg[2].rowidx, g.seg[2].rowkey, g.seg[2].ld, aoff2);
 
     // Issue the global loads of chunk c into a ring slot.  UNCONDITIONAL and always safe: addresses are
     // clamped into the segment; the validity bits zero the out-of-range elements when the chunk lands.
     // A chunk index beyond the walk yields an all-zero chunk.
-    auto issue = [&](int c, f32x4 (&qa)[A4], f32x4 (&qb)[B4], unsigned& ma, unsigned& mb) {
-        const int cc_ = c < nchunks ? c : nchunks - 1;
-        const int sidx = (cc_ >= cum0 ? 1 : 0) + (cc_ >= cum1 ? 1 : 0);
-        const int cstart = sidx == 0 ? 0 : (sidx == 1 ? cum0 : cum1);
-        const int koff = (c - cstart) * BK;
-        const float* abase = sidx == 0 ? g.seg[0].ptr : (sidx == 1 ? g.seg[1].ptr : g.seg[2].ptr);
-        const int sk = sidx == 0 ? slen[0] : (sidx == 1 ? slen[1] : slen[2]);
-        const int kw = (sidx == 0 ? g.seg[0].kw : (sidx == 1 ? g.seg[1].kw : g.seg[2].kw)) + kbeg;
+    // (The chunk -> segment selection is done by the S2VT_ISSUE macro at KERNEL scope, on plain local values:
+    // inside a lambda the same "sidx == 0 ? a : b" picks between by-reference captures, which hipcc folds
+    // into a load through a run-time offset into the closure object -- the closure, every local it points
+    // to and the argument struct then live in scratch, and scratch loads share vmcnt with the ring.)
+    auto issue_at = [&](int koff, const float* abase, int sk, int kw, const int (&aro)[A4], f32x4 (&qa)[A4], f32x4 (&qb)[B4],
+                        unsigned& ma, unsigned& mb) __attribute__((always_inline)) {
+#ifdef S2VT_ABLATE
+        if (g.dbg & 4) { ma = 0; mb = 0; return; }
+#endif
         unsigned va = 0, vb = 0;
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
             const int idx = tid + i * NT;
             const int k = koff + (idx % (BK / 4)) * 4;
-            const int ro = sidx == 0 ? aoff0[i] : (sidx == 1 ? aoff1[i] : aoff2[i]);
+            const int ro = aro[i];
             if constexpr (VEC) {
                 const bool ok = ro >= 0 && k < sk;
                 gload16(qa[i], abase + (ok ? ro + k : 0));
@@ -284,10 +325,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         ma = va;
         mb = vb;
     };
+#define S2VT_ISSUE(CHUNK, SLOT)                                                                          \
+    do {                                                                                                 \
+        const int c_ = (CHUNK);                                                                          \
+        const int cc_ = c_ < nchunks ? c_ : nchunks - 1;                                                 \
+        const int sidx_ = (cc_ >= cum0 ? 1 : 0) + (cc_ >= cum1 ? 1 : 0);                                 \
+        const int cstart_ = sidx_ == 0 ? 0 : (sidx_ == 1 ? cum0 : cum1);                                 \
+        const float* abase_ = sidx_ == 0 ? sp0 : (sidx_ == 1 ? sp1 : sp2);                               \
+        const int sk_ = sidx_ == 0 ? slen0 : (sidx_ == 1 ? slen1 : slen2);                               \
+        const int kw_ = (sidx_ == 0 ? skw0 : (sidx_ == 1 ? skw1 : skw2)) + kbeg;                         \
+        int aro_[A4];                                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < A4; ++i_)                                                \
+            aro_[i_] = sidx_ == 0 ? aoff0[i_] : (sidx_ == 1 ? aoff1[i_] : aoff2[i_]);                    \
+        issue_at((c_ - cstart_) * BK, abase_, sk_, kw_, aro_, ra[SLOT], rb[SLOT], pa[SLOT], pb[SLOT]);   \
+    } while (0)
 
     // Land a ring slot in an LDS buffer.  The caller has already waited (hand-counted vmcnt) for this
     // slot's loads; pin() keeps every consumer below that wait.
-    auto land = [&](int buf, f32x4 (&qa)[A4], f32x4 (&qb)[B4], unsigned ma, unsigned mb) {
+    auto land = [&](int buf, f32x4 (&qa)[A4], f32x4 (&qb)[B4], unsigned ma, unsigned mb) __attribute__((always_inline)) {
+#ifdef S2VT_ABLATE
+        if (g.dbg & 2) return;
+#endif
         float* a = As + buf * BM * SA;
         float* b = Bs + buf * BK * SB;
 #pragma unroll
@@ -317,9 +375,54 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         }
     };
 
+    // The ring's last PF-1 chunks (beyond the walk, never landed) are still in flight when the loop exits.
+    // Wait for them AND keep every ring register formally alive until after that wait: an asm load's
+    // destination is "written" at the asm statement as far as hipcc knows, so a slot that is never read again
+    // is free at once, and hipcc hands it to epilogue values (pure register code may be scheduled above an
+    // asm volatile) that the late-arriving load data then overwrites -- seen as wrong dwords / wild addresses
+    // whenever the operands were cold in cache.
+    auto drain_ring = [&]() __attribute__((always_inline)) {
+        if constexpr (VEC) {
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+#pragma unroll
+                for (int i = 0; i < A4; ++i) pin(ra[j][i]);
+#pragma unroll
+                for (int i = 0; i < B4; ++i) pin(rb[j][i]);
+            }
+        }
+    };
+
     // MFMAs of k-steps [KS0, KS1) of one chunk (hipcc interleaves the fragment reads with the MFMAs).
-    auto compute = [&](int buf, auto ks0_, auto ks1_) {
+    auto compute = [&](int buf, auto ks0_, auto ks1_) __attribute__((always_inline)) {
         constexpr int KS0 = decltype(ks0_)::value, KS1 = decltype(ks1_)::value;
+#ifdef S2VT_ABLATE
+        if (g.dbg & 16) {
+#pragma unroll
+            for (int ks = KS0; ks < KS1; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, 1.0f, acc[i][j], 0, 0, 0);
+            return;
+        }
+        if (g.dbg & 1) {
+            const float* a_ = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
+            const float* b_ = Bs + buf * BK * SB + lq * SB + l15;
+            float sacc = 0.f;
+#pragma unroll
+            for (int ks = KS0; ks < KS1; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) sacc += a_[i * 16 * SA + ks * 4];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sacc += b_[ks * 4 * SB + j * 16];
+            }
+            acc[0][0][0] += sacc;
+            return;
+        }
+#endif
         const float* a = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
         const float* b = Bs + buf * BK * SB + lq * SB + l15;
 #pragma unroll
@@ -328,7 +431,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
 #pragma unroll
             for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * SA + ks * 4];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = b[ks * 4 * SB + (j / TNG) * CG + (wn * TNG + j % TNG) * 16];
+            for (int j = 0; j < TN; ++j)
+                bv[j] = b[ks * 4 * SB + (Cfg::GW ? wn * CG + j * 16 : (j / TNG) * CG + (wn * TNG + j % TNG) * 16)];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -340,13 +444,86 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     using KH = std::integral_constant<int, S2VT_LAND_AT>;
     using K8 = std::integral_constant<int, BK / 4>;
 
+    if constexpr (NBUF == 3) {
+        // ---- fragment-pipelined loop (skinny-M kernels that run at one or two waves per SIMD): THREE LDS
+        // stages and TWO fragment register sets, so that the MFMAs of chunk c read only registers whose
+        // ds_reads were issued a whole iteration earlier, the ds_reads of chunk c+1 go out in one burst
+        // right after the barrier, and chunk c+2 is stored to LDS under the MFMAs:
+        //   global --(ring, PF chunks)--> registers --> LDS[(c+2)%3] --barrier--> fragments[(c+1)&1] --> MFMA(c)
+        constexpr int KS = BK / 4;
+        float fa[2][KS][TM], fb[2][KS][TN];
+        auto read_frags = [&](int buf, float (&qa)[KS][TM], float (&qb)[KS][TN]) __attribute__((always_inline)) {
+#ifdef S2VT_ABLATE
+            if (g.dbg & 16) return;
+#endif
+            const float* a = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
+            const float* b = Bs + buf * BK * SB + lq * SB + l15;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) qa[ks][i] = a[i * 16 * SA + ks * 4];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    qb[ks][j] = b[ks * 4 * SB + (Cfg::GW ? wn * CG + j * 16 : (j / TNG) * CG + (wn * TNG + j % TNG) * 16)];
+            }
+        };
+        auto mfma_range = [&](float (&qa)[KS][TM], float (&qb)[KS][TN], auto ks0_, auto ks1_) __attribute__((always_inline)) {
+            constexpr int KS0 = decltype(ks0_)::value, KS1 = decltype(ks1_)::value;
+#ifdef S2VT_ABLATE
+            if (g.dbg & 1) return;
+#endif
+#pragma unroll
+            for (int ks = KS0; ks < KS1; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[ks][i], qb[ks][j], acc[i][j], 0, 0, 0);
+        };
+        if (nchunks > 0) {
+            // prologue: chunks 0, 1 -> LDS[0], LDS[1]; chunks 2 .. PF in flight (slot = chunk % PF); fragments of chunk 0
+            S2VT_ISSUE(0, 0);
+            S2VT_ISSUE(1, 1);
+            if constexpr (VEC) wait_vmcnt<0>();
+            land(0, ra[0], rb[0], pa[0], pb[0]);
+            land(1, ra[1], rb[1], pa[1], pb[1]);
+#pragma unroll
+            for (int x = 2; x <= PF; ++x) S2VT_ISSUE(x, x % PF);
+            __syncthreads();
+            read_frags(0, fa[0], fb[0]);
+            int c = 0, b1 = 1, b2 = 2;          // LDS stages of chunks c+1 and c+2
+            bool more = true;
+            while (more) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    if (more) {
+                        read_frags(b1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+                        S2VT_ISSUE(c + 1 + PF, (j + 1) % PF);
+                        mfma_range(fa[j & 1], fb[j & 1], K0{}, KH{});
+                        if constexpr (VEC) wait_vmcnt<WAITN>();
+                        land(b2, ra[(j + 2) % PF], rb[(j + 2) % PF], pa[(j + 2) % PF], pb[(j + 2) % PF]);
+                        mfma_range(fa[j & 1], fb[j & 1], KH{}, K8{});
+#ifdef S2VT_ABLATE
+                        if (!(g.dbg & 8))
+#endif
+                        __syncthreads();
+                        ++c;
+                        b1 = b2;                                   // stages advance to (c+1)%3, (c+2)%3
+                        b2 = (b2 == 2) ? 0 : b2 + 1;
+                        more = c < nchunks;
+                    }
+                }
+            }
+            drain_ring();
+        }
+    } else
     if (nchunks > 0) {
         // prologue: chunk 0 -> LDS[0]; chunks 1 .. PF-1 in flight in ring slots 1 .. PF-1
-        issue(0, ra[0], rb[0], pa[0], pb[0]);
+        S2VT_ISSUE(0, 0);
         if constexpr (VEC) wait_vmcnt<0>();
         land(0, ra[0], rb[0], pa[0], pb[0]);
 #pragma unroll
-        for (int j = 1; j < PF; ++j) issue(j, ra[j], rb[j], pa[j], pb[j]);
+        for (int j = 1; j < PF; ++j) S2VT_ISSUE(j, j);
         __syncthreads();
 
         // Steady state: iteration c has LDS[c&1] = chunk c and ring slot (c+i)%PF = chunk c+i in flight
@@ -362,20 +539,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
                 if (more) {
-                    issue(c + PF, ra[j], rb[j], pa[j], pb[j]);
+                    S2VT_ISSUE(c + PF, j);
                     compute(c & 1, K0{}, KH{});
                     if constexpr (VEC) wait_vmcnt<WAITN>();
                     land((c + 1) & 1, ra[(j + 1) % PF], rb[(j + 1) % PF], pa[(j + 1) % PF], pb[(j + 1) % PF]);
                     compute(c & 1, KH{}, K8{});
+#ifdef S2VT_ABLATE
+                    if (!(g.dbg & 8))
+#endif
                     __syncthreads();
                     ++c;
                     more = c < nchunks;
                 }
             }
         }
-        if constexpr (VEC) wait_vmcnt<0>();     // the ring's last PF-1 (all-zero, beyond-the-walk) chunks: drain before the epilogue
+        drain_ring();
     }
 
+#undef S2VT_ISSUE
     // ------------------------------------------------------------------ epilogues
     if constexpr (EPI == EPI_STORE) {
 #pragma unroll
@@ -441,6 +622,55 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
                         gp[0] = si; gp[H] = tj; gp[2 * H] = sf; gp[3 * H] = so;
                     }
                 }
+        }
+    } else if constexpr (EPI == EPI_LSTM_GW) {
+        // gate exchange: wave wn holds gate wn of the tile's units; z goes through LDS as Z[row][gate][unit]
+        // (rows ZS floats apart), then every thread finishes (row, unit) pairs as in EPI_LSTM.
+        constexpr int ZS = Cfg::ZS;
+        const int H = g.N;
+        __syncthreads();                       // every wave is done reading the operand buffers
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    smem[((wm * TM + i) * 16 + lq * 4 + r) * ZS + wn * CG + j * 16 + l15] = acc[i][j][r];
+        __syncthreads();
+        for (int pidx = tid; pidx < BM * CG; pidx += NT) {
+            const int row = pidx / CG, uu = pidx % CG;
+            const int m = m0 + row, u = n0 + uu;
+            if (m >= g.M || u >= H) continue;
+            const float* z = smem + row * ZS + uu;
+            const float zi = z[0] + g.bias[u];
+            const float zj = z[CG] + g.bias[H + u];
+            const float zf = z[2 * CG] + g.bias[2 * H + u];
+            const float zo = z[3 * CG] + g.bias[3 * H + u];
+            const float si = dm_sigmoidf(zi);
+            const float tj = dm_tanhf(zj);
+            const float sf = dm_sigmoidf(zf + 1.0f);
+            const float so = dm_sigmoidf(zo);
+            const size_t o = (size_t)m * H + u;
+            const size_t op = (size_t)(g.cprev_rowmod > 0 ? m % g.cprev_rowmod : m) * H + u;
+            const float t1 = g.c_prev[op] * sf;
+            const float t2 = si * tj;
+            const float c = t1 + t2;
+            const float h = dm_tanhf(c) * so;
+            g.c_new[o] = c;
+            g.h_new[o] = h;
+            if (g.out) {
+                float ov = h;
+                if (g.keep < 1.0f) {
+                    const float k01 = dropout_keep01(g.seed_lo, g.seed_hi, (uint32_t)g.video_id[m], (uint32_t)g.sample_id[m],
+                                                     g.drop_code, (uint32_t)u, g.keep);
+                    ov = (h / g.keep) * k01;
+                }
+                g.out[o] = ov;
+            }
+            if (g.gates) {
+                float* gp = g.gates + (size_t)m * 4 * H + u;
+                gp[0] = si; gp[H] = tj; gp[2 * H] = sf; gp[3 * H] = so;
+            }
         }
     } else {  // EPI_PICK
 #pragma unroll

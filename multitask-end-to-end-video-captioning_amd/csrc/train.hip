@@ -29,7 +29,24 @@ struct TrainWs {
     float *WoutT, *W2T, *W1T, *dO2, *dZ1, *dZ2, *dX2, *dX1, *dH1, *slab, *dc;
 };
 
-constexpr int kSlabs = 4;
+// Split-K plan of the recurrent data-gradient product dz[M,4H] @ Whh^T[4H,H] (order-free): enough K slabs
+// that the launch has >= ~512 workgroups of the 64x32 tile; the slabs are summed by the next step's
+// pointwise kernel.
+constexpr int kMaxSlabs = 16;
+struct SlabPlan { int splits, kper, nslab; };
+SlabPlan slab_plan(int M, int H)
+{
+    const int K = 4 * H;
+    const long tiles = (long)((M + 63) / 64) * ((H + 31) / 32);
+    int splits = (int)((512 + tiles - 1) / tiles);
+    if (splits < 1) splits = 1;
+    if (splits > kMaxSlabs) splits = kMaxSlabs;
+    SlabPlan p;
+    p.kper = ((K + splits - 1) / splits + BK - 1) / BK * BK;      // what nn_bwd computes from `splits`
+    p.nslab = (K + p.kper - 1) / p.kper;
+    p.splits = splits;
+    return p;
+}
 
 size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
 {
@@ -47,7 +64,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.dO2 = c.take<float>(Tc * n * H);
     w.dZ1 = c.take<float>(T * b * 4 * H); w.dZ2 = c.take<float>(T * n * 4 * H);
     w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * b * E); w.dH1 = c.take<float>(T * b * H);
-    w.slab = c.take<float>((size_t)kSlabs * n * H); w.dc = c.take<float>(n * H);
+    w.slab = c.take<float>((size_t)kMaxSlabs * n * H); w.dc = c.take<float>(n * H);
     if (out) *out = w;
     return c.off;
 }
@@ -195,16 +212,15 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
         HIP_TRY(nn_bwd(dlogits, V, w.WoutT, H, w.dO2, H, Tc * N, H, V, 1, 0, st));
     }
     // ---- LSTM2 back through time
-    const int kper = ((4 * H + kSlabs - 1) / kSlabs + BK - 1) / BK * BK;
-    const int nslab = (4 * H + kper - 1) / kper;     // what nn_bwd(..., kSlabs, ...) produces
+    const SlabPlan sp2 = slab_plan(N, H), sp1 = slab_plan(B, H);
     for (int t = T - 1; t >= 0; --t) {
         HIP_TRY(launch_lstm_bwd_pointwise(w.G2 + (size_t)t * 4 * NH, w.C2 + (t + 1) * NH, w.C2 + t * NH,
-                                          t == T - 1 ? nullptr : w.slab, nslab, NH,
+                                          t == T - 1 ? nullptr : w.slab, sp2.nslab, NH,
                                           t >= Tv ? w.dO2 + (size_t)(t - Tv) * NH : nullptr, H, t == T - 1 ? nullptr : w.dc,
                                           w.dc, w.dZ2 + (size_t)t * 4 * NH, N, H, keep, seed, 512u + (uint32_t)t, video_id,
                                           sample_id, st));
         if (t > 0) {
-            HIP_TRY(nn_bwd(w.dZ2 + (size_t)t * 4 * NH, 4 * H, w.W2T + (H + E), K2, w.slab, H, N, H, 4 * H, kSlabs, NH, st));
+            HIP_TRY(nn_bwd(w.dZ2 + (size_t)t * 4 * NH, 4 * H, w.W2T + (H + E), K2, w.slab, H, N, H, 4 * H, sp2.splits, NH, st));
         }
     }
     // d[out1 ; embed] for every step at once
@@ -215,10 +231,10 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
     HIP_TRY(launch_reduce_dropout(w.dX2, H + E, w.dH1, T, B, N, H, keep, seed, 256u, video_id, sample_id, st));
     for (int t = T - 1; t >= 0; --t) {
         HIP_TRY(launch_lstm_bwd_pointwise(w.G1 + (size_t)t * 4 * BH, w.C1 + (t + 1) * BH, w.C1 + t * BH,
-                                          t == T - 1 ? nullptr : w.slab, nslab, BH, w.dH1 + t * BH, H,
+                                          t == T - 1 ? nullptr : w.slab, sp1.nslab, BH, w.dH1 + t * BH, H,
                                           t == T - 1 ? nullptr : w.dc, w.dc, w.dZ1 + (size_t)t * 4 * BH, B, H, 1.0f, seed, 0u,
                                           nullptr, nullptr, st));
-        if (t > 0) HIP_TRY(nn_bwd(w.dZ1 + (size_t)t * 4 * BH, 4 * H, w.W1T + E, K1, w.slab, H, B, H, 4 * H, kSlabs, BH, st));
+        if (t > 0) HIP_TRY(nn_bwd(w.dZ1 + (size_t)t * 4 * BH, 4 * H, w.W1T + E, K1, w.slab, H, B, H, 4 * H, sp1.splits, BH, st));
     }
     HIP_TRY(nn_bwd(w.dZ1, 4 * H, w.W1T, K1, w.dX1, E, Tv * B, E, 4 * H, 1, 0, st));
 
