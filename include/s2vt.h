@@ -12,7 +12,8 @@
  *     fp32 (token ids int32), DEVICE pointers owned by the caller; the library allocates nothing
  *     on the device -- scratch comes from a caller-provided workspace (query *_workspace_bytes).
  *   - Every call takes a hipStream_t (as void*) and is asynchronous w.r.t. the host; no hidden
- *     synchronisation.  A handle-free API: all state is in the arguments.
+ *     synchronisation.  The core API is handle-free (all state is in the arguments); the session
+ *     API at the end wraps the samplers around a handle that owns its workspace.
  *   - Return value: 0 = S2VT_OK, < 0 = S2VT_E_*.  Never throws, never exits.  After
  *     S2VT_E_HIP, s2vt_last_hip_error() holds the hipError_t.
  *   - Numeric contract: forward contractions are ascending-k fp32 fmaf chains on
@@ -223,6 +224,64 @@ int s2vt_attr_head_fwd(const float* video, int32_t B, int32_t Tv, int32_t D, con
                        int32_t A, const float* labels, float* mean_feat, float* z, float* bce, s2vt_stream stream);
 int s2vt_attr_head_bwd(const float* mean_feat, const float* z, const float* labels, int32_t B, int32_t D, int32_t A,
                        float scale, float* dz_scratch, float* d_attr_W, float* d_attr_b, s2vt_stream stream);
+
+/* ==== session API + the single-op entry points of the boundary ============= */
+
+/* ---- session handle: owns ONE device workspace sized for (max_B, max_K); nothing else is allocated.
+ * s2vt_encode_fwd = encoding stage (tf_s2vt.py:97-122) + the decode-stage work that does not depend on a
+ * sampled word (the LSTM1 trajectory and its W2 partials); s2vt_decode_greedy = build_sampler
+ * (tf_s2vt.py:217-266; B = 1 is build_generator :169-214); s2vt_decode_multinomial = K runs of
+ * build_multinomial_sampler (reinforcement_multisampling_tf_s2vt.py:294-339, driven at :743-753) on the
+ * SAME encode -- any number of decode calls may follow one encode call.  ids_out: int32 [B, Tc] resp.
+ * [K*B, Tc] (sample-major).  One handle per (device, stream); a handle is not thread-safe. */
+typedef struct s2vt_handle s2vt_handle;
+int s2vt_create(const s2vt_dims* d, int32_t max_B, int32_t max_K, s2vt_handle** out);
+int s2vt_destroy(s2vt_handle* h);
+int s2vt_encode_fwd(s2vt_handle* h, const s2vt_params* p, const float* video, int32_t B, s2vt_stream stream);
+int s2vt_decode_greedy(s2vt_handle* h, const s2vt_params* p, int32_t* ids_out, s2vt_stream stream);
+int s2vt_decode_multinomial(s2vt_handle* h, const s2vt_params* p, int32_t K, uint64_t seed, int32_t video_base,
+                            int32_t* ids_out, s2vt_stream stream);
+
+/* ---- BasicLSTMCell weight layouts.  The kernels consume the TF layout directly (W[in+H, 4H], columns
+ * [i | j | f | o], rows [x ; h]); these convert to / from a split, gate-interleaved form
+ * (Wx[in, H, 4], Wh[H, H, 4]: the four gates of a unit adjacent) for hosts that keep i2h / h2h apart. */
+int s2vt_pack_weights(const float* W_tf, int32_t in_dim, int32_t H, float* Wx_packed, float* Wh_packed, s2vt_stream stream);
+int s2vt_unpack_weights(const float* Wx_packed, const float* Wh_packed, int32_t in_dim, int32_t H, float* W_tf,
+                        s2vt_stream stream);
+
+/* ---- frame embedding backward (gradient of tf.nn.xw_plus_b, tf_s2vt.py:98): ACCUMULATES
+ * d_encode_image_W[d, E] += video[B*Tv, d]^T @ d_emb[B*Tv, E] and d_encode_image_b[E] += colsum(d_emb). */
+int s2vt_frame_embed_bwd(const s2vt_dims* d, const float* video, const float* d_emb, int32_t B, float* d_encode_image_W,
+                         float* d_encode_image_b, s2vt_stream stream);
+
+/* ---- BasicLSTMCell backward, one step (inverse of s2vt_lstm_cell_fwd's pointwise part): gates [M,4H] as
+ * saved by the forward, dh [M,H] = total gradient w.r.t. h' (recurrent + output), dc_in [M,H] or NULL,
+ * c_prev NULL = zero state.  Writes dz [M,4H] (pre-activation gate gradients, columns i|j|f|o) and
+ * dc_prev [M,H]; the weight / input gradients are contractions with dz (s2vt_gemm / s2vt_bptt_bwd). */
+int s2vt_lstm_cell_bwd(const float* gates, const float* c_new, const float* c_prev, const float* dh, const float* dc_in,
+                       float* dz, float* dc_prev, int32_t M, int32_t H, s2vt_stream stream);
+
+/* ---- the two objectives by name.  s2vt_xent_smooth_fwd_bwd: tf.losses.softmax_cross_entropy with
+ * label_smoothing (tf_s2vt.py:155).  s2vt_pg_nll_fwd_bwd: the reward-scaled NLL of
+ * reinforcement_multisampling_tf_s2vt.py:286-291,643-646 -- coef[t*N+n] = adv[n] * mask[n,t] is formed on
+ * the device (coef_scratch: N*Tc floats), logits/target time-major; both overwrite logits with d/dlogits. */
+int s2vt_xent_smooth_fwd_bwd(float* logits, int32_t ld, int32_t R, int32_t V, const int32_t* target, const float* coef,
+                             float label_smoothing, float* nll, s2vt_stream stream);
+int s2vt_pg_nll_fwd_bwd(float* logits, int32_t ld, int32_t N, int32_t Tc, int32_t V, const int32_t* target_tm,
+                        const float* adv, const float* mask, float* coef_scratch, float* nll, float* lp_target,
+                        s2vt_stream stream);
+
+/* out[r, :] = Wemb[idx[r], :]  -- tf.nn.embedding_lookup (tf_s2vt.py:128-134). */
+int s2vt_embed_gather(const float* Wemb, int32_t ldw, const int32_t* idx, int32_t R, int32_t E, float* out, int32_t ldo,
+                      s2vt_stream stream);
+
+/* tf.clip_by_global_norm over one flat range (reinforcement_multisampling_tf_s2vt.py:650):
+ * g *= clip_norm / max(||g||, clip_norm); *sumsq_scratch receives ||g||^2 (before clipping). */
+int s2vt_global_norm_clip(float* g, int64_t n, float clip_norm, float* sumsq_scratch, s2vt_stream stream);
+
+/* In-place SUM all-reduce of the flat gradient bucket over an existing RCCL communicator (ncclComm_t as
+ * void*), on `stream`.  RCCL is resolved at run time; Python hosts use torch.distributed instead. */
+int s2vt_allreduce_grads(float* bucket, int64_t n, void* rccl_comm, s2vt_stream stream);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,20 @@ SIGNATURES = {
     "s2vt_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "s2vt_attr_head_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_attr_head_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "s2vt_create": (C.c_int, [_DP, _i32, _i32, C.POINTER(_vp)]),
+    "s2vt_destroy": (C.c_int, [_vp]),
+    "s2vt_encode_fwd": (C.c_int, [_vp, _PP, _vp, _i32, _vp]),
+    "s2vt_decode_greedy": (C.c_int, [_vp, _PP, _vp, _vp]),
+    "s2vt_decode_multinomial": (C.c_int, [_vp, _PP, _i32, _u64, _i32, _vp, _vp]),
+    "s2vt_pack_weights": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "s2vt_unpack_weights": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "s2vt_frame_embed_bwd": (C.c_int, [_DP, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "s2vt_lstm_cell_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "s2vt_xent_smooth_fwd_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp]),
+    "s2vt_pg_nll_fwd_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "s2vt_embed_gather": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "s2vt_global_norm_clip": (C.c_int, [_vp, _i64, _f32, _vp, _vp]),
+    "s2vt_allreduce_grads": (C.c_int, [_vp, _i64, _vp, _vp]),
 }
 
 

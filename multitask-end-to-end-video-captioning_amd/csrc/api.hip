@@ -181,13 +181,12 @@ int s2vt_frame_embed_fwd(const s2vt_dims* d, const s2vt_params* p, const float* 
 // ---------------------------------------------------------------------------------------------
 // samplers
 // ---------------------------------------------------------------------------------------------
-namespace {
-struct SampleWs {
-    float *emb, *Xp1, *c1, *h1, *P2, *c2e[2], *h2e[2], *c2[2], *h2[2];
-    unsigned long long* packed;
-    int32_t *vid, *sid, *bos;
-};
+}  // extern "C"
 
+namespace s2vt_api {
+
+// Workspace of one sampler pass.  Everything up to `split` depends on B only (the encode half); the rest on
+// the number of decode rows R.
 size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
 {
     const size_t H = d->lstm_dim, E = d->word_dim, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step, T = Tv + Tc;
@@ -196,59 +195,32 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
     t.Xp1 = c.take<float>((size_t)B * Tv * 4 * H);
     t.c1 = c.take<float>((T + 1) * B * H); t.h1 = c.take<float>((T + 1) * B * H);     // LSTM1 state history, slot 0 = zeros
     t.P2 = c.take<float>(T * B * 4 * H);                                                // h1[t+1] @ W2[0:H] for every step
-    for (int i = 0; i < 2; ++i) {
-        t.c2e[i] = c.take<float>((size_t)B * H); t.h2e[i] = c.take<float>((size_t)B * H);
-        t.c2[i] = c.take<float>((size_t)R * H); t.h2[i] = c.take<float>((size_t)R * H);
-    }
+    for (int i = 0; i < 2; ++i) { t.c2e[i] = c.take<float>((size_t)B * H); t.h2e[i] = c.take<float>((size_t)B * H); }
+    for (int i = 0; i < 2; ++i) { t.c2[i] = c.take<float>((size_t)R * H); t.h2[i] = c.take<float>((size_t)R * H); }
     t.packed = c.take<unsigned long long>((size_t)Tc * R);
     t.vid = c.take<int32_t>(R); t.sid = c.take<int32_t>(R); t.bos = c.take<int32_t>(R);
     if (w) *w = t;
     return c.off;
 }
-}  // namespace
 
-size_t s2vt_sample_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t K, int32_t with_greedy)
+// Encoding stage (tf_s2vt.py:97-122) plus everything of the decoding stage that does not depend on a
+// sampled word: frame embedding, the whole LSTM1 trajectory, its products with the out1 rows of W2, LSTM2 over
+// the Tv frames.  Leaves the encoder state in w.c2e/h2e[Tv & 1].
+int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, int B, const SampleWs& w, s2vt_stream stream)
 {
-    if (!dims_ok(d) || B <= 0 || K < 0) return 0;
-    Carver c(nullptr, 0);
-    return carve_sample(c, d, B, (K + (with_greedy ? 1 : 0)) * B, nullptr);
-}
-
-int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t K, int32_t with_greedy,
-                uint64_t seed, int32_t video_base, int32_t* ids_out, void* workspace, size_t workspace_bytes,
-                s2vt_stream stream)
-{
-    if (!dims_ok(d) || !p || !video || !ids_out || !workspace || B <= 0 || K < 0 || (K == 0 && !with_greedy))
-        return S2VT_E_BADARG;
-    if (!p->Wemb || !p->encode_image_W || !p->encode_image_b || !p->lstm1_W || !p->lstm1_b || !p->lstm2_W ||
-        !p->lstm2_b || !p->embed_word_W || !p->embed_word_b)
-        return S2VT_E_BADARG;
-    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
-    const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
-    const int R = (K + (with_greedy ? 1 : 0)) * B;
-    Carver c(workspace, workspace_bytes);
-    SampleWs w;
-    carve_sample(c, d, B, R, &w);
-    if (!c.ok()) return S2VT_E_WORKSPACE;
+    const int H = d->lstm_dim, E = d->word_dim, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
     hipStream_t st = S(stream);
-
-    // zero initial states (tf_s2vt.py:105-107) and the packed pick words
     const int T = Tv + Tc;
     const size_t BH = (size_t)B * H;
+    // zero initial states (tf_s2vt.py:105-107)
     HIP_TRY(hipMemsetAsync(w.c1, 0, BH * 4, st));
     HIP_TRY(hipMemsetAsync(w.h1, 0, BH * 4, st));
     HIP_TRY(hipMemsetAsync(w.c2e[0], 0, BH * 4, st));
     HIP_TRY(hipMemsetAsync(w.h2e[0], 0, BH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.packed, 0, (size_t)Tc * R * 8, st));
-    hipLaunchKernelGGL(sampler_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.vid, w.sid, B, K, R, video_base);
-    hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.bos, 1, R);   // <bos> = 1
-    HIP_TRY(hipGetLastError());
-
     int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
     if (rc != S2VT_OK) return rc;
 
     NoiseIds none{nullptr, nullptr, 0};
-    NoiseIds ids{w.vid, w.sid, seed};
     // Each cell product is the ascending-k chain of concat([x, h]) @ W (tf_s2vt.py:119-143).  The rows of W
     // that multiply inputs known before the step are consumed first, batched over time; the per-step
     // launch continues the chain from that partial with the rows whose inputs the step produces.
@@ -277,8 +249,26 @@ int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, in
                           none, 0, -1, st, w.P2 + (size_t)t * 4 * BH, 4 * H, 0));
         cur = nxt;
     }
-    // ---- decoding stage (tf_s2vt.py:126-153 as specialised by the samplers): LSTM2 + vocab at M = R rows;
-    // the R sample rows of a video share its out1 partial (row % B).
+    return S2VT_OK;
+}
+
+// Decoding stage (tf_s2vt.py:126-153 as specialised by the samplers): LSTM2 + vocab at M = R rows, K
+// multinomial row blocks then (with_greedy) one argmax block; the R rows of a video share its out1
+// partial (row % B).  Needs sample_encode's results in the same workspace.
+int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int with_greedy, uint64_t seed, int video_base,
+                  int32_t* ids_out, const SampleWs& w, s2vt_stream stream)
+{
+    const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
+    const int R = (K + (with_greedy ? 1 : 0)) * B;
+    hipStream_t st = S(stream);
+    const size_t BH = (size_t)B * H;
+    HIP_TRY(hipMemsetAsync(w.packed, 0, (size_t)Tc * R * 8, st));
+    hipLaunchKernelGGL(sampler_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.vid, w.sid, B, K, R, video_base);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.bos, 1, R);   // <bos> = 1
+    HIP_TRY(hipGetLastError());
+    NoiseIds none{nullptr, nullptr, 0};
+    NoiseIds ids{w.vid, w.sid, seed};
+    const int cur = Tv & 1;                  // where sample_encode left the encoder state
     int cur2 = 0;
     for (int t = 0; t < Tc; ++t) {
         const int nxt2 = cur2 ^ 1;
@@ -297,6 +287,40 @@ int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, in
     hipLaunchKernelGGL(unpack_ids_kernel, dim3((R * Tc + 255) / 256), dim3(256), 0, st, w.packed, ids_out, R, Tc);
     HIP_TRY(hipGetLastError());
     return S2VT_OK;
+}
+
+bool sampler_params_ok(const s2vt_params* p)
+{
+    return p && p->Wemb && p->encode_image_W && p->encode_image_b && p->lstm1_W && p->lstm1_b && p->lstm2_W && p->lstm2_b &&
+           p->embed_word_W && p->embed_word_b;
+}
+
+}  // namespace s2vt_api
+
+extern "C" {
+
+size_t s2vt_sample_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t K, int32_t with_greedy)
+{
+    if (!dims_ok(d) || B <= 0 || K < 0) return 0;
+    Carver c(nullptr, 0);
+    return carve_sample(c, d, B, (K + (with_greedy ? 1 : 0)) * B, nullptr);
+}
+
+int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t K, int32_t with_greedy,
+                uint64_t seed, int32_t video_base, int32_t* ids_out, void* workspace, size_t workspace_bytes,
+                s2vt_stream stream)
+{
+    if (!dims_ok(d) || !sampler_params_ok(p) || !video || !ids_out || !workspace || B <= 0 || K < 0 || (K == 0 && !with_greedy))
+        return S2VT_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
+    const int R = (K + (with_greedy ? 1 : 0)) * B;
+    Carver c(workspace, workspace_bytes);
+    SampleWs w;
+    carve_sample(c, d, B, R, &w);
+    if (!c.ok()) return S2VT_E_WORKSPACE;
+    int rc = sample_encode(d, p, video, B, w, stream);
+    if (rc != S2VT_OK) return rc;
+    return sample_decode(d, p, B, K, with_greedy, seed, video_base, ids_out, w, stream);
 }
 
 }  // extern "C"

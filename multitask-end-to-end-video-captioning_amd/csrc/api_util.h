@@ -117,6 +117,18 @@ inline hipError_t store_call(const ASeg* segs, int nseg, const float* W, int ldw
     return launch_gemm(a, EPI_STORE, cfg, st);
 }
 
+// ---- sampler halves (api.hip), shared with the session API (session.hip)
+struct SampleWs {
+    float *emb, *Xp1, *c1, *h1, *P2, *c2e[2], *h2e[2], *c2[2], *h2[2];
+    unsigned long long* packed;
+    int32_t *vid, *sid, *bos;
+};
+size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w);
+int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, int B, const SampleWs& w, s2vt_stream stream);
+int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int with_greedy, uint64_t seed, int video_base,
+                  int32_t* ids_out, const SampleWs& w, s2vt_stream stream);
+bool sampler_params_ok(const s2vt_params* p);
+
 inline bool dims_ok(const s2vt_dims* d)
 {
     return d && d->dim_image > 0 && d->n_words > 0 && d->word_dim > 0 && d->lstm_dim > 0 && d->n_video_lstm_step > 0 &&

@@ -183,8 +183,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         tile_n = (slot / ntile_m) * 8 + xcd;
         if (tile_n >= ntile_n) return;
     } else {
-        tile_n = blockIdx.x % ntile_n;
-        tile_m = blockIdx.x / ntile_n;
+        // Many-tile shapes: XCD b % 8 takes a contiguous band of the tile sequence (column tiles fastest), so the
+        // workgroups that share an A row block run on ONE XCD and it is fetched into one L2 instead of eight
+        // (bijective for any tile count).
+        const int nwg = ntile_m * ntile_n, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        tile_n = t % ntile_n;
+        tile_m = t / ntile_n;
     }
     const int m0 = tile_m * BM;
     const int n0 = tile_n * CG;             // within-group column offset

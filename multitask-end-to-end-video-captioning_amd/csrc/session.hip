@@ -1,0 +1,222 @@
+// session.hip -- the remaining entry points of the boundary listed in SURVEY.md section 8(b): a session handle
+// that owns its sampler workspace (create / destroy / encode / decode_greedy / decode_multinomial), the
+// single-op backward calls (frame embedding, LSTM cell), the two loss flavours by name (label-smoothed XE,
+// reward-scaled policy-gradient NLL), embedding gather, global-norm clip, weight (re)packing between the
+// TF BasicLSTMCell layout and a gate-interleaved split layout, and a thin RCCL all-reduce for C/C++ hosts.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include "api_util.h"
+
+using namespace s2vt_api;
+
+struct s2vt_handle {
+    s2vt_dims dims;
+    int32_t max_B, max_K;
+    void* ws;
+    size_t ws_bytes;
+    int32_t enc_B;          // batch of the last s2vt_encode_fwd (0 = none)
+};
+
+namespace {
+
+__global__ void pack_lstm_kernel(const float* W, int rows, int H, float* P, int to_packed)
+{
+    // TF layout: W[r, g*H + u]  <->  gate-interleaved: P[r, u*4 + g]   (g = i, j, f, o)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * 4 * H) return;
+    const int col = (int)(i % (4 * (size_t)H)), r = (int)(i / (4 * (size_t)H));
+    const int g = col / H, u = col % H;
+    const size_t a = (size_t)r * 4 * H + col, b = (size_t)r * 4 * H + (size_t)u * 4 + g;
+    if (to_packed) P[b] = W[a];
+    else P[a] = W[b];
+}
+
+__global__ void pg_coef_kernel(const float* adv, const float* mask, float* coef, int N, int Tc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // time-major row t*N + n
+    if (i >= N * Tc) return;
+    const int t = i / N, n = i % N;
+    coef[i] = adv[n] * mask[n * Tc + t];
+}
+
+__global__ void gather_rows_kernel(const float* W, int ldw, const int32_t* idx, int R, int E, float* out, int ldo)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* src = W + (size_t)idx[r] * ldw;
+    for (int e = threadIdx.x & 63; e < E; e += 64) out[(size_t)r * ldo + e] = src[e];
+}
+
+__global__ void scale_by_clip_kernel(float* g, int64_t n, const float* sumsq, float clip)
+{
+    const float s = clip / fmaxf(sqrtf(*sumsq), clip);          // tf.clip_by_global_norm
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = g[i] * s;
+}
+
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+
+}  // namespace
+
+extern "C" {
+
+int s2vt_create(const s2vt_dims* d, int32_t max_B, int32_t max_K, s2vt_handle** out)
+{
+    if (!dims_ok(d) || max_B <= 0 || max_K < 0 || !out) return S2VT_E_BADARG;
+    s2vt_handle* h = new (std::nothrow) s2vt_handle;
+    if (!h) return S2VT_E_BADARG;
+    h->dims = *d; h->max_B = max_B; h->max_K = max_K; h->enc_B = 0; h->ws = nullptr;
+    h->ws_bytes = s2vt_sample_workspace_bytes(d, max_B, max_K, 1);
+    hipError_t e = hipMalloc(&h->ws, h->ws_bytes);
+    if (e != hipSuccess) { delete h; return hip_fail(e); }
+    *out = h;
+    return S2VT_OK;
+}
+
+int s2vt_destroy(s2vt_handle* h)
+{
+    if (!h) return S2VT_OK;
+    hipError_t e = h->ws ? hipFree(h->ws) : hipSuccess;
+    delete h;
+    return e == hipSuccess ? S2VT_OK : hip_fail(e);
+}
+
+int s2vt_encode_fwd(s2vt_handle* h, const s2vt_params* p, const float* video, int32_t B, s2vt_stream stream)
+{
+    if (!h || !sampler_params_ok(p) || !video || B <= 0 || B > h->max_B) return S2VT_E_BADARG;
+    Carver c(h->ws, h->ws_bytes);
+    SampleWs w;
+    carve_sample(c, &h->dims, B, (h->max_K + 1) * B, &w);
+    if (!c.ok()) return S2VT_E_WORKSPACE;
+    int rc = sample_encode(&h->dims, p, video, B, w, stream);
+    h->enc_B = rc == S2VT_OK ? B : 0;
+    return rc;
+}
+
+static int decode_common(s2vt_handle* h, const s2vt_params* p, int K, int greedy, uint64_t seed, int video_base, int32_t* ids_out,
+                         s2vt_stream stream)
+{
+    if (!h || !sampler_params_ok(p) || !ids_out || h->enc_B <= 0 || K < 0 || K > h->max_K) return S2VT_E_BADARG;
+    Carver c(h->ws, h->ws_bytes);
+    SampleWs w;
+    carve_sample(c, &h->dims, h->enc_B, (h->max_K + 1) * h->enc_B, &w);     // same layout as the encode call
+    return sample_decode(&h->dims, p, h->enc_B, K, greedy, seed, video_base, ids_out, w, stream);
+}
+
+int s2vt_decode_greedy(s2vt_handle* h, const s2vt_params* p, int32_t* ids_out, s2vt_stream stream)
+{
+    return decode_common(h, p, 0, 1, 0, 0, ids_out, stream);
+}
+
+int s2vt_decode_multinomial(s2vt_handle* h, const s2vt_params* p, int32_t K, uint64_t seed, int32_t video_base,
+                            int32_t* ids_out, s2vt_stream stream)
+{
+    if (K <= 0) return S2VT_E_BADARG;
+    return decode_common(h, p, K, 0, seed, video_base, ids_out, stream);
+}
+
+int s2vt_pack_weights(const float* W_tf, int32_t in_dim, int32_t H, float* Wx_packed, float* Wh_packed, s2vt_stream stream)
+{
+    if (!W_tf || !Wh_packed || in_dim < 0 || H <= 0 || (in_dim > 0 && !Wx_packed)) return S2VT_E_BADARG;
+    const size_t nx = (size_t)in_dim * 4 * H, nh = (size_t)H * 4 * H;
+    if (nx) hipLaunchKernelGGL(pack_lstm_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, S(stream), W_tf, in_dim, H, Wx_packed, 1);
+    hipLaunchKernelGGL(pack_lstm_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, S(stream), W_tf + nx, H, H, Wh_packed, 1);
+    HIP_TRY(hipGetLastError());
+    return S2VT_OK;
+}
+
+int s2vt_unpack_weights(const float* Wx_packed, const float* Wh_packed, int32_t in_dim, int32_t H, float* W_tf, s2vt_stream stream)
+{
+    if (!W_tf || !Wh_packed || in_dim < 0 || H <= 0 || (in_dim > 0 && !Wx_packed)) return S2VT_E_BADARG;
+    const size_t nx = (size_t)in_dim * 4 * H, nh = (size_t)H * 4 * H;
+    if (nx) hipLaunchKernelGGL(pack_lstm_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, S(stream), Wx_packed, in_dim, H, W_tf, 0);
+    hipLaunchKernelGGL(pack_lstm_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, S(stream), Wh_packed, H, H, W_tf + nx, 0);
+    HIP_TRY(hipGetLastError());
+    return S2VT_OK;
+}
+
+int s2vt_frame_embed_bwd(const s2vt_dims* d, const float* video, const float* d_emb, int32_t B, float* d_encode_image_W,
+                         float* d_encode_image_b, s2vt_stream stream)
+{
+    if (!dims_ok(d) || !video || !d_emb || !d_encode_image_W || !d_encode_image_b || B < 0) return S2VT_E_BADARG;
+    if (B == 0) return S2VT_OK;
+    const int R = B * d->n_video_lstm_step, D = d->dim_image, E = d->word_dim;
+    TnArgs a{video, nullptr, D, d_emb, E, d_encode_image_W, E, R, D, E, 1};
+    HIP_TRY(launch_gemm_tn(a, S(stream)));
+    HIP_TRY(launch_colsum(d_emb, E, R, E, d_encode_image_b, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_lstm_cell_bwd(const float* gates, const float* c_new, const float* c_prev, const float* dh, const float* dc_in,
+                       float* dz, float* dc_prev, int32_t M, int32_t H, s2vt_stream stream)
+{
+    if (!gates || !c_new || !dh || !dz || !dc_prev || M < 0 || H <= 0) return S2VT_E_BADARG;
+    if (M == 0) return S2VT_OK;
+    HIP_TRY(launch_lstm_bwd_pointwise(gates, c_new, c_prev, nullptr, 0, 0, dh, H, dc_in, dc_prev, dz, M, H, 1.0f, 0, 0u, nullptr,
+                                      nullptr, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_xent_smooth_fwd_bwd(float* logits, int32_t ld, int32_t R, int32_t V, const int32_t* target, const float* coef,
+                             float label_smoothing, float* nll, s2vt_stream stream)
+{
+    return s2vt_softmax_nll_fwd_bwd(logits, ld, R, V, target, coef, label_smoothing, nll, nullptr, stream);
+}
+
+int s2vt_pg_nll_fwd_bwd(float* logits, int32_t ld, int32_t N, int32_t Tc, int32_t V, const int32_t* target_tm,
+                        const float* adv, const float* mask, float* coef_scratch, float* nll, float* lp_target,
+                        s2vt_stream stream)
+{
+    if (!logits || !target_tm || !adv || !mask || !coef_scratch || N < 0 || Tc <= 0) return S2VT_E_BADARG;
+    if (N == 0) return S2VT_OK;
+    hipLaunchKernelGGL(pg_coef_kernel, dim3((N * Tc + 255) / 256), dim3(256), 0, S(stream), adv, mask, coef_scratch, N, Tc);
+    HIP_TRY(hipGetLastError());
+    return s2vt_softmax_nll_fwd_bwd(logits, ld, N * Tc, V, target_tm, coef_scratch, 0.0f, nll, lp_target, stream);
+}
+
+int s2vt_embed_gather(const float* Wemb, int32_t ldw, const int32_t* idx, int32_t R, int32_t E, float* out, int32_t ldo,
+                      s2vt_stream stream)
+{
+    if (!Wemb || !idx || !out || R < 0 || E <= 0 || ldw < E || ldo < E) return S2VT_E_BADARG;
+    if (R == 0) return S2VT_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, S(stream), Wemb, ldw, idx, R, E, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return S2VT_OK;
+}
+
+int s2vt_global_norm_clip(float* g, int64_t n, float clip_norm, float* sumsq_scratch, s2vt_stream stream)
+{
+    if (!g || !sumsq_scratch || n < 0 || !(clip_norm > 0.0f)) return S2VT_E_BADARG;
+    HIP_TRY(hipMemsetAsync(sumsq_scratch, 0, sizeof(float), S(stream)));
+    HIP_TRY(launch_grad_finalize(g, nullptr, n, nullptr, 0.0f, sumsq_scratch, S(stream)));
+    if (n > 0) {
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(scale_by_clip_kernel, dim3(blocks), dim3(256), 0, S(stream), g, n, sumsq_scratch, clip_norm);
+        HIP_TRY(hipGetLastError());
+    }
+    return S2VT_OK;
+}
+
+int s2vt_allreduce_grads(float* bucket, int64_t n, void* rccl_comm, s2vt_stream stream)
+{
+    if (!bucket || n < 0 || !rccl_comm) return S2VT_E_BADARG;
+    // RCCL is resolved at run time: the process that owns the communicator has it loaded already
+    // (torch ships its own copy); a C++ host links librccl itself.
+    static nccl_allreduce_fn fn = [] {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!sym) {
+            void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (lib) sym = dlsym(lib, "ncclAllReduce");
+        }
+        return reinterpret_cast<nccl_allreduce_fn>(sym);
+    }();
+    if (!fn) return S2VT_E_BADARG;
+    const int rc = fn(bucket, bucket, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, rccl_comm, S(stream));
+    return rc == 0 ? S2VT_OK : S2VT_E_HIP;
+}
+
+}  // extern "C"

@@ -259,3 +259,116 @@ def attr_head_bwd(mean, z, labels, scale, d_attr_W, d_attr_b):
     check(lib().s2vt_attr_head_bwd(_ptr(mean), _ptr(z), _ptr(labels), B, D, A, float(scale), _ptr(dz), _ptr(d_attr_W),
                                    _ptr(d_attr_b), _stream()), "s2vt_attr_head_bwd")
     return dz
+
+
+# ---------------------------------------------------------------------------------------------
+# session API + single-op entry points (include/s2vt.h, last section)
+# ---------------------------------------------------------------------------------------------
+class Session:
+    """s2vt_create / s2vt_destroy: a handle that owns its sampler workspace.  encode once, then any
+    number of greedy / multinomial decodes on that encode."""
+
+    def __init__(self, dims: Dims, max_B: int, max_K: int):
+        self.dims = dims
+        self._h = C.c_void_p()
+        check(lib().s2vt_create(C.byref(dims), max_B, max_K, C.byref(self._h)), "s2vt_create")
+        self._B = 0
+
+    def close(self):
+        if self._h:
+            check(lib().s2vt_destroy(self._h), "s2vt_destroy")
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, params: Params, video):
+        _chk_f32(video)
+        assert video.is_contiguous()
+        self._B = video.shape[0]
+        check(lib().s2vt_encode_fwd(self._h, C.byref(params), _ptr(video), self._B, _stream()), "s2vt_encode_fwd")
+
+    def decode_greedy(self, params: Params):
+        ids = torch.empty((self._B, self.dims.n_caption_lstm_step), dtype=torch.int32, device="cuda")
+        check(lib().s2vt_decode_greedy(self._h, C.byref(params), _ptr(ids), _stream()), "s2vt_decode_greedy")
+        return ids
+
+    def decode_multinomial(self, params: Params, K: int, seed: int, video_base: int = 0):
+        ids = torch.empty((K * self._B, self.dims.n_caption_lstm_step), dtype=torch.int32, device="cuda")
+        check(lib().s2vt_decode_multinomial(self._h, C.byref(params), K, seed, video_base, _ptr(ids), _stream()),
+              "s2vt_decode_multinomial")
+        return ids
+
+
+def pack_weights(W_tf, in_dim: int):
+    _chk_f32(W_tf)
+    H = W_tf.shape[1] // 4
+    Wx = torch.empty((in_dim, H, 4), dtype=torch.float32, device=W_tf.device)
+    Wh = torch.empty((H, H, 4), dtype=torch.float32, device=W_tf.device)
+    check(lib().s2vt_pack_weights(_ptr(W_tf), in_dim, H, _ptr(Wx), _ptr(Wh), _stream()), "s2vt_pack_weights")
+    return Wx, Wh
+
+
+def unpack_weights(Wx, Wh):
+    _chk_f32(Wx, Wh)
+    in_dim, H = Wx.shape[0], Wh.shape[0]
+    W = torch.empty((in_dim + H, 4 * H), dtype=torch.float32, device=Wh.device)
+    check(lib().s2vt_unpack_weights(_ptr(Wx), _ptr(Wh), in_dim, H, _ptr(W), _stream()), "s2vt_unpack_weights")
+    return W
+
+
+def frame_embed_bwd(dims: Dims, video, d_emb, dW, db):
+    _chk_f32(video, d_emb, dW, db)
+    check(lib().s2vt_frame_embed_bwd(C.byref(dims), _ptr(video), _ptr(d_emb), video.shape[0], _ptr(dW), _ptr(db), _stream()),
+          "s2vt_frame_embed_bwd")
+
+
+def lstm_cell_bwd(gates, c_new, c_prev, dh, dc_in=None):
+    _chk_f32(gates, c_new, c_prev, dh, dc_in)
+    M, H = c_new.shape
+    dz = torch.empty((M, 4 * H), dtype=torch.float32, device=dh.device)
+    dc_prev = torch.empty_like(c_new)
+    check(lib().s2vt_lstm_cell_bwd(_ptr(gates), _ptr(c_new), _ptr(c_prev), _ptr(dh), _ptr(dc_in), _ptr(dz), _ptr(dc_prev), M, H,
+                                   _stream()), "s2vt_lstm_cell_bwd")
+    return dz, dc_prev
+
+
+def xent_smooth_fwd_bwd(logits, target, coef, label_smoothing=0.05):
+    _chk_f32(logits, coef)
+    R, V = logits.shape
+    nll = torch.empty(R, dtype=torch.float32, device=logits.device)
+    check(lib().s2vt_xent_smooth_fwd_bwd(_ptr(logits), logits.stride(0), R, V, _ptr(target), _ptr(coef), float(label_smoothing),
+                                         _ptr(nll), _stream()), "s2vt_xent_smooth_fwd_bwd")
+    return nll
+
+
+def pg_nll_fwd_bwd(logits, target_tm, adv, mask):
+    """logits [Tc*N, V] time-major (overwritten with d/dlogits), target_tm int32 [Tc*N], adv [N], mask [N,Tc]."""
+    _chk_f32(logits, adv, mask)
+    N, Tc = mask.shape
+    V = logits.shape[1]
+    coef = torch.empty(N * Tc, dtype=torch.float32, device=logits.device)
+    nll = torch.empty_like(coef)
+    lp = torch.empty_like(coef)
+    check(lib().s2vt_pg_nll_fwd_bwd(_ptr(logits), logits.stride(0), N, Tc, V, _ptr(target_tm), _ptr(adv), _ptr(mask), _ptr(coef),
+                                    _ptr(nll), _ptr(lp), _stream()), "s2vt_pg_nll_fwd_bwd")
+    return nll, lp, coef
+
+
+def embed_gather(Wemb, idx):
+    _chk_f32(Wemb)
+    assert idx.dtype == torch.int32 and idx.is_cuda
+    out = torch.empty((idx.numel(), Wemb.shape[1]), dtype=torch.float32, device=Wemb.device)
+    check(lib().s2vt_embed_gather(_ptr(Wemb), Wemb.stride(0), _ptr(idx), idx.numel(), Wemb.shape[1], _ptr(out), out.stride(0),
+                                  _stream()), "s2vt_embed_gather")
+    return out
+
+
+def global_norm_clip(g, clip_norm: float):
+    _chk_f32(g)
+    sumsq = torch.empty(1, dtype=torch.float32, device=g.device)
+    check(lib().s2vt_global_norm_clip(_ptr(g), g.numel(), float(clip_norm), _ptr(sumsq), _stream()), "s2vt_global_norm_clip")
+    return sumsq
