@@ -66,12 +66,14 @@ def cpu_baseline():
                 "sample": f"one greedy sampler pass at B={B} ({tp:.1f} s, torch-CPU fp32); step rate extrapolated x{4 * K + 1} by flops"}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
+    nsteps = max(1, min(4, int(15.0 / max(est, 1e-3))))          # ~10-30 s of CPU work
     t0 = time.time()
-    T.reference_structured_step(p, m, v, 0, video, K, TC, r, b, gen=g)
-    dt = time.time() - t0
+    for i in range(nsteps):
+        T.reference_structured_step(p, m, v, i, video, K, TC, r, b, gen=g)
+    dt = (time.time() - t0) / nsteps
     return {"value": K * B * TC / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"1 full REINFORCE step (B={B}, K={K}, Tc={TC}, |V|={V}) structured as the reference: "
-                      f"{K}+1 sampler passes + fwd/bwd at {K * B} rows + clip + Adam, torch-CPU fp32, {cores} threads, {dt:.1f} s"}
+            "sample": f"{nsteps} full REINFORCE step(s) (B={B}, K={K}, Tc={TC}, |V|={V}) structured as the reference: "
+                      f"{K}+1 sampler passes + fwd/bwd at {K * B} rows + clip + Adam, torch-CPU fp32, {cores} threads, {dt:.1f} s/step"}
 
 
 def main():
@@ -87,11 +89,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
+    local = local % ndev                          # (functional tests may put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("S2VT_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for single-GPU functional tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import s2vt_amd
     from s2vt_amd import model as M
@@ -145,7 +153,8 @@ def main():
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get(f"{dom['kernel_class']}:{dom['name']}")
+                ent = json.load(open(pmc)).get(f"{dom['kernel_class']}:{dom['name']}")
+                traffic = ent["bytes_per_launch"] if ent else None        # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, tools/collect_pmc.sh)
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "kernel": f"{cls}, tile {dom['name']}", "launches": dom["launches"],

@@ -1,0 +1,133 @@
+"""Data side of the callers: feature files, sentence files, vocabulary, per-video reference index.
+
+Mirrors get_video_feature_caption_pair (tf_s2vt.py:324-345, same in reinforcement_multisampling_tf_s2vt.py
+:524-545) and the vocabulary read in train() (:605-610), re-designed for the device path:
+
+* the feature TEXT file ("vid<N>_frame_<k>,f0,...") is read ONCE by the C++ reader of libs2vt_host.so into a
+  contiguous float32 [n_videos, Tv, d] array and cached next to the file as .npy (+ the video order); the
+  reference re-parses it into Python lists of strings on every run;
+* batches are gathered into a pinned host buffer so the [B, Tv, d] block goes to HBM in one coalesced copy;
+* `CaptionIndex` answers "all captions of video v" from a dict built once; the reference scans all ~48k
+  (id, sentence) pairs per video per step (get_captions, reinforcement_multisampling_tf_s2vt.py:600-601).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import reward
+
+
+def read_sentences(sent_file):
+    """[(video_id, sentence)] as an [n, 2] array of str, file order (tf_s2vt.py:327-331)."""
+    sents = []
+    with open(sent_file, "r") as f:
+        for line in f:
+            id_sent = line.strip().split("\t")
+            sents.append((id_sent[0], id_sent[1] if len(id_sent) > 1 else ""))
+    return np.array(sents, dtype=object).reshape(-1, 2)
+
+
+def read_vocabulary(vocabulary_file):
+    with open(vocabulary_file, "r") as f:
+        return [line.rstrip() for line in f]
+
+
+class FeatureStore:
+    """All videos of one feature file as float32 [n_videos, Tv, d]; `store[vid]` / `store.batch(vids)`."""
+
+    def __init__(self, features: np.ndarray, video_ids):
+        assert features.ndim == 3 and features.dtype == np.float32 and len(video_ids) == features.shape[0]
+        self.features = np.ascontiguousarray(features)
+        self.video_ids = list(video_ids)
+        self.index = {v: i for i, v in enumerate(self.video_ids)}
+        self._pinned = None
+
+    @classmethod
+    def from_csv(cls, feature_file, cache=True):
+        npy, meta = feature_file + ".f32.npy", feature_file + ".ids.json"
+        if cache and os.path.exists(npy) and os.path.exists(meta) and os.path.getmtime(npy) >= os.path.getmtime(feature_file):
+            return cls(np.load(npy), json.load(open(meta)))
+        L = reward.host_lib()
+        L.s2vt_feature_csv_scan.restype = C.c_int
+        L.s2vt_feature_csv_scan.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.s2vt_feature_csv_read.restype = C.c_int
+        L.s2vt_feature_csv_read.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        n, d = C.c_int64(), C.c_int32()
+        rc = L.s2vt_feature_csv_scan(feature_file.encode(), C.byref(n), C.byref(d))
+        if rc != 0:
+            raise IOError(f"cannot read {feature_file} (code {rc}: -2 open failed, -3 ragged rows)")
+        rows = np.empty((n.value, d.value), np.float32)
+        ids = np.zeros((n.value, 64), np.uint8)
+        rc = L.s2vt_feature_csv_read(feature_file.encode(), n.value, d.value, rows.ctypes.data, ids.ctypes.data, 64)
+        if rc != 0:
+            raise IOError(f"malformed feature file {feature_file} (code {rc})")
+        frame_ids = [bytes(r).split(b"\0", 1)[0].decode() for r in ids]
+        order, per = [], {}
+        for i, fid in enumerate(frame_ids):                    # video id = text before the first '_' (tf_s2vt.py:336)
+            v = fid.split("_")[0]
+            if v not in per:
+                per[v] = []
+                order.append(v)
+            per[v].append(i)
+        lengths = {len(v) for v in per.values()}
+        assert len(lengths) == 1, f"videos with different numbers of frames: {sorted(lengths)}"   # tf_s2vt.py:342
+        feats = np.stack([rows[per[v]] for v in order])
+        if cache:
+            try:
+                np.save(npy, feats)
+                json.dump(order, open(meta, "w"))
+            except OSError:
+                pass
+        return cls(feats, order)
+
+    def __len__(self):
+        return len(self.video_ids)
+
+    def __contains__(self, vid):
+        return vid in self.index
+
+    def __getitem__(self, vid):
+        return self.features[self.index[vid]]
+
+    def batch(self, vids, pinned=True):
+        """[B, Tv, d] float32; a pinned torch tensor when torch + a GPU are present (else numpy)."""
+        rows = np.fromiter((self.index[v] for v in vids), np.int64, len(vids))
+        if pinned:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    B = len(rows)
+                    if self._pinned is None or self._pinned.shape[0] < B:
+                        self._pinned = torch.empty((B,) + self.features.shape[1:], dtype=torch.float32).pin_memory()
+                    out = self._pinned[:B]
+                    np.take(self.features, rows, axis=0, out=out.numpy())
+                    return out
+            except ImportError:
+                pass
+        return self.features[rows]
+
+
+def get_video_feature_caption_pair(sent_file, feature_file):
+    """(sents [n,2], FeatureStore) -- the reference returns (np.array(sents), dict video -> list of Tv rows)."""
+    return read_sentences(sent_file), FeatureStore.from_csv(feature_file)
+
+
+class CaptionIndex:
+    """video id -> all of its captions (what get_captions(train_captions, vid) scans for)."""
+
+    def __init__(self, sents):
+        self.by_video = {}
+        for vid, s in sents:
+            self.by_video.setdefault(vid, []).append(s)
+        self.video_ids = list(self.by_video)
+        self.row = {v: i for i, v in enumerate(self.video_ids)}
+
+    def get_captions(self, vid):
+        return self.by_video[vid]
+
+    def refs_by_video(self):
+        return [self.by_video[v] for v in self.video_ids]

@@ -21,16 +21,28 @@ def shard_range(n_videos: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+def _all_reduce_sum(t: torch.Tensor, group=None):
+    """SUM all-reduce in place.  Backend "nccl" (= RCCL on ROCm) reduces device memory directly; under
+    "gloo" (CPU tests, and the single-GPU functional test of the N>1 path) a device tensor is staged
+    through the host."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 def allreduce_bucket(grad_flat: torch.Tensor, n_params: int, local_mask_sum, group=None):
     """In place: grad_flat[:n_params] <- sum over ranks, returns the GLOBAL sum(mask) as a 1-element
     view of the bucket's tail slot (so one collective carries both)."""
     grad_flat[n_params] = local_mask_sum
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(grad_flat, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(grad_flat, group)
     return grad_flat[n_params:n_params + 1]
 
 
 def allreduce_small(t: torch.Tensor, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(t, group)
     return t

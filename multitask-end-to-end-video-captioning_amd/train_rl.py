@@ -1,0 +1,95 @@
+"""Self-critical REINFORCE driver: the counterpart of train() in reinforcement_multisampling_tf_s2vt.py
+:602-880 on the HIP path.
+
+Step of the reference                                   | here
+--------------------------------------------------------+---------------------------------------------------
+9 sess.run of the sampler graphs (:743-753), each       | model.sample(video, K, with_greedy=True): ONE call,
+  re-encoding the batch, vstack on the host (:757-764)  |   one encode, rows already sample-major
+decode_captions_masks: ids -> strings + mask (:783-784) | mask on the device (cumsum of <eos>), no strings
+get_captions scan + evaluate_captions_cider x2 (:787-803| reward.CiderD.score_ids on the int32 ids (C++, threads),
+  pyciderevalcap on strings)                            |   references indexed per video once
+features tiled x8 on the host (:779-782)                | never tiled: rows address video n % B
+sess.run([train_op, sum_loss]) (:823)                   | model.reinforce_update (forward with dropout, reward-scaled
+                                                        |   NLL, BPTT, all-reduce, clip 5, Adam, lr 1e-6 * 0.5^(step//1000))
+"""
+from __future__ import annotations
+
+import argparse
+import random
+import time
+
+import numpy as np
+
+from . import hostglue, reward
+from .train_common import Config, Corpus, epoch_batches, greedy_eval, learning_rate, optimistic_restore, save_checkpoint
+
+
+def rl_config(**kw):
+    base = dict(start_learning_rate=1e-6, decay_steps=1000, clip_norm=5.0, batch_size=256, multisample=8,
+                model_name="reinforce_multisample_model")
+    base.update(kw)
+    return Config(**base)
+
+
+def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, restore=None, log=print):
+    import torch
+    from . import model as M
+    wordtoix, ixtoword = hostglue.preProBuildWordVocab(train_corpus.vocabulary)
+    K = cfg.multisample
+    if model is None:
+        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, cfg.batch_size,
+                                          cfg.n_video_lstm_step + cfg.n_caption_lstm_step, cfg.n_video_lstm_step,
+                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed, multisample=K)
+    if restore:
+        log(f"restored: {optimistic_restore(model, restore)}")
+    scorer = reward.CiderD(train_corpus.index.refs_by_video(), wordtoix)
+    test_scorer = reward.CiderD(test_corpus.index.refs_by_video(), wordtoix) if test_corpus is not None else None
+    rng = random.Random(cfg.seed)
+    caps = train_corpus.captions
+    history = []
+    if test_corpus is not None:
+        log(f"before train: ciderD {greedy_eval(model, test_corpus, ixtoword, test_scorer, cfg.batch_size)[1]}")
+    for epoch in range(cfg.n_epochs):
+        losses, adv = [], []
+        for it, idx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
+            if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
+                break
+            t0 = time.time()
+            vid = caps[idx, 0]
+            video = train_corpus.features.batch(vid)
+            samples, greedy_words = model.sample(video, K, True, seed=cfg.seed + 7919 * (model.global_step + 1))
+            is_eos = samples == 0
+            mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()        # 1 up to and incl. the first <eos>
+            rows = np.asarray([train_corpus.index.row[v] for v in vid], np.int32)
+            r = scorer.score_ids(samples.cpu().numpy(), np.tile(rows, K))               # [K*B], sample-major like the ids
+            b = scorer.score_ids(greedy_words.cpu().numpy(), rows)                      # [B]
+            st = model.reinforce_update(video, samples, mask, r, hostglue.tile_baseline(b, K),
+                                        lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm)
+            losses.append(float(st.loss)); adv.append(float(r.mean() - b.mean()))
+            log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} loss: {losses[-1]:.5f} "
+                f"r: {r.mean():.4f} b: {b.mean():.4f} Elapsed time: {time.time() - t0:.3f}")
+        entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None, "r_minus_b": float(np.mean(adv)) if adv else None}
+        if test_corpus is not None:
+            _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, test_scorer, cfg.batch_size)
+        entry["checkpoint"] = save_checkpoint(model, cfg, epoch)
+        history.append(entry)
+        log(f"Epoch {epoch} is done: {entry}")
+    return model, history
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train-sents", required=True); ap.add_argument("--train-feats", required=True)
+    ap.add_argument("--test-sents"); ap.add_argument("--test-feats")
+    ap.add_argument("--vocab", required=True); ap.add_argument("--restore")
+    ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=8); ap.add_argument("--model-path", default="./new_multisamp_reinforcement_models")
+    a = ap.parse_args()
+    cfg = rl_config(n_epochs=a.epochs, batch_size=a.batch_size, multisample=a.samples, model_path=a.model_path)
+    tr = Corpus(a.train_sents, a.train_feats, vocabulary_file=a.vocab)
+    te = Corpus(a.test_sents, a.test_feats, vocabulary=tr.vocabulary) if a.test_sents and a.test_feats else None
+    train(cfg, tr, te, restore=a.restore)
+
+
+if __name__ == "__main__":
+    main()

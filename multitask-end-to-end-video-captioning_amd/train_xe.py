@@ -1,0 +1,69 @@
+"""Cross-entropy training driver: the counterpart of train() in tf_s2vt.py:404-560 on the HIP path.
+
+    python -m s2vt_amd.train_xe --train-sents S --train-feats F --test-sents S2 --test-feats F2 --vocab V
+
+Per step the reference runs sess.run([train_op, tf_loss]) on build_model (label-smoothed XE with the Q1
+batch-mean rule, weight decay, clip 10, Adam, lr 1e-3 halved every 5000 steps); here that is
+Video_Caption_Generator.xe_update.  One process per GPU under torch.distributed.run for data parallel."""
+from __future__ import annotations
+
+import argparse
+import random
+import time
+
+import numpy as np
+
+from . import hostglue, reward
+from .train_common import Config, Corpus, epoch_batches, greedy_eval, learning_rate, save_checkpoint
+
+
+def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, log=print):
+    import torch
+    from . import model as M
+    wordtoix, ixtoword = hostglue.preProBuildWordVocab(train_corpus.vocabulary)
+    if model is None:
+        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, cfg.batch_size,
+                                          cfg.n_video_lstm_step + cfg.n_caption_lstm_step, cfg.n_video_lstm_step,
+                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed)
+    scorer = reward.CiderD(test_corpus.index.refs_by_video(), wordtoix) if test_corpus is not None else None
+    rng = random.Random(cfg.seed)
+    caps = train_corpus.captions
+    history = []
+    for epoch in range(cfg.n_epochs):
+        losses = []
+        for it, idx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
+            if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
+                break
+            t0 = time.time()
+            vid, sentence = caps[idx, 0], caps[idx, 1].tolist()
+            captions_ind, captions_mask = hostglue.sentence_padding_toix(sentence, wordtoix, cfg.n_caption_lstm_step)
+            st = model.xe_update(train_corpus.features.batch(vid), np.asarray(captions_ind, np.int32), captions_mask,
+                                 lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm)
+            losses.append(float(st.loss))
+            log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
+                f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")
+        entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None}
+        if test_corpus is not None:
+            _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, scorer, cfg.batch_size)
+        entry["checkpoint"] = save_checkpoint(model, cfg, epoch)
+        history.append(entry)
+        log(f"Epoch {epoch} is done: {entry}")
+    return model, history
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train-sents", required=True); ap.add_argument("--train-feats", required=True)
+    ap.add_argument("--test-sents"); ap.add_argument("--test-feats")
+    ap.add_argument("--vocab", required=True)
+    ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--model-path", default="./new_s2vt_models")
+    a = ap.parse_args()
+    cfg = Config(n_epochs=a.epochs, batch_size=a.batch_size, model_path=a.model_path, model_name=f"batch_size{a.batch_size}_s2vt_model")
+    tr = Corpus(a.train_sents, a.train_feats, vocabulary_file=a.vocab)
+    te = Corpus(a.test_sents, a.test_feats, vocabulary=tr.vocabulary) if a.test_sents and a.test_feats else None
+    train(cfg, tr, te)
+
+
+if __name__ == "__main__":
+    main()

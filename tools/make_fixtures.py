@@ -101,3 +101,28 @@ def main():
 
 if __name__ == "__main__":
     sys.exit(main())
+
+
+def msvd_slice(out_path):
+    """tests/golden/msvd_slice.json: a slice of the reference's own DATA files -- the captions of the first 40
+    training videos (msvd_sents_train_noval_lc_nopunc.txt) and the part of msvd_vocabulary1.txt they use (with
+    ~5% of those words dropped so that the slice has out-of-vocabulary reference words)."""
+    refs, order = {}, []
+    for line in open(os.path.join(REF, "msvd_sents_train_noval_lc_nopunc.txt")):
+        vid, sent = line.rstrip("\n").split("\t")
+        if vid not in refs:
+            if len(order) == 40:
+                continue
+            refs[vid] = []
+            order.append(vid)
+        refs[vid].append(sent)
+    vocab_all = [l.rstrip() for l in open(os.path.join(REF, "msvd_vocabulary1.txt"))]
+    used = set(w for v in order for s in refs[v] for w in s.split())
+    vocab = [w for i, w in enumerate(vocab_all) if w in used or i < 300]
+    vocab = [w for i, w in enumerate(vocab) if not (i % 19 == 7 and w != "<en_unk>")]
+    json.dump({"source": "msvd_sents_train_noval_lc_nopunc.txt (first 40 videos) + msvd_vocabulary1.txt (subset), made by tools/make_fixtures.py",
+               "vocab": vocab, "refs_by_video": [refs[v] for v in order]}, open(out_path, "w"))
+
+
+if __name__ == "__main__" and os.path.isdir(REF):
+    msvd_slice(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "msvd_slice.json"))
