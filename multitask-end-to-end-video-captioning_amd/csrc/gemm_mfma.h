@@ -95,6 +95,9 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+// 16 zero bytes in device memory: an out-of-range lane of a ring load reads THESE instead of a clamped
+// in-range address, so its chunk element arrives as zeros and needs no select when it lands in LDS
+static __device__ const float s2vt_zero16[4] __attribute__((aligned(16), used)) = {0.f, 0.f, 0.f, 0.f};
 // a wave-uniform value as an opaque SGPR value (v_readfirstlane): the optimizer cannot look through it
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ const float* uniform(const float* p)
@@ -271,9 +274,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     row_offsets(slen1, g.seg[1].rowmod, g.seg[1].rowidx, g.seg[1].rowkey, g.seg[1].ld, aoff1);
     row_offsets(slen2, g.seg[2].rowmod, g.seg[2].rowidx, g.seg[2].rowkey, g.seg[2].ld, aoff2);
 
-    // Issue the global loads of chunk c into a ring slot.  UNCONDITIONAL and always safe: addresses are
-    // clamped into the segment; the validity bits zero the out-of-range elements when the chunk lands.
-    // A chunk index beyond the walk yields an all-zero chunk.
+    // Issue the global loads of chunk c into a ring slot.  UNCONDITIONAL and always safe: an out-of-range
+    // element (row >= M, k beyond the segment, column >= N, chunk beyond the walk) is loaded from
+    // s2vt_zero16 instead, so it lands as zeros.
     // (The chunk -> segment selection is done by the S2VT_ISSUE macro at KERNEL scope, on plain local values:
     // inside a lambda the same "sidx == 0 ? a : b" picks between by-reference captures, which hipcc folds
     // into a load through a run-time offset into the closure object -- the closure, every local it points
@@ -291,8 +294,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             const int ro = aro[i];
             if constexpr (VEC) {
                 const bool ok = ro >= 0 && k < sk;
-                gload16(qa[i], abase + (ok ? ro + k : 0));
-                va |= (ok ? 1u : 0u) << i;
+                gload16(qa[i], ok ? abase + (ro + k) : s2vt_zero16);
             } else {   // odd shapes (tests): ordinary compiler-scheduled loads, zero-filled right here
                 f32x4 v;
 #pragma unroll
@@ -315,8 +317,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             const float* wrow = g.W + (size_t)(kw + (kok ? k : 0)) * g.ldw + grp * g.gstride;
             if constexpr (VEC) {
                 const bool ok = kok && cc < g.N;
-                gload16(qb[i], wrow + (ok ? cc : 0));
-                vb |= (ok ? 1u : 0u) << i;
+                gload16(qb[i], ok ? wrow + cc : s2vt_zero16);
             } else {
                 f32x4 v;
 #pragma unroll
@@ -358,8 +359,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         for (int i = 0; i < A4; ++i) {
             if constexpr (VEC) pin(qa[i]);
             f32x4 v = qa[i];
-            if constexpr (VEC)
-                if (!((ma >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
             const int idx = tid + i * NT;
             if (A4 * NT == BM * (BK / 4) || idx < BM * (BK / 4)) {
                 float* d = a + (idx / (BK / 4)) * SA + (idx % (BK / 4)) * 4;
@@ -371,8 +370,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         for (int i = 0; i < B4; ++i) {
             if constexpr (VEC) pin(qb[i]);
             f32x4 v = qb[i];
-            if constexpr (VEC)
-                if (!((mb >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
             const int idx = tid + i * NT;
             if (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4)) {
                 float* d = b + (idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4;
