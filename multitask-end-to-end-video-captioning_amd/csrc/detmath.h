@@ -124,6 +124,24 @@ __device__ __forceinline__ float gumbel_at(uint32_t seed_lo, uint32_t seed_hi, u
     return -dm_logf(-dm_logf(u));
 }
 
+// Gumbel words of FOUR consecutive columns 4q .. 4q+3 come from ONE Philox block, and in the MFMA accumulator
+// layout those columns sit in four adjacent lanes (a quad) that also share their four rows.  So per (row
+// group, column tile) quad lane e computes the block of row e only, and the 4x4 (row x column) words are
+// exchanged inside the quad with DPP broadcasts: a quarter of the Philox work of calling gumbel_at per
+// element, same words bit for bit.
+template <int C>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, C * 0x55, 0xF, 0xF, true);    // quad_perm: every lane <- lane C
+}
+template <int R>
+__device__ __forceinline__ uint32_t quad_word_from(const u32x4& mine, uint32_t e)
+{
+    const uint32_t x = quad_bcast<R>(mine.x), y = quad_bcast<R>(mine.y), z = quad_bcast<R>(mine.z), w = quad_bcast<R>(mine.w);
+    return e == 0 ? x : e == 1 ? y : e == 2 ? z : w;
+}
+__device__ __forceinline__ float gumbel_from_word(uint32_t word) { return -dm_logf(-dm_logf(u01(word))); }
+
 // DropoutWrapper keep decision (reference tf_s2vt.py:75,77: floor(keep + U[0,1)) ) from the dropout
 // stream: key (seed_lo, seed_hi ^ 'DROP'), counter (unit>>2, video, sample, code), code =
 // layer*256 + unrolled step index.

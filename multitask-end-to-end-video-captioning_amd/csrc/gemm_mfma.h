@@ -676,40 +676,66 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             }
         }
     } else {  // EPI_PICK
+        // Column tiles start at multiples of 16, so the quad l15 = 4q .. 4q+3 holds columns 4Q .. 4Q+3 of the
+        // SAME four rows (lq*4 + r): quad lane e draws the Philox block of row r = e, the words are exchanged
+        // with DPP (detmath.h).  All 64 lanes take part in every exchange (no divergence around it).
+        const uint32_t e4 = (uint32_t)l15 & 3u;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int mrow = m0 + (wm * TM + i) * 16 + lq * 4;
+            int sid[4], vid[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + (wm * TM + i) * 16 + lq * 4 + r;
-                const bool mok = m < g.M;
-                int sid = -1, vid = 0;
-                if (mok) { sid = g.sample_id[m]; vid = g.video_id[m]; }
-                float best = 0.0f;
-                uint32_t bidx = 0xFFFFFFFFu;
-                bool have = false;
+                const bool mok = mrow + r < g.M;
+                sid[r] = mok ? g.sample_id[mrow + r] : -1;
+                vid[r] = mok ? g.video_id[mrow + r] : 0;
+            }
+            const int sid_own = e4 == 0 ? sid[0] : e4 == 1 ? sid[1] : e4 == 2 ? sid[2] : sid[3];
+            const int vid_own = e4 == 0 ? vid[0] : e4 == 1 ? vid[1] : e4 == 2 ? vid[2] : vid[3];
+            float best[4];
+            uint32_t bidx[4];
+            bool have[4];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + (wn * TN + j) * 16 + l15;
-                    if (mok && col < g.N) {
+            for (int r = 0; r < 4; ++r) { best[r] = 0.0f; bidx[r] = 0xFFFFFFFFu; have[r] = false; }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 16 + l15;
+                u32x4 blk = {0u, 0u, 0u, 0u};
+                if (sid_own >= 0)
+                    blk = philox4x32_10((uint32_t)col >> 2, (uint32_t)vid_own, (uint32_t)sid_own, (uint32_t)g.step, g.seed_lo,
+                                        g.seed_hi);
+                uint32_t word[4];
+                word[0] = quad_word_from<0>(blk, e4);
+                word[1] = quad_word_from<1>(blk, e4);
+                word[2] = quad_word_from<2>(blk, e4);
+                word[3] = quad_word_from<3>(blk, e4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow + r;
+                    if (m < g.M && col < g.N) {
                         float v = acc[i][j][r] + g.bias[col];
                         if (g.logits_out) g.logits_out[(size_t)m * g.ldc + col] = v;
-                        if (sid >= 0)
-                            v = v + gumbel_at(g.seed_lo, g.seed_hi, (uint32_t)vid, (uint32_t)sid, (uint32_t)g.step,
-                                              (uint32_t)col);
+                        if (sid[r] >= 0) v = v + gumbel_from_word(word[r]);
                         v = v + 0.0f;  // -0 -> +0 so that the integer order equals the float order
-                        if (!have || v > best) { best = v; bidx = (uint32_t)col; have = true; }
+                        if (!have[r] || v > best[r]) { best[r] = v; bidx[r] = (uint32_t)col; have[r] = true; }
                     }
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mrow + r;
                 // reduce over the 16 lanes that hold this row's columns (ties -> lowest index)
-                unsigned long long key = have ? (((unsigned long long)orderable(best) << 32) | (uint32_t)(~bidx)) : 0ull;
+                unsigned long long key = have[r] ? (((unsigned long long)orderable(best[r]) << 32) | (uint32_t)(~bidx[r])) : 0ull;
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) {
                     const unsigned long long o = __shfl_xor(key, off, 64);
                     key = o > key ? o : key;
                 }
-                if (l15 == 0 && mok && key != 0ull) atomicMax(&g.pick[m], key);
+                if (l15 == 0 && m < g.M && key != 0ull) atomicMax(&g.pick[m], key);
             }
+        }
     }
+
 }
 
 }  // namespace s2vt
