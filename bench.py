@@ -117,7 +117,8 @@ def main():
         s, _greedy = mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
         is_eos = (s == 0)
         mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()   # 1 up to and incl. first <eos>
-        return mdl.reinforce_update(video, s, mask, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B)
+        return mdl.reinforce_update(video, s, mask, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,
+                                    reuse_sampler_state=True)    # LSTM1 trajectory of the sampler pass (same videos, same weights)
 
     for i in range(args.warmup):
         step(i)

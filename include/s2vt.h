@@ -165,6 +165,16 @@ int s2vt_teacher_forced_fwd(const s2vt_dims* d, const s2vt_params* p, const floa
                             const int32_t* sample_id, float* logits_out, void* workspace, size_t workspace_bytes,
                             s2vt_stream stream);
 
+/* Same, inside a REINFORCE step: LSTM1's state trajectory depends only on the frames and the weights, and the
+ * sampler pass of the step (s2vt_sample / s2vt_encode_fwd on the SAME video block, SAME weights) has just
+ * computed it.  Pass that call's workspace (and its row count R = (K + with_greedy) * B) and the trajectory and
+ * gates are copied from it instead of being recomputed.  sampler_workspace == NULL: identical to the above. */
+int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
+                                  const int32_t* caption, float keep, uint64_t seed, const int32_t* video_id,
+                                  const int32_t* sample_id, float* logits_out, void* workspace, size_t workspace_bytes,
+                                  const void* sampler_workspace, size_t sampler_workspace_bytes, int32_t sampler_rows,
+                                  s2vt_stream stream);
+
 /* ---- softmax / NLL rows, forward + backward ----------------------------------------------------
  * nll[r] = -sum_v q[v] * log_softmax(logits[r])[v],  q = onehot(target[r])*(1-s) + s/V
  * (tf.losses.softmax_cross_entropy(label_smoothing=s), tf_s2vt.py:155; s = 0 gives the

@@ -194,6 +194,7 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
     t.emb = c.take<float>((size_t)B * Tv * E);
     t.Xp1 = c.take<float>((size_t)B * Tv * 4 * H);
     t.c1 = c.take<float>((T + 1) * B * H); t.h1 = c.take<float>((T + 1) * B * H);     // LSTM1 state history, slot 0 = zeros
+    t.G1 = c.take<float>(T * B * 4 * H);                                                // LSTM1 activated gates (reused by the update pass)
     t.P2 = c.take<float>(T * B * 4 * H);                                                // h1[t+1] @ W2[0:H] for every step
     for (int i = 0; i < 2; ++i) { t.c2e[i] = c.take<float>((size_t)B * H); t.h2e[i] = c.take<float>((size_t)B * H); }
     for (int i = 0; i < 2; ++i) { t.c2[i] = c.take<float>((size_t)R * H); t.h2[i] = c.take<float>((size_t)R * H); }
@@ -233,7 +234,8 @@ int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, 
     for (int t = 0; t < T; ++t) {
         ASeg s1 = make_seg(w.h1 + t * BH, H, H, E);
         HIP_TRY(lstm_call(&s1, 1, p->lstm1_W, p->lstm1_b, w.c1 + t * BH, 0, w.c1 + (t + 1) * BH, w.h1 + (t + 1) * BH, nullptr,
-                          nullptr, B, H, 1.0f, none, 0, -1, st, t < Tv ? w.Xp1 + (size_t)t * 4 * H : nullptr, Tv * 4 * H, 0));
+                          w.G1 + (size_t)t * 4 * BH, B, H, 1.0f, none, 0, -1, st, t < Tv ? w.Xp1 + (size_t)t * 4 * H : nullptr,
+                          Tv * 4 * H, 0));
     }
     // ---- the out1 rows of W2 for every step at once (M = T*B)
     {

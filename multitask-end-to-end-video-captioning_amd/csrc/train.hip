@@ -109,6 +109,16 @@ int s2vt_teacher_forced_fwd(const s2vt_dims* d, const s2vt_params* p, const floa
                             const int32_t* sample_id, float* logits, void* workspace, size_t workspace_bytes,
                             s2vt_stream stream)
 {
+    return s2vt_teacher_forced_fwd_reuse(d, p, video, B, N, caption, keep, seed, video_id, sample_id, logits, workspace,
+                                         workspace_bytes, nullptr, 0, 0, stream);
+}
+
+int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
+                                  const int32_t* caption, float keep, uint64_t seed, const int32_t* video_id,
+                                  const int32_t* sample_id, float* logits, void* workspace, size_t workspace_bytes,
+                                  const void* sampler_workspace, size_t sampler_workspace_bytes, int32_t sampler_rows,
+                                  s2vt_stream stream)
+{
     if (!dims_ok(d) || !params_ok(p) || !video || !caption || !logits || !workspace || B <= 0 || N <= 0 || N % B)
         return S2VT_E_BADARG;
     if (!(keep > 0.0f) || (keep < 1.0f && (!video_id || !sample_id))) return S2VT_E_BADARG;
@@ -140,16 +150,28 @@ int s2vt_teacher_forced_fwd(const s2vt_dims* d, const s2vt_params* p, const floa
     // batched launch; the per-step launch then continues each chain from that partial with the
     // recurrent rows.
     // ---- LSTM1: input rows of W1 for the Tv frames (row j*Tv + t of emb), then the recurrence on B rows
-    {
-        ASeg sx = make_seg(w.emb, E, E, 0);
-        HIP_TRY(store_call(&sx, 1, p->lstm1_W, 4 * H, nullptr, w.Xp1, 4 * H, B * Tv, 4 * H, 0, -1, st));
-    }
-    for (int t = 0; t < T; ++t) {
-        // tf_s2vt.py:119 (encode) / :140 (decode, zero padding input: only the recurrent rows remain)
-        ASeg s1 = make_seg(w.H1 + t * BH, H, H, E);
-        HIP_TRY(lstm_call(&s1, 1, p->lstm1_W, p->lstm1_b, w.C1 + t * BH, 0, w.C1 + (t + 1) * BH, w.H1 + (t + 1) * BH, nullptr,
-                          w.G1 + (size_t)t * 4 * BH, B, H, 1.0f, none, 0, -1, st, t < Tv ? w.Xp1 + (size_t)t * 4 * H : nullptr,
-                          Tv * 4 * H, 0));
+    if (sampler_workspace) {
+        // The sampler pass of this step already ran LSTM1 on these videos with these weights (its state never
+        // sees a word or a dropout mask): take its state history and activated gates instead of recomputing.
+        Carver sc(const_cast<void*>(sampler_workspace), sampler_workspace_bytes);
+        SampleWs sw;
+        carve_sample(sc, d, B, sampler_rows, &sw);
+        if (!sc.ok() || sampler_rows <= 0) return S2VT_E_WORKSPACE;
+        HIP_TRY(hipMemcpyAsync(w.C1, sw.c1, (size_t)(T + 1) * BH * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(w.H1, sw.h1, (size_t)(T + 1) * BH * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(w.G1, sw.G1, (size_t)T * 4 * BH * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+        {
+            ASeg sx = make_seg(w.emb, E, E, 0);
+            HIP_TRY(store_call(&sx, 1, p->lstm1_W, 4 * H, nullptr, w.Xp1, 4 * H, B * Tv, 4 * H, 0, -1, st));
+        }
+        for (int t = 0; t < T; ++t) {
+            // tf_s2vt.py:119 (encode) / :140 (decode, zero padding input: only the recurrent rows remain)
+            ASeg s1 = make_seg(w.H1 + t * BH, H, H, E);
+            HIP_TRY(lstm_call(&s1, 1, p->lstm1_W, p->lstm1_b, w.C1 + t * BH, 0, w.C1 + (t + 1) * BH, w.H1 + (t + 1) * BH,
+                              nullptr, w.G1 + (size_t)t * 4 * BH, B, H, 1.0f, none, 0, -1, st,
+                              t < Tv ? w.Xp1 + (size_t)t * 4 * H : nullptr, Tv * 4 * H, 0));
+        }
     }
     // DropoutWrapper(LSTM1) output for the N sample rows (tf_s2vt.py:75; code = 256 + t)
     HIP_TRY(launch_expand_dropout(w.H1 + BH, w.O1, T, B, N, H, keep, seed, 256u, video_id, sample_id, st));

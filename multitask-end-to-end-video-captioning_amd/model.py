@@ -239,14 +239,21 @@ class Video_Caption_Generator:
         return video, sentence, []
 
     # -------------------------------------------------------------------------------- training graphs
-    def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep):
+    def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep, reuse_sampler_state=False):
         """Teacher-forced forward + softmax-NLL fwd/bwd.  caption [N,Tc] int32 device, coef_tm
         time-major [Tc*N].  Leaves dlogits + activations ready for backward()."""
         B = video.shape[0]
         N = caption.shape[0]
         vid, sid = self._row_ids(B, rep, video_base)
         seed = self.dropout_seed + 104729 * self.global_step
-        logits, ws = ops.teacher_forced_fwd(self.dims, self.store.params, video, caption, N, keep, seed, vid, sid)
+        state = None
+        if reuse_sampler_state:
+            ls = ops.sample.last_state
+            assert ls is not None and ls[2] == video.data_ptr() and ls[3] == B, \
+                "reuse_sampler_state needs a sample() call on this very video tensor right before the update"
+            state = (ls[0], ls[1])
+        logits, ws = ops.teacher_forced_fwd(self.dims, self.store.params, video, caption, N, keep, seed, vid, sid,
+                                            sampler_state=state)
         target = caption.t().contiguous().view(-1)
         nll, lp = ops.softmax_nll_fwd_bwd(logits, target, coef_tm, smoothing)
         self._ctx = (video, N, logits, ws, keep, seed, vid, sid)
@@ -277,11 +284,13 @@ class Video_Caption_Generator:
         ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, self._sumsq, clip_norm, lr, self.global_step)
 
     def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
-                         true_labels=None):
+                         true_labels=None, reuse_sampler_state=False):
         """build_loss + the REINFORCE objective and train_op of train()
         (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc],
         rewards / baseline [N], rows sample-major over the B videos.
-        With true_labels [B, label_dim] the multitask objective of
+        reuse_sampler_state: the sample() call that produced `sampled` ran just before on this same video tensor
+        with the current weights -- its LSTM1 trajectory is reused (the reference recomputes the whole unroll in
+        build_loss).  With true_labels [B, label_dim] the multitask objective of
         reinforce_multitask_e2e_attribute_loss.py:957 is used instead:
             -(1-alpha) * PG / sum(mask) + alpha * sum(bce) / (label_dim * B)."""
         video = self._dev(video, torch.float32)
@@ -293,7 +302,7 @@ class Video_Caption_Generator:
         pg_w = (1.0 - self.alpha) if multitask else 1.0
         coef = (mask * (adv * pg_w)[:, None]).t().contiguous().view(-1)
         keep = self.dropout_rate if keep is None else keep
-        nll, _ = self._forward_loss(video, cap, coef, 0.0, rep, video_base, keep)
+        nll, _ = self._forward_loss(video, cap, coef, 0.0, rep, video_base, keep, reuse_sampler_state)
         msum = mask.sum()
         loss_local = torch.dot(coef, nll)
         self.backward()

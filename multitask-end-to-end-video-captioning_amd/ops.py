@@ -145,7 +145,11 @@ def sample(dims: Dims, params: Params, video, K: int, seed: int, video_base: int
     ids = torch.empty(((K + g) * B, dims.n_caption_lstm_step), dtype=torch.int32, device=video.device)
     check(L.s2vt_sample(C.byref(dims), C.byref(params), _ptr(video), B, K, g, seed, video_base, _ptr(ids), _ptr(ws),
                         ws.numel(), _stream()), "s2vt_sample")
+    sample.last_state = (ws, (K + g) * B, video.data_ptr(), B)        # for teacher_forced_fwd(sampler_state=...)
     return ids[:K * B], (ids[K * B:] if with_greedy else None)
+
+
+sample.last_state = None
 
 
 def train_workspace(dims: Dims, B: int, N: int, device):
@@ -155,8 +159,10 @@ def train_workspace(dims: Dims, B: int, N: int, device):
 
 
 def teacher_forced_fwd(dims: Dims, params: Params, video, caption, N: int, keep=1.0, seed=0, video_id=None,
-                       sample_id=None, ws=None, logits=None):
-    """Teacher-forced unroll on N = rep*B sample-major rows.  Returns time-major logits [Tc*N, V]."""
+                       sample_id=None, ws=None, logits=None, sampler_state=None):
+    """Teacher-forced unroll on N = rep*B sample-major rows.  Returns time-major logits [Tc*N, V].
+    sampler_state = (workspace tensor, rows) of the sample() call of the same step on the same video block:
+    LSTM1's trajectory is taken from it instead of being recomputed."""
     _chk_f32(video)
     assert caption.is_cuda and caption.dtype == torch.int32 and caption.is_contiguous() and caption.shape[0] == N
     B = video.shape[0]
@@ -164,8 +170,10 @@ def teacher_forced_fwd(dims: Dims, params: Params, video, caption, N: int, keep=
         ws = train_workspace(dims, B, N, video.device)
     if logits is None:
         logits = torch.empty((dims.n_caption_lstm_step * N, dims.n_words), dtype=torch.float32, device=video.device)
-    check(lib().s2vt_teacher_forced_fwd(C.byref(dims), C.byref(params), _ptr(video), B, N, _ptr(caption), float(keep), seed,
-                                        _ptr(video_id), _ptr(sample_id), _ptr(logits), _ptr(ws), ws.numel(), _stream()),
+    sws, srows = sampler_state if sampler_state is not None else (None, 0)
+    check(lib().s2vt_teacher_forced_fwd_reuse(C.byref(dims), C.byref(params), _ptr(video), B, N, _ptr(caption), float(keep), seed,
+                                              _ptr(video_id), _ptr(sample_id), _ptr(logits), _ptr(ws), ws.numel(), _ptr(sws),
+                                              0 if sws is None else sws.numel(), srows, _stream()),
           "s2vt_teacher_forced_fwd")
     return logits, ws
 

@@ -56,7 +56,7 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
                 break
             t0 = time.time()
             vid = caps[idx, 0]
-            video = train_corpus.features.batch(vid)
+            video = model._dev(train_corpus.features.batch(vid), torch.float32)      # one H2D copy, shared by sample + update
             samples, greedy_words = model.sample(video, K, True, seed=cfg.seed + 7919 * (model.global_step + 1))
             is_eos = samples == 0
             mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()        # 1 up to and incl. the first <eos>
@@ -64,7 +64,7 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
             r = scorer.score_ids(samples.cpu().numpy(), np.tile(rows, K))               # [K*B], sample-major like the ids
             b = scorer.score_ids(greedy_words.cpu().numpy(), rows)                      # [B]
             st = model.reinforce_update(video, samples, mask, r, hostglue.tile_baseline(b, K),
-                                        lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm)
+                                        lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm, reuse_sampler_state=True)
             losses.append(float(st.loss)); adv.append(float(r.mean() - b.mean()))
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} loss: {losses[-1]:.5f} "
                 f"r: {r.mean():.4f} b: {b.mean():.4f} Elapsed time: {time.time() - t0:.3f}")

@@ -145,3 +145,27 @@ def test_clip_and_adam_tf_three_steps(gpu, oracle):
         gpu.adam_tf(th, gd, m, v, sumsq, 5.0, 1e-3, step)
         assert np.allclose(th.cpu().numpy(), pt["w"].numpy(), rtol=2e-5, atol=2e-6)
     assert np.allclose(m.cpu().numpy(), mt["w"].numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_sampler_state_reuse_is_equivalent(gpu, oracle):
+    """reinforce_update(reuse_sampler_state=True) takes LSTM1's trajectory from the sampler pass of the step: the
+    loss is bit-identical to recomputing it, the finalized gradients agree to the run-to-run noise of the
+    order-free (atomic) gradient reductions."""
+    import torch
+    from s2vt_amd import hostglue, model as M
+    d = oracle.Dims(label_dim=0, **CASES[1]["dims"])
+    rng = np.random.default_rng(11)
+    B, K = 4, 3
+    video = torch.as_tensor(np.abs(rng.standard_normal((B, d.n_video_lstm_step, d.dim_image)) * 0.5).astype(np.float32)).cuda()
+    r = rng.random(K * B).astype(np.float32) * 2; b = np.tile(rng.random(B).astype(np.float32) * 2, K)
+    outs = []
+    for reuse in (False, True):
+        mdl = M.Video_Caption_Generator(d.dim_image, d.n_words, d.word_dim, d.lstm_dim, B, 0, d.n_video_lstm_step,
+                                        d.n_caption_lstm_step, dropout_rate=0.9, seed=5)
+        s, _ = mdl.sample(video, K, True, seed=77)
+        mask = torch.as_tensor(hostglue.masks_from_ids(s.cpu().numpy())).cuda()
+        st = mdl.reinforce_update(video, s, mask, r, b, lr=0.0, reuse_sampler_state=reuse)
+        outs.append((float(st.loss), mdl.store.grad[:mdl.store.numel].clone()))
+    assert outs[0][0] == outs[1][0]
+    scale = float(outs[0][1].abs().max())
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-5 * scale

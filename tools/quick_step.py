@@ -16,7 +16,7 @@ def step(i):
     s, gr = mdl.sample(video, K, True, seed=1000 + i)
     is_eos = (s == 0)
     mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()
-    return mdl.reinforce_update(video, s, mask, r, b, lr=1e-6)
+    return mdl.reinforce_update(video, s, mask, r, b, lr=1e-6, reuse_sampler_state=True)
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
