@@ -194,6 +194,13 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
                   int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                   const int32_t* sample_id, void* workspace, size_t workspace_bytes, s2vt_stream stream);
 
+/* The same in two parts for data-parallel callers: phase 1 = the vocab projection only (dW/db of embed_word and the
+ * gradient w.r.t. LSTM2's outputs) -- after it the embed_word gradients are final, so their all-reduce can run
+ * under phase 2 (everything else).  phase 0 = s2vt_bptt_bwd. */
+int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
+                        int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
+                        const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase, s2vt_stream stream);
+
 /* dWemb[idx[r], :] += dE[r, :]  -- gradient of tf.nn.embedding_lookup (tf_s2vt.py:128-134). */
 int s2vt_embed_scatter_add(const float* dE, int32_t ld, const int32_t* idx, int32_t R, int32_t E, float* dWemb,
                            s2vt_stream stream);

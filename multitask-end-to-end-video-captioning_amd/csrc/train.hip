@@ -207,6 +207,15 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
                   int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                   const int32_t* sample_id, void* workspace, size_t workspace_bytes, s2vt_stream stream)
 {
+    return s2vt_bptt_bwd_phase(d, p, grads, video, B, N, dlogits, keep, seed, video_id, sample_id, workspace, workspace_bytes, 0,
+                               stream);
+}
+
+int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
+                        int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
+                        const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase, s2vt_stream stream)
+{
+    if (phase < 0 || phase > 2) return S2VT_E_BADARG;
     if (!dims_ok(d) || !params_ok(p) || !params_ok(grads) || !video || !dlogits || !workspace || B <= 0 || N <= 0 || N % B)
         return S2VT_E_BADARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
@@ -221,18 +230,19 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
     const size_t NH = (size_t)N * H;
     const int K2 = 2 * H + E, K1 = E + H;
 
-    // transposed weight copies for the data-gradient products
-    HIP_TRY(launch_transpose(p->embed_word_W, V, w.WoutT, H, H, V, st));
-    HIP_TRY(launch_transpose(p->lstm2_W, 4 * H, w.W2T, K2, K2, 4 * H, st));
-    HIP_TRY(launch_transpose(p->lstm1_W, 4 * H, w.W1T, K1, K1, 4 * H, st));
-
-    // ---- vocab projection
-    {
+    // phase 1 = the vocab projection (its gradients are final after it: a data-parallel caller starts their
+    // all-reduce while phase 2, everything else, still runs); phase 0 = both
+    if (phase != 2) {
+        // transposed weight copy for the data-gradient product + the vocab projection
+        HIP_TRY(launch_transpose(p->embed_word_W, V, w.WoutT, H, H, V, st));
         TnArgs a{w.O2 + (size_t)Tv * NH, nullptr, H, dlogits, V, grads->embed_word_W, V, Tc * N, H, V, 1};
         HIP_TRY(launch_gemm_tn(a, st));
         HIP_TRY(launch_colsum(dlogits, V, Tc * N, V, grads->embed_word_b, st));
         HIP_TRY(nn_bwd(dlogits, V, w.WoutT, H, w.dO2, H, Tc * N, H, V, 1, 0, st));
     }
+    if (phase == 1) return S2VT_OK;
+    HIP_TRY(launch_transpose(p->lstm2_W, 4 * H, w.W2T, K2, K2, 4 * H, st));
+    HIP_TRY(launch_transpose(p->lstm1_W, 4 * H, w.W1T, K1, K1, 4 * H, st));
     // ---- LSTM2 back through time
     const SlabPlan sp2 = slab_plan(N, H), sp1 = slab_plan(B, H);
     for (int t = T - 1; t >= 0; --t) {

@@ -46,3 +46,19 @@ def allreduce_small(t: torch.Tensor, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         _all_reduce_sum(t, group)
     return t
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_async(t: torch.Tensor, group=None):
+    """Start a SUM all-reduce of `t` (a contiguous slice of the gradient bucket) and return a handle whose
+    .wait() orders the CURRENT stream after it -- under "nccl" (RCCL) the collective runs on the communicator's
+    own stream, beside the kernels launched meanwhile; under "gloo" it is done synchronously (host staging)."""
+    if world_size(group) <= 1:
+        return None
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        _all_reduce_sum(t, group)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)

@@ -260,9 +260,23 @@ class Video_Caption_Generator:
         return nll, lp
 
     def backward(self):
+        """BPTT into the flat gradient bucket.  Data parallel: the vocab-projection gradients (a third of the
+        bucket) are final after phase 1, so their all-reduce is started there and runs over xGMI beside phase 2;
+        apply_gradients() reduces the rest and waits for both."""
         video, N, dlogits, ws, keep, seed, vid, sid = self._ctx
-        self.store.grad.zero_()
-        ops.bptt_bwd(self.dims, self.store.params, self.store.grads, video, N, dlogits, ws, keep, seed, vid, sid)
+        st = self.store
+        st.grad.zero_()
+        self._pending = []
+        self._early = None
+        if dp.world_size() > 1:
+            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, phase=1)
+            lo = st.offsets["embed_word_W"]
+            hi = st.offsets["embed_word_b"] + (int(np.prod(st.shapes["embed_word_b"])) + 63) // 64 * 64
+            self._early = (lo, hi)
+            self._pending.append(dp.allreduce_async(st.grad[lo:hi]))
+            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, phase=2)
+        else:
+            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid)
 
     def apply_gradients(self, mask_sum, lr, clip_norm, weight_decay=0.0, attr_scale=None):
         """All-reduce (RCCL, one flat bucket + sum(mask) in its tail), 1/sum(mask), weight decay,
@@ -270,7 +284,20 @@ class Video_Caption_Generator:
         attr_scale: constant normaliser of the attribute-head gradients (their range of the bucket is
         touched by the multilabel loss only, so it is finalised with its own scale)."""
         st = self.store
-        gsum = dp.allreduce_bucket(st.grad, st.numel, mask_sum)
+        early = getattr(self, "_early", None)
+        if early is not None and dp.world_size() > 1:
+            lo, hi = early
+            st.grad[st.numel] = mask_sum
+            pend = getattr(self, "_pending", [])
+            pend.append(dp.allreduce_async(st.grad[:lo]))
+            pend.append(dp.allreduce_async(st.grad[hi:]))            # includes the tail slot carrying sum(mask)
+            for w in pend:
+                if w is not None:
+                    w.wait()
+            self._pending, self._early = [], None
+            gsum = st.grad[st.numel:st.numel + 1]
+        else:
+            gsum = dp.allreduce_bucket(st.grad, st.numel, mask_sum)
         torch.reciprocal(gsum, out=self._gscale)
         self._sumsq.zero_()
         nd = st.n_decayed

@@ -191,10 +191,11 @@ def softmax_nll_fwd_bwd(logits, target, coef, smoothing=0.0):
 
 
 def bptt_bwd(dims: Dims, params: Params, grads: Params, video, N: int, dlogits, ws, keep=1.0, seed=0, video_id=None,
-             sample_id=None):
+             sample_id=None, phase=0):
+    """phase 0 = the whole backward; 1 = vocab projection only; 2 = the rest (data-parallel overlap)."""
     _chk_f32(video, dlogits)
-    check(lib().s2vt_bptt_bwd(C.byref(dims), C.byref(params), C.byref(grads), _ptr(video), video.shape[0], N, _ptr(dlogits),
-                              float(keep), seed, _ptr(video_id), _ptr(sample_id), _ptr(ws), ws.numel(), _stream()),
+    check(lib().s2vt_bptt_bwd_phase(C.byref(dims), C.byref(params), C.byref(grads), _ptr(video), video.shape[0], N, _ptr(dlogits),
+                                    float(keep), seed, _ptr(video_id), _ptr(sample_id), _ptr(ws), ws.numel(), phase, _stream()),
           "s2vt_bptt_bwd")
 
 
