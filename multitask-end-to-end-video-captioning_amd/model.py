@@ -232,6 +232,12 @@ class Video_Caption_Generator:
         video = Placeholder("video", (1, self.n_video_lstm_step, self.dim_image), np.float32)
 
         def fn(v):
+            if beam_size > 1:                    # final_beam_search.py:226-294 (B = 1, TopN beams)
+                from .beam_search import BeamSearchGenerator
+                sent, _, _ = BeamSearchGenerator(self, beam_size, length_normalization_factor).generate(v)
+                ids = np.zeros(self.n_caption_lstm_step, np.int64)
+                ids[:len(sent)] = sent[:self.n_caption_lstm_step]
+                return {f"word_{t}": ids[t] for t in range(self.n_caption_lstm_step)}
             _, g = self.sample(v, 0, True)
             ids = g.cpu().numpy().astype(np.int64)[0]
             return {f"word_{t}": ids[t] for t in range(self.n_caption_lstm_step)}
