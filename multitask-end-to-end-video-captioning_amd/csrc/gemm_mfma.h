@@ -189,9 +189,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         // Many-tile shapes: XCD b % 8 takes a contiguous band of the tile sequence (column tiles fastest), so the
         // workgroups that share an A row block run on ONE XCD and it is fetched into one L2 instead of eight
         // (bijective for any tile count).
-        const int nwg = ntile_m * ntile_n, q = nwg >> 3, r = nwg & 7;
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        // (only for wide outputs, >= 16 column tiles: with few column tiles the plain order already gives every
+        // XCD its own one or two weight panels, and banding would re-stream the whole weight matrix per row block
+        // -- measured 1.0 GB -> 1.9 GB of fabric reads on the 8000x4000x1500 data-gradient product)
+        int t = blockIdx.x;
+        if (ntile_n >= 16) {
+            const int nwg = ntile_m * ntile_n, q = nwg >> 3, r = nwg & 7;
+            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+            t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        }
         tile_n = t % ntile_n;
         tile_m = t / ntile_n;
     }
