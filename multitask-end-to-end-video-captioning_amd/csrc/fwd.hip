@@ -56,7 +56,10 @@ const CfgEntry kPick[] = {
     make_entry<2, 2, 2, 4, 1, EPI_PICK>("64x128(2x2)"),
     make_entry<2, 4, 3, 3, 1, EPI_PICK>("96x192(2x4)"),
     make_entry<2, 4, 3, 3, 1, EPI_PICK, 3>("96x192(2x4)p3"),
+    make_entry<2, 2, 2, 3, 1, EPI_PICK>("64x96(2x2)"),
+    make_entry<2, 2, 3, 2, 1, EPI_PICK>("96x64(2x2)"),
 };
+constexpr int kPick64x96 = 5;
 
 const CfgEntry* table(int epi, int* n)
 {
@@ -208,7 +211,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     std::call_once(g_attr_once, set_lds_attrs);
     int n;
     const CfgEntry* t = table(epi, &n);
-    if (cfg < 0 || cfg >= n) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : choose(t, n, a.M, a.N);
+    // vocab pick: 64x96 tiles put ~3 independent workgroups on every CU at M = (K+1)*B = 384 (750 tiles); measured
+    // 109 us vs 131 us for one 96x192 8-wave workgroup per CU and 136 us for 64x128
+    if (cfg < 0 || cfg >= n) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : (epi == EPI_PICK && a.M >= 64 ? kPick64x96 : choose(t, n, a.M, a.N));
     const CfgEntry& e = t[cfg];
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     const int mt = ceil_div(a.M, e.BM), nt = ceil_div(a.N, e.CG);

@@ -4,6 +4,8 @@
 // global-norm clip + TF-form Adam.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "api_util.h"
 
 using namespace s2vt_api;
@@ -37,8 +39,10 @@ struct SlabPlan { int splits, kper, nslab; };
 SlabPlan slab_plan(int M, int H)
 {
     const int K = 4 * H;
-    const long tiles = (long)((M + 63) / 64) * ((H + 31) / 32);
-    int splits = (int)((512 + tiles - 1) / tiles);
+    static const int want = [] { const char* e = getenv("S2VT_SLAB_WGS"); return e ? atoi(e) : 512; }();     // dev knob
+    static const int tn_ = [] { const char* e = getenv("S2VT_SLAB_TILE_N"); return e ? atoi(e) : 32; }();   // dev knob (columns of the tile nn_bwd will get)
+    const long tiles = (long)((M + 63) / 64) * ((H + tn_ - 1) / tn_);
+    int splits = (int)((want + tiles - 1) / tiles);
     if (splits < 1) splits = 1;
     if (splits > kMaxSlabs) splits = kMaxSlabs;
     SlabPlan p;
@@ -90,7 +94,8 @@ hipError_t nn_bwd(const float* A, int lda, const float* W, int ldw, float* C, in
         a.splits = (K + a.kper - 1) / a.kper;
         a.slab_stride = slab_stride;
     }
-    return launch_gemm(a, EPI_STORE, -1, st);
+    static const int cfg_ = [] { const char* e = getenv("S2VT_SLAB_CFG"); return e ? atoi(e) : -1; }();     // dev knob
+    return launch_gemm(a, EPI_STORE, splits > 1 ? cfg_ : -1, st);
 }
 
 }  // namespace
