@@ -120,13 +120,23 @@ def main():
         return mdl.reinforce_update(video, s, mask, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,
                                     reuse_sampler_state=True)    # LSTM1 trajectory of the sampler pass (same videos, same weights)
 
+    # Warm-up: every contraction launch is bracketed by HIP events (in-library, on the launching stream) to get the
+    # per-kernel table and find the dominant kernel; inside the timed region only THAT kernel keeps its events
+    # (two events per launch on all ~600 launches of a step cost ~10 % of the step).
+    ops.prof_filter(-1, -1)
+    ops.prof_enable(True)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    warm_rows = ops.prof_collect()
+    dom_w = max(warm_rows, key=lambda r: r["total_ms"]) if warm_rows else None
+    if dom_w:
+        ops.prof_filter(dom_w["kernel_class"], dom_w["tile_cfg"])
+    else:
+        ops.prof_enable(False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.prof_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         st = step(args.warmup + i)
@@ -137,6 +147,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.prof_enable(False)
     rows = ops.prof_collect()
+    ops.prof_filter(-1, -1)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -162,9 +173,9 @@ def main():
                     "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
                     "share_of_step": round(dom["total_ms"] / (dt * 1e3), 3),
                     "whole_step_frac": round(FLOPS_PER_STEP * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "all_kernels": [{"class": r["kernel_class"], "tile": r["name"], "launches": r["launches"],
-                                     "ms": round(r["total_ms"], 2), "tflops": round(r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)}
-                                    for r in sorted(rows, key=lambda r: -r["total_ms"])]}
+                    "all_kernels_warmup": [{"class": r["kernel_class"], "tile": r["name"], "launches": r["launches"],
+                                            "ms": round(r["total_ms"], 2), "tflops": round(r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)}
+                                           for r in sorted(warm_rows, key=lambda r: -r["total_ms"])]}
         out = {"metric": "sampled caption tokens/sec (REINFORCE step)", "value": round(value, 1), "unit": "tokens/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -87,6 +87,10 @@ typedef struct s2vt_prof_row {
     char name[32];
 } s2vt_prof_row;
 int s2vt_prof_enable(int on);
+/* Restrict the event brackets to one (kernel_class, tile_cfg); -1 = any.  Two events per launch cost ~1.5 us of
+ * stream time each, ~10 % of a 600-launch step: bench.py profiles every launch during warm-up to find the dominant
+ * kernel and only that kernel inside the timed region. */
+int s2vt_prof_filter(int kernel_class, int tile_cfg);
 int s2vt_prof_collect(s2vt_prof_row* rows, int max_rows);
 
 /* ---- test hook: evaluate the contract's scalar functions on the device --------------------

@@ -49,6 +49,7 @@ SIGNATURES = {
     "s2vt_last_hip_error": (C.c_int, []),
     "s2vt_error_string": (C.c_char_p, [C.c_int]),
     "s2vt_prof_enable": (C.c_int, [C.c_int]),
+    "s2vt_prof_filter": (C.c_int, [C.c_int, C.c_int]),
     "s2vt_prof_collect": (C.c_int, [C.POINTER(ProfRow), C.c_int]),
     "s2vt_math_eval": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp]),
     "s2vt_gumbel_eval": (C.c_int, [_u64, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -76,6 +76,12 @@ int s2vt_prof_enable(int on)
     return S2VT_OK;
 }
 
+int s2vt_prof_filter(int kernel_class, int tile_cfg)
+{
+    prof_filter(kernel_class, tile_cfg);
+    return S2VT_OK;
+}
+
 int s2vt_prof_collect(s2vt_prof_row* rows, int max_rows)
 {
     if (!rows || max_rows <= 0) return S2VT_E_BADARG;

@@ -409,7 +409,8 @@ constexpr TnCfg tn_entry()
     return TnCfg{gemm_tn_kernel<WM, WN, TM, TN, true>, gemm_tn_kernel<WM, WN, TM, TN, false>, BMo, BNo, 64 * WM * WN,
                  2 * 32 * (SAo + SBo) * 4};
 }
-const TnCfg kTn[] = {tn_entry<2, 2, 4, 4>() /*128x128*/, tn_entry<2, 2, 2, 4>() /*64x128*/, tn_entry<2, 2, 2, 2>() /*64x64*/};
+const TnCfg kTn[] = {tn_entry<2, 2, 4, 4>() /*128x128*/, tn_entry<2, 2, 2, 4>() /*64x128*/, tn_entry<2, 2, 2, 2>() /*64x64*/,
+                     tn_entry<2, 2, 3, 3>() /*96x96*/, tn_entry<2, 2, 2, 3>() /*64x96*/, tn_entry<2, 2, 3, 4>() /*96x128*/};
 std::once_flag g_tn_once;
 }  // namespace
 
@@ -426,6 +427,8 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     int ci = 0;
     if (tiles(kTn[0]) < 200) ci = 1;
     if (ci == 1 && tiles(kTn[1]) < 200) ci = 2;
+    static const int force = [] { const char* e = getenv("S2VT_TN_CFG"); return e ? atoi(e) : -1; }();       // dev knob
+    if (force >= 0 && ci == 0) ci = force;
     const TnCfg& c = kTn[ci];
     const long nt = tiles(c);
     int splits = 1;
@@ -449,14 +452,14 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     }
     const bool vec = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0 && (a.lda & 3) == 0 &&
                      (a.ldb & 3) == 0 && (a.Kout & 3) == 0 && (a.N & 3) == 0;
-    if (!prof_on()) {
+    if (!prof_wants(3, ci)) {
         hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
         return hipGetLastError();
     }
     hipEvent_t e0, e1;
     hipError_t pe = prof_events(&e0, &e1);
     if (pe != hipSuccess) return pe;
-    static const char* names[] = {"tn128x128(2x2)", "tn64x128(2x2)", "tn64x64(2x2)"};
+    static const char* names[] = {"tn128x128(2x2)", "tn64x128(2x2)", "tn64x64(2x2)", "tn96x96(2x2)", "tn64x96(2x2)", "tn96x128(2x2)"};
     (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
     (void)hipEventRecord(e1, st);

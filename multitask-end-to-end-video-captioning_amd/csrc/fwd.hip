@@ -34,6 +34,9 @@ const CfgEntry kStore[] = {
     make_entry<2, 2, 4, 4, 1, EPI_STORE>("128x128(2x2)"),
     make_entry<4, 1, 2, 2, 1, EPI_STORE>("128x32(4x1)"),
     make_entry<4, 1, 1, 2, 1, EPI_STORE>("64x32(4x1)"),
+    make_entry<2, 2, 2, 3, 1, EPI_STORE>("64x96(2x2)"),
+    make_entry<2, 2, 3, 3, 1, EPI_STORE>("96x96(2x2)"),
+    make_entry<2, 2, 3, 4, 1, EPI_STORE>("96x128(2x2)"),
 };
 const CfgEntry kLstm[] = {
     // all four gates of 16 (32) units in one wave
@@ -86,19 +89,22 @@ bool can_vec(const GemmArgs& a)
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// Pick the configuration with the best estimated time on 256 CUs: work per workgroup times the
-// number of dispatch rounds, with a small penalty for thin tiles (more operand traffic per flop).
-int choose(const CfgEntry* t, int n, int M, int N)
+// Pick the configuration with the best estimated time on 256 CUs.  The launch is MFMA-bound when every CU holds
+// at least two workgroups, and the workgroups of a CU share its matrix pipes, so time ~ (workgroups on the busiest
+// CU) x (flops of one tile), times a penalty for thin tiles (operand bytes per flop) and for a lone 4-wave
+// workgroup per CU (nothing to overlap its barriers with).  Calibrated on the bench shapes: 6400x12000x1000 picks
+// 96x96 (105 vs 96 TFLOP/s for 128x128, whose 400 tiles leave half the CUs with one workgroup), the others 128x128.
+int choose(const CfgEntry* t, int n, int M, int N, int splits = 1)
 {
     int best = 0;
     double best_cost = 1e300;
     for (int i = 0; i < n; ++i) {
-        const long wgs = (long)ceil_div(M, t[i].BM) * ceil_div(N, t[i].CG);
-        const int per_cu = t[i].lds_bytes > 80 * 1024 ? 1 : 2;
-        const double rounds = (double)((wgs + 256L * per_cu - 1) / (256L * per_cu));
+        const long wgs = (long)ceil_div(M, t[i].BM) * ceil_div(N, t[i].CG) * (splits > 1 ? splits : 1);
+        const long per_cu = (wgs + 255) / 256;
         const double tile = (double)t[i].BM * t[i].CG;
         const double traffic = 1.0 + 24.0 * (t[i].BM + t[i].CG) / tile;  // operand bytes per flop, relative
-        const double cost = rounds * per_cu * tile * traffic;
+        const double lone = (per_cu == 1 && t[i].NT < 512) ? 1.4 : 1.0;
+        const double cost = (double)per_cu * tile * traffic * lone;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
     return best;
@@ -120,6 +126,7 @@ std::once_flag g_attr_once;
 struct Pending { int cls, cfg; const char* name; double flops; hipEvent_t e0, e1; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+int g_prof_cls = -1, g_prof_cfg = -1;      // >= 0: only launches of this (class, tile cfg) are bracketed by events
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_event_pool;
 
@@ -145,6 +152,13 @@ void prof_enable(bool on)
     g_prof_on = on;
 }
 bool prof_on() { return g_prof_on; }
+bool prof_wants(int cls, int cfg) { return g_prof_on && (g_prof_cls < 0 || (g_prof_cls == cls && (g_prof_cfg < 0 || g_prof_cfg == cfg))); }
+void prof_filter(int cls, int cfg)
+{
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    g_prof_cls = cls;
+    g_prof_cfg = cfg;
+}
 
 hipError_t prof_events(hipEvent_t* e0, hipEvent_t* e1)
 {
@@ -213,7 +227,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     const CfgEntry* t = table(epi, &n);
     // vocab pick: 64x96 tiles put ~3 independent workgroups on every CU at M = (K+1)*B = 384 (750 tiles); measured
     // 109 us vs 131 us for one 96x192 8-wave workgroup per CU and 136 us for 64x128
-    if (cfg < 0 || cfg >= n) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : (epi == EPI_PICK && a.M >= 64 ? kPick64x96 : choose(t, n, a.M, a.N));
+    if (cfg < 0 || cfg >= n) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : (epi == EPI_PICK && a.M >= 64 ? kPick64x96 : choose(t, n, a.M, a.N, a.splits));
     const CfgEntry& e = t[cfg];
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     const int mt = ceil_div(a.M, e.BM), nt = ceil_div(a.N, e.CG);
@@ -225,7 +239,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     const unsigned gx = a2.xcd_map ? (unsigned)(mt * ceil_div(nt, 8) * 8) : (unsigned)(mt * nt);
     const dim3 grid(gx, (unsigned)(a.splits > 1 ? a.splits : 1), 1);
     KernelFn fn = can_vec(a) ? e.vec : e.scalar;
-    if (!g_prof_on) {
+    if (!prof_wants(epi == EPI_LSTM_GW ? EPI_LSTM : epi, cfg)) {
         hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a2);
         return hipGetLastError();
     }

@@ -17,6 +17,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st);
 struct ProfRow { int cls, cfg; long launches; double ms, flops; const char* name; };
 void prof_enable(bool on);
 bool prof_on();
+bool prof_wants(int cls, int cfg);          // profiler on and (cls, cfg) passes the filter
+void prof_filter(int cls, int cfg);         // -1 = any
 void prof_record(int cls, int cfg, const char* name, double flops, hipEvent_t e0, hipEvent_t e1);
 hipError_t prof_events(hipEvent_t* e0, hipEvent_t* e1);
 int prof_collect(ProfRow* rows, int max_rows);

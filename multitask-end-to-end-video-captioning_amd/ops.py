@@ -215,6 +215,10 @@ def prof_enable(on: bool):
     check(lib().s2vt_prof_enable(1 if on else 0), "s2vt_prof_enable")
 
 
+def prof_filter(kernel_class: int = -1, tile_cfg: int = -1):
+    check(lib().s2vt_prof_filter(kernel_class, tile_cfg), "s2vt_prof_filter")
+
+
 def prof_collect():
     """Rows of the launch profiler (call after torch.cuda.synchronize())."""
     rows = (_lib.ProfRow * 64)()
