@@ -10,9 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace s2vt {
+#include "gemm_mfma.h"      // gload16 / wait_vmcnt / pin / s2vt_zero16: the asm-issued load ring
 
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
+namespace s2vt {
 
 struct TnKArgs {
     const float* A; const int* rowidx; int lda;
@@ -30,6 +30,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
     constexpr int NT = 64 * WM * WN, BMo = WM * TM * 16, BNo = WN * TN * 16, BR = 32;
     constexpr int SAo = (BMo % 32 == 16) ? BMo : BMo + 16, SBo = (BNo % 32 == 16) ? BNo : BNo + 16;
     constexpr int A4 = (BR * (BMo / 4) + NT - 1) / NT, B4 = (BR * (BNo / 4) + NT - 1) / NT;
+    constexpr int LPC = A4 + B4;                       // asm-issued loads per chunk per thread
+    constexpr int PF = 2;                              // chunks in flight (ring slots), as the forward kernel's big tiles
+    constexpr int WAITN = (PF - 1) * LPC;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][BR][SAo]
     float* Bs = smem + 2 * BR * SAo;   // [2][BR][SBo]
@@ -40,82 +43,86 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
     const int k0 = (blockIdx.x / ntn) * BMo, n0 = (blockIdx.x % ntn) * BNo;
     const int mbeg = blockIdx.y * g.mper;
     const int mend = (mbeg + g.mper < g.Mred) ? mbeg + g.mper : g.Mred;
+    const int nchunks = mend > mbeg ? (mend - mbeg + BR - 1) / BR : 0;
 
-    f32x4_t acc[TM][TN];
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[A4], rb[B4];
-    auto load = [&](int m0) {
+    // Staging ring: PF chunks between global memory and the LDS double buffer.  VEC: loads are inline asm (hipcc
+    // would sink ordinary loads next to their LDS store and drain them with vmcnt(0)), waited for with a
+    // hand-counted vmcnt; out-of-range lanes (rows beyond the split, columns beyond the matrix) read s2vt_zero16.
+    f32x4 ra[PF][A4], rb[PF][B4];
+    auto issue = [&](int c, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
+        const int m0 = mbeg + c * BR;
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
             const int idx = tid + i * NT;
-            const int r = idx / (BMo / 4), c = (idx % (BMo / 4)) * 4;
-            const int m = m0 + r, k = k0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < BR * (BMo / 4) && m < mend) {
-                const int src = g.rowidx ? g.rowidx[m] : m;
-                const float* p = g.A + (size_t)src * g.lda + k;
-                if (VEC) {
-                    if (k < g.Kout) v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (k + 0 < g.Kout) v.x = p[0];
-                    if (k + 1 < g.Kout) v.y = p[1];
-                    if (k + 2 < g.Kout) v.z = p[2];
-                    if (k + 3 < g.Kout) v.w = p[3];
+            const int r = idx / (BMo / 4), cc = (idx % (BMo / 4)) * 4;
+            const int m = m0 + r, k = k0 + cc;
+            const bool inr = (A4 * NT == BR * (BMo / 4) || idx < BR * (BMo / 4)) && m < mend;
+            if constexpr (VEC) {
+                const bool ok = inr && k < g.Kout;
+                const int src = ok ? (g.rowidx ? g.rowidx[m] : m) : 0;
+                gload16(qa[i], ok ? g.A + (size_t)src * g.lda + k : s2vt_zero16);
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (inr) {
+                    const int src = g.rowidx ? g.rowidx[m] : m;
+                    const float* p = g.A + (size_t)src * g.lda + k;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < g.Kout) v[e] = p[e];
                 }
+                qa[i] = v;
             }
-            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
             const int idx = tid + i * NT;
-            const int r = idx / (BNo / 4), c = (idx % (BNo / 4)) * 4;
-            const int m = m0 + r, n = n0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < BR * (BNo / 4) && m < mend) {
-                const float* p = g.B + (size_t)m * g.ldb + n;
-                if (VEC) {
-                    if (n < g.N) v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (n + 0 < g.N) v.x = p[0];
-                    if (n + 1 < g.N) v.y = p[1];
-                    if (n + 2 < g.N) v.z = p[2];
-                    if (n + 3 < g.N) v.w = p[3];
+            const int r = idx / (BNo / 4), cc = (idx % (BNo / 4)) * 4;
+            const int m = m0 + r, n = n0 + cc;
+            const bool inr = (B4 * NT == BR * (BNo / 4) || idx < BR * (BNo / 4)) && m < mend;
+            if constexpr (VEC) {
+                const bool ok = inr && n < g.N;
+                gload16(qb[i], ok ? g.B + (size_t)m * g.ldb + n : s2vt_zero16);
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (inr) {
+                    const float* p = g.B + (size_t)m * g.ldb + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < g.N) v[e] = p[e];
                 }
+                qb[i] = v;
             }
-            rb[i] = v;
         }
     };
-    auto store = [&](int buf) {
+    auto land = [&](int buf, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
         float* a = As + buf * BR * SAo;
         float* b = Bs + buf * BR * SBo;
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
+            if constexpr (VEC) pin(qa[i]);
             const int idx = tid + i * NT;
-            if (idx < BR * (BMo / 4))
-                *reinterpret_cast<float4*>(a + (idx / (BMo / 4)) * SAo + (idx % (BMo / 4)) * 4) = ra[i];
+            if (A4 * NT == BR * (BMo / 4) || idx < BR * (BMo / 4))
+                *reinterpret_cast<f32x4*>(a + (idx / (BMo / 4)) * SAo + (idx % (BMo / 4)) * 4) = qa[i];
         }
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
+            if constexpr (VEC) pin(qb[i]);
             const int idx = tid + i * NT;
-            if (idx < BR * (BNo / 4))
-                *reinterpret_cast<float4*>(b + (idx / (BNo / 4)) * SBo + (idx % (BNo / 4)) * 4) = rb[i];
+            if (B4 * NT == BR * (BNo / 4) || idx < BR * (BNo / 4))
+                *reinterpret_cast<f32x4*>(b + (idx / (BNo / 4)) * SBo + (idx % (BNo / 4)) * 4) = qb[i];
         }
     };
-
-    if (mbeg < mend) { load(mbeg); store(0); }
-    __syncthreads();
-    int buf = 0;
-    for (int m0 = mbeg; m0 < mend; m0 += BR) {
-        const bool more = m0 + BR < mend;
-        if (more) load(m0 + BR);
+    auto compute = [&](int buf, int ms0, int ms1) __attribute__((always_inline)) {
         const float* a = As + buf * BR * SAo + lq * SAo + (wm * TM) * 16 + l15;
         const float* b = Bs + buf * BR * SBo + lq * SBo + (wn * TN) * 16 + l15;
 #pragma unroll
-        for (int ms = 0; ms < BR / 4; ++ms) {
+        for (int ms = ms0; ms < ms1; ++ms) {
             float av[TM], bv[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) av[i] = a[ms * 4 * SAo + i * 16];
@@ -127,9 +134,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store(buf ^ 1);
+    };
+
+    if (nchunks > 0) {
+        // prologue: chunk 0 -> LDS[0]; chunk 1 in flight in slot 1.  (Chunks beyond the split load zeros.)
+        issue(0, ra[0], rb[0]);
+        if constexpr (VEC) wait_vmcnt<0>();
+        land(0, ra[0], rb[0]);
+        issue(1, ra[1], rb[1]);
         __syncthreads();
-        buf ^= 1;
+        int c = 0;
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                if (more) {
+                    issue(c + PF, ra[j], rb[j]);                  // the slot chunk c came from
+                    compute(c & 1, 0, BR / 8);
+                    if constexpr (VEC) wait_vmcnt<WAITN>();       // all but the youngest chunk have returned
+                    land((c + 1) & 1, ra[(j + 1) % PF], rb[(j + 1) % PF]);
+                    compute(c & 1, BR / 8, BR / 4);
+                    __syncthreads();
+                    ++c;
+                    more = c < nchunks;
+                }
+            }
+        }
+        // loads still in flight belong to chunks beyond the split: wait, and keep their registers alive until then
+        if constexpr (VEC) {
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+#pragma unroll
+                for (int i = 0; i < A4; ++i) pin(ra[j][i]);
+#pragma unroll
+                for (int i = 0; i < B4; ++i) pin(rb[j][i]);
+            }
+        }
     }
 
 #pragma unroll
