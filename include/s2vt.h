@@ -300,6 +300,20 @@ int s2vt_embed_gather(const float* Wemb, int32_t ldw, const int32_t* idx, int32_
  * g *= clip_norm / max(||g||, clip_norm); *sumsq_scratch receives ||g||^2 (before clipping). */
 int s2vt_global_norm_clip(float* g, int64_t n, float clip_norm, float* sumsq_scratch, s2vt_stream stream);
 
+/* ---- generic order-free pieces for backward graphs composed on the host (used by the attention captioner's
+ * training step, attention.py; the S2VT path has them fused inside s2vt_bptt_bwd) ---------------------------
+ * s2vt_gemm_tn : C[Kout,N] (+)= A[row(m), :Kout]^T @ B[m, :N] over m < Mred  (weight gradients; rowidx gathers rows)
+ * s2vt_transpose: out[c, r] = in[r, c]                       s2vt_colsum: out[n] += sum_m X[m, n]  (bias gradients)
+ * s2vt_tanh_bwd : dx = dy * (1 - y^2)                        s2vt_dropout_bwd: dh = (dout / keep) * mask, the adjoint
+ *                 of the DropoutWrapper output of s2vt_lstm_cell_fwd (same seed / ids / drop_code). */
+int s2vt_gemm_tn(const float* A, int32_t lda, const int32_t* rowidx, const float* B, int32_t ldb, float* C, int32_t ldc,
+                 int32_t Mred, int32_t Kout, int32_t N, int32_t accumulate, s2vt_stream stream);
+int s2vt_transpose(const float* in, int32_t ldi, float* out, int32_t ldo, int32_t R, int32_t Cc, s2vt_stream stream);
+int s2vt_colsum(const float* X, int32_t ld, int32_t M, int32_t N, float* out, s2vt_stream stream);
+int s2vt_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, s2vt_stream stream);
+int s2vt_dropout_bwd(const float* dout, int32_t ld, float* dh, int32_t M, int32_t H, float keep, uint64_t seed,
+                     uint32_t drop_code, const int32_t* video_id, const int32_t* sample_id, s2vt_stream stream);
+
 /* In-place SUM all-reduce of the flat gradient bucket over an existing RCCL communicator (ncclComm_t as
  * void*), on `stream`.  RCCL is resolved at run time; Python hosts use torch.distributed instead. */
 int s2vt_allreduce_grads(float* bucket, int64_t n, void* rccl_comm, s2vt_stream stream);

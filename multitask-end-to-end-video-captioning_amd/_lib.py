@@ -86,6 +86,11 @@ SIGNATURES = {
     "s2vt_pg_nll_fwd_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_embed_gather": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _i32, _vp]),
     "s2vt_global_norm_clip": (C.c_int, [_vp, _i64, _f32, _vp, _vp]),
+    "s2vt_gemm_tn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "s2vt_transpose": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "s2vt_colsum": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "s2vt_tanh_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "s2vt_dropout_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _f32, _u64, _u32, _vp, _vp, _vp]),
     "s2vt_allreduce_grads": (C.c_int, [_vp, _i64, _vp, _vp]),
 }
 

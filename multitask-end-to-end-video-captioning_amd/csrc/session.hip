@@ -56,6 +56,12 @@ __global__ void scale_by_clip_kernel(float* g, int64_t n, const float* sumsq, fl
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = g[i] * s;
 }
 
+__global__ void tanh_bwd_kernel(const float* y, const float* dy, float* dx, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * (1.0f - y[i] * y[i]);
+}
+
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 
 }  // namespace
@@ -197,6 +203,48 @@ int s2vt_global_norm_clip(float* g, int64_t n, float clip_norm, float* sumsq_scr
         hipLaunchKernelGGL(scale_by_clip_kernel, dim3(blocks), dim3(256), 0, S(stream), g, n, sumsq_scratch, clip_norm);
         HIP_TRY(hipGetLastError());
     }
+    return S2VT_OK;
+}
+
+/* ---- generic pieces for graphs composed on the host (the attention captioner's backward) ---- */
+int s2vt_gemm_tn(const float* A, int32_t lda, const int32_t* rowidx, const float* Bm, int32_t ldb, float* Cm, int32_t ldc,
+                 int32_t Mred, int32_t Kout, int32_t N, int32_t accumulate, s2vt_stream stream)
+{
+    if (!A || !Bm || !Cm || Mred < 0 || Kout <= 0 || N <= 0 || lda < Kout || ldb < N || ldc < N) return S2VT_E_BADARG;
+    if (Mred == 0) return S2VT_OK;
+    TnArgs a{A, rowidx, lda, Bm, ldb, Cm, ldc, Mred, Kout, N, accumulate ? 1 : 0};
+    HIP_TRY(launch_gemm_tn(a, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_transpose(const float* in, int32_t ldi, float* out, int32_t ldo, int32_t R, int32_t Cc, s2vt_stream stream)
+{
+    if (!in || !out || R < 0 || Cc < 0 || ldi < Cc || ldo < R) return S2VT_E_BADARG;
+    HIP_TRY(launch_transpose(in, ldi, out, ldo, R, Cc, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_colsum(const float* X, int32_t ld, int32_t M, int32_t N, float* out, s2vt_stream stream)
+{
+    if (!X || !out || M < 0 || N <= 0 || ld < N) return S2VT_E_BADARG;
+    HIP_TRY(launch_colsum(X, ld, M, N, out, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, s2vt_stream stream)
+{
+    if (!y || !dy || !dx || n < 0) return S2VT_E_BADARG;
+    if (n == 0) return S2VT_OK;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), y, dy, dx, n);
+    HIP_TRY(hipGetLastError());
+    return S2VT_OK;
+}
+
+int s2vt_dropout_bwd(const float* dout, int32_t ld, float* dh, int32_t M, int32_t H, float keep, uint64_t seed,
+                     uint32_t drop_code, const int32_t* video_id, const int32_t* sample_id, s2vt_stream stream)
+{
+    if (!dout || !dh || M < 0 || H <= 0 || ld < H || !(keep > 0.0f) || (keep < 1.0f && (!video_id || !sample_id))) return S2VT_E_BADARG;
+    HIP_TRY(launch_reduce_dropout(dout, ld, dh, 1, M, M, H, keep, seed, drop_code, video_id, sample_id, S(stream)));
     return S2VT_OK;
 }
 

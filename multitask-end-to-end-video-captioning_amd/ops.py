@@ -385,3 +385,41 @@ def global_norm_clip(g, clip_norm: float):
     sumsq = torch.empty(1, dtype=torch.float32, device=g.device)
     check(lib().s2vt_global_norm_clip(_ptr(g), g.numel(), float(clip_norm), _ptr(sumsq), _stream()), "s2vt_global_norm_clip")
     return sumsq
+
+
+def gemm_tn(A, B, C_, accumulate=True, rowidx=None):
+    """C_[Kout,N] (+)= A[row(m)]^T @ B over the rows m (weight gradient of X @ W)."""
+    _chk_f32(A, B, C_)
+    Mred, N = B.shape
+    Kout = C_.shape[0]
+    check(lib().s2vt_gemm_tn(_ptr(A), A.stride(0), _ptr(rowidx), _ptr(B), B.stride(0), _ptr(C_), C_.stride(0), Mred, Kout, N,
+                             1 if accumulate else 0, _stream()), "s2vt_gemm_tn")
+
+
+def transpose(W):
+    _chk_f32(W)
+    R, Cc = W.shape
+    out = torch.empty((Cc, R), dtype=torch.float32, device=W.device)
+    check(lib().s2vt_transpose(_ptr(W), W.stride(0), _ptr(out), R, R, Cc, _stream()), "s2vt_transpose")
+    return out
+
+
+def colsum(X, out):
+    _chk_f32(X, out)
+    check(lib().s2vt_colsum(_ptr(X), X.stride(0), X.shape[0], X.shape[1], _ptr(out), _stream()), "s2vt_colsum")
+
+
+def tanh_bwd(y, dy):
+    _chk_f32(y, dy)
+    dx = torch.empty_like(y)
+    check(lib().s2vt_tanh_bwd(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), _stream()), "s2vt_tanh_bwd")
+    return dx
+
+
+def dropout_bwd(dout, keep, seed, drop_code, video_id, sample_id):
+    _chk_f32(dout)
+    M, H = dout.shape
+    dh = torch.empty((M, H), dtype=torch.float32, device=dout.device)
+    check(lib().s2vt_dropout_bwd(_ptr(dout), dout.stride(0), _ptr(dh), M, H, float(keep), seed, drop_code, _ptr(video_id),
+                                 _ptr(sample_id), _stream()), "s2vt_dropout_bwd")
+    return dh

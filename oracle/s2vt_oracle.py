@@ -384,12 +384,13 @@ def attention_forward(p, d: Dims, video, caption, drop=None, keep=1.0, greedy=Fa
     Vt = np.ascontiguousarray(Vt.reshape(B, Tv, H).transpose(1, 0, 2))        # [Tv,B,H]  (:98)
     P = xw_plus_b(Vt.reshape(Tv * B, H), p["embed_att_Ua"], p["embed_att_ba"]).reshape(Tv, B, H)  # (:107)
     c = np.zeros((B, H), np.float32); h_prev = np.zeros((B, H), np.float32)
+    q_prev = np.zeros((B, H), np.float32)                                    # attention query = previous DROPPED output (:135)
     emb = np.zeros((B, H), np.float32)                                       # (:105)
     W3 = p["lstm3_W"]; Wp = p["embed_nn_Wp"]
     logits = np.empty((B, Tc, d.n_words), np.float32); alphas = np.empty((Tc, Tv, B), np.float32)
     ids = np.empty((B, Tc), np.int32)
     for t in range(Tc):
-        hWa = gemm_chain(h_prev, p["embed_att_Wa"])
+        hWa = gemm_chain(q_prev, p["embed_att_Wa"])
         alpha, ctx = attention_step(hWa, P, Vt, p["embed_att_w"])            # (:113-128)
         z = gemm_chain(ctx, W3[:H]); gemm_chain(emb, W3[H:2 * H], z); gemm_chain(h_prev, W3[2 * H:], z)
         bias_add(z, p["lstm3_b"])
@@ -397,7 +398,8 @@ def attention_forward(p, d: Dims, video, caption, drop=None, keep=1.0, greedy=Fa
         y = gemm_chain(out, Wp[:H]); gemm_chain(ctx, Wp[H:2 * H], y); gemm_chain(emb, Wp[2 * H:], y)
         bias_add(y, p["embed_nn_bp"])
         lib().orc_tanh_inplace(_fp(y), C.c_int64(y.size))                     # (:134)
-        h_prev = h
+        h_prev = h                                                            # the cell state carries the clean h (state_is_tuple=False)
+        q_prev = out                                                          # `h_prev = output1` (:135): the DropoutWrapper output
         logits[:, t] = xw_plus_b(y, p["embed_word_W"], p["embed_word_b"])     # (:143)
         alphas[t] = alpha
         if greedy:

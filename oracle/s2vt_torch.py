@@ -139,9 +139,10 @@ def attention_teacher_forced(p, video, caption, drop=None, keep=1.0):
     Vt = (video.reshape(B * Tv, D) @ p["encode_image_W"] + p["encode_image_b"]).reshape(B, Tv, H).transpose(0, 1)
     P = Vt @ p["embed_att_Ua"] + p["embed_att_ba"]
     c = torch.zeros(B, H, dtype=dt); h_prev = torch.zeros(B, H, dtype=dt); emb = torch.zeros(B, H, dtype=dt)
+    q_prev = torch.zeros(B, H, dtype=dt)        # attention query = the previous DropoutWrapper output (original_attention.py:135)
     out_logits, alphas = [], []
     for t in range(Tc):
-        e = torch.tanh(h_prev @ p["embed_att_Wa"] + P) @ p["embed_att_w"]          # [Tv,B,1]
+        e = torch.tanh(q_prev @ p["embed_att_Wa"] + P) @ p["embed_att_w"]          # [Tv,B,1]
         ex = torch.exp(e.squeeze(-1))
         den = ex.sum(0)
         den = den + (den == 0).to(dt)
@@ -151,6 +152,7 @@ def attention_teacher_forced(p, video, caption, drop=None, keep=1.0):
         out, c, h = lstm_cell(torch.cat([ctx, emb], 1), c, h_prev, p["lstm3_W"], p["lstm3_b"], dm, keep)
         y = torch.tanh(torch.cat([out, ctx, emb], 1) @ p["embed_nn_Wp"] + p["embed_nn_bp"])
         h_prev = h
+        q_prev = out
         emb = p["Wemb"][caption[:, t]]
         out_logits.append(y @ p["embed_word_W"] + p["embed_word_b"])
         alphas.append(alpha)
