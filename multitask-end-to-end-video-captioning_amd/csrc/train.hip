@@ -73,6 +73,35 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     return c.off;
 }
 
+// A second stream for the backward pass: the recurrences (25 dependent steps of small kernels, ~half the
+// matrix pipes idle) run on the caller's stream while weight-gradient contractions that do not depend on them
+// run here, forked / joined with events so the call keeps its stream semantics.  Created once per process.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = false;
+};
+SideStream& side_stream()
+{
+    static SideStream ss = [] {
+        SideStream t;
+        const char* off = getenv("S2VT_NO_OVERLAP");          // dev knob: run the backward on one stream
+        if (off && off[0] == '1') return t;
+        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return t;
+        for (auto& e : t.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return t;
+        t.ok = true;
+        return t;
+    }();
+    return ss;
+}
+// side waits for everything issued so far on `from`
+hipError_t fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev)
+{
+    hipError_t e = hipEventRecord(ev, from);
+    return e != hipSuccess ? e : hipStreamWaitEvent(to, ev, 0);
+}
+
 bool params_ok(const s2vt_params* p)
 {
     return p && p->Wemb && p->encode_image_W && p->encode_image_b && p->lstm1_W && p->lstm1_b && p->lstm2_W && p->lstm2_b &&
@@ -237,12 +266,16 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
 
     // phase 1 = the vocab projection (its gradients are final after it: a data-parallel caller starts their
     // all-reduce while phase 2, everything else, still runs); phase 0 = both
+    SideStream& ss = side_stream();
+    hipStream_t sd = ss.ok ? ss.s : st;                     // weight-gradient work that may run beside a recurrence
     if (phase != 2) {
         // transposed weight copy for the data-gradient product + the vocab projection
-        HIP_TRY(launch_transpose(p->embed_word_W, V, w.WoutT, H, H, V, st));
+        hipStream_t sv = phase == 0 ? sd : st;              // (phase 1: its gradients must be final on the caller's stream)
+        if (sv != st) HIP_TRY(fork_to(st, sv, ss.ev[0]));
         TnArgs a{w.O2 + (size_t)Tv * NH, nullptr, H, dlogits, V, grads->embed_word_W, V, Tc * N, H, V, 1};
-        HIP_TRY(launch_gemm_tn(a, st));
-        HIP_TRY(launch_colsum(dlogits, V, Tc * N, V, grads->embed_word_b, st));
+        HIP_TRY(launch_gemm_tn(a, sv));
+        HIP_TRY(launch_colsum(dlogits, V, Tc * N, V, grads->embed_word_b, sv));
+        HIP_TRY(launch_transpose(p->embed_word_W, V, w.WoutT, H, H, V, st));
         HIP_TRY(nn_bwd(dlogits, V, w.WoutT, H, w.dO2, H, Tc * N, H, V, 1, 0, st));
     }
     if (phase == 1) return S2VT_OK;
@@ -260,6 +293,18 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
             HIP_TRY(nn_bwd(w.dZ2 + (size_t)t * 4 * NH, 4 * H, w.W2T + (H + E), K2, w.slab, H, N, H, 4 * H, sp2.splits, NH, st));
         }
     }
+    // dZ2 is complete: LSTM2's weight gradients go to the side stream, beside dX2 and LSTM1's recurrence
+    if (sd != st) HIP_TRY(fork_to(st, sd, ss.ev[1]));
+    {
+        TnArgs a{w.O1, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W, 4 * H, T * N, H, 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(a, sd));
+        TnArgs b{p->Wemb, w.prev, E, w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, grads->lstm2_W + (size_t)H * 4 * H, 4 * H, Tc * N, E,
+                 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(b, sd));
+        TnArgs e{w.H2, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, T * N, H, 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(e, sd));
+        HIP_TRY(launch_colsum(w.dZ2, 4 * H, T * N, 4 * H, grads->lstm2_b, sd));
+    }
     // d[out1 ; embed] for every step at once
     HIP_TRY(nn_bwd(w.dZ2, 4 * H, w.W2T, K2, w.dX2, H + E, T * N, H + E, 4 * H, 1, 0, st));
     // ---- LSTM1 back through time, on the B per-video rows: the gradient w.r.t. its dropped output is
@@ -275,16 +320,8 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
     }
     HIP_TRY(nn_bwd(w.dZ1, 4 * H, w.W1T, K1, w.dX1, E, Tv * B, E, 4 * H, 1, 0, st));
 
-    // ---- weight gradients: one contraction over all unrolled steps per weight block
+    // ---- remaining weight gradients: one contraction over all unrolled steps per weight block
     {
-        TnArgs a{w.O1, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W, 4 * H, T * N, H, 4 * H, 1};
-        HIP_TRY(launch_gemm_tn(a, st));
-        TnArgs b{p->Wemb, w.prev, E, w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, grads->lstm2_W + (size_t)H * 4 * H, 4 * H, Tc * N, E,
-                 4 * H, 1};
-        HIP_TRY(launch_gemm_tn(b, st));
-        TnArgs e{w.H2, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, T * N, H, 4 * H, 1};
-        HIP_TRY(launch_gemm_tn(e, st));
-        HIP_TRY(launch_colsum(w.dZ2, 4 * H, T * N, 4 * H, grads->lstm2_b, st));
         TnArgs f{w.emb, w.encidx, E, w.dZ1, 4 * H, grads->lstm1_W, 4 * H, Tv * B, E, 4 * H, 1};
         HIP_TRY(launch_gemm_tn(f, st));
         TnArgs g{w.H1, nullptr, H, w.dZ1, 4 * H, grads->lstm1_W + (size_t)E * 4 * H, 4 * H, T * B, H, 4 * H, 1};
@@ -297,6 +334,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         HIP_TRY(launch_gemm_tn(h, st));
         HIP_TRY(launch_colsum(w.dX1, E, Tv * B, E, grads->encode_image_b, st));
     }
+    if (sd != st) HIP_TRY(fork_to(sd, st, ss.ev[2]));        // join: the caller's stream waits for the side stream's gradients
     return S2VT_OK;
 }
 
