@@ -19,12 +19,12 @@ struct CfgEntry {
     int BM, CG, NT, lds_bytes;
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, int NBUF = 2>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, int NBUF = 2, int BKT = 32>
 constexpr CfgEntry make_entry(const char* name)
 {
-    using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true, NBUF>;
-    return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true, NBUF>, gemm_kernel<WM, WN, TM, TN, NG, EPI, false, NBUF>,
-                    C::BM, C::CG, C::NT, C::LDS_FLOATS * 4};
+    using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true, NBUF, BKT>;
+    return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true, NBUF, BKT>,
+                    gemm_kernel<WM, WN, TM, TN, NG, EPI, false, NBUF, BKT>, C::BM, C::CG, C::NT, C::LDS_FLOATS * 4};
 }
 
 // name = BMxBN(wavesMxwavesN)
@@ -51,7 +51,9 @@ const CfgEntry kLstm[] = {
     make_entry<1, 4, 5, 1, 4, EPI_LSTM_GW>("gw80x16u(1x4)"),
     make_entry<2, 4, 3, 1, 4, EPI_LSTM_GW>("gw96x16u(2x4)"),
     make_entry<2, 4, 3, 1, 4, EPI_LSTM_GW, 3>("gw96x16u(2x4)p3"),
+    make_entry<1, 4, 1, 1, 4, EPI_LSTM_GW, 2, 64>("gw16x16u(1x4)k64"),
 };
+constexpr int kLstmGw16k64 = 10;     // 64-deep chunks for the M <= 64 step: 8 MFMAs per wave per 32-deep chunk leave the barrier dominant
 constexpr int kLstmGwFirst = 3;      // index of gw16x16u; the gw entries follow in order of rows
 const CfgEntry kPick[] = {
     make_entry<4, 1, 1, 4, 1, EPI_PICK>("64x64(4x1)"),
@@ -117,7 +119,8 @@ int choose_lstm(int M)
 {
     const int rows = ceil_div(ceil_div(M, 4), 16) * 16;       // 16, 32, ... rows per workgroup
     const int step = rows / 16;                                // 1..6 -> gw16 .. gw96
-    return kLstmGwFirst + (step < 1 ? 0 : (step > 6 ? 5 : step - 1));
+    if (step <= 1) return kLstmGw16k64;
+    return kLstmGwFirst + (step > 6 ? 5 : step - 1);
 }
 
 std::once_flag g_attr_once;

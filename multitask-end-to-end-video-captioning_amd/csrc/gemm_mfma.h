@@ -108,8 +108,12 @@ __device__ __forceinline__ const float* uniform(const float* p)
     return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
 }
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2, int BKT = 32>
 struct GemmCfg {
+    // K-chunk depth of this configuration (k per barrier): 32 by default; 64 / 128 for the tiles whose chunk holds few
+    // MFMAs per wave (M = 64 step kernels: 8 per chunk at 32), where the per-chunk barrier and waits dominate
+    static constexpr int BK = BKT;
+    static constexpr int SA = BKT + 2;                        // A rows BK + 2 floats apart: bank = 2*row + k
     static constexpr int NT = 64 * WM * WN;
     static constexpr int BM = WM * TM * 16;
     static constexpr int BN = WN * TN * 16;
@@ -154,10 +158,11 @@ struct GemmCfg {
     static_assert(!GW || (WN == 4 && NG == 4), "gate-per-wave needs four waves along N");
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2, int BKT = 32>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
 {
-    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, NBUF>;
+    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, NBUF, BKT>;
+    constexpr int BK = Cfg::BK, SA = Cfg::SA;                  // (shadow the namespace-scope defaults)
     constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, TNG = Cfg::TNG, CG = Cfg::CG, SB = Cfg::SB;
     constexpr int A4 = Cfg::A4, B4 = Cfg::B4;
     constexpr int PF = Cfg::PF;
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         }
     };
     using K0 = std::integral_constant<int, 0>;
-    using KH = std::integral_constant<int, S2VT_LAND_AT>;
+    using KH = std::integral_constant<int, S2VT_LAND_AT * (BK / 32)>;
     using K8 = std::integral_constant<int, BK / 4>;
 
     if constexpr (NBUF == 3) {
