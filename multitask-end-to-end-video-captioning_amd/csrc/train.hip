@@ -73,7 +73,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     return c.off;
 }
 
-// A second stream for the backward pass: the recurrences (25 dependent steps of small kernels, ~half the
+// An optional second stream for the backward pass: the recurrences (25 dependent steps of small kernels, ~half the
 // matrix pipes idle) run on the caller's stream while weight-gradient contractions that do not depend on them
 // run here, forked / joined with events so the call keeps its stream semantics.  Created once per process.
 struct SideStream {
@@ -85,8 +85,11 @@ SideStream& side_stream()
 {
     static SideStream ss = [] {
         SideStream t;
-        const char* off = getenv("S2VT_NO_OVERLAP");          // dev knob: run the backward on one stream
-        if (off && off[0] == '1') return t;
+        // Opt-in (S2VT_OVERLAP=1).  Measured on MI355X: the two streams do run concurrently, but the kernels
+        // only slow each other down (TN 724 -> 1462 us, slab GEMM 28 -> 46 us per launch) for a net 0.1 ms of
+        // 15.6, and per-launch durations stop meaning anything for the roofline, so one stream is the default.
+        const char* on = getenv("S2VT_OVERLAP");
+        if (!(on && on[0] == '1')) return t;
         if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return t;
         for (auto& e : t.ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return t;

@@ -8,10 +8,10 @@ src, dst = sys.argv[1], sys.argv[2]
 
 
 def prof_key(kname):
-    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (\d+)>", kname)
+    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)>", kname)
     if m:
-        WM, WN, TM, TN, NG, EPI, _, NBUF = [int(x) if x.isdigit() else x for x in m.groups()]
-        p3 = "p3" if NBUF == 3 else ""
+        WM, WN, TM, TN, NG, EPI, _, NBUF, BKT = [int(x) if x.isdigit() else x for x in m.groups()]
+        p3 = ("p3" if NBUF == 3 else "") + (f"k{BKT}" if BKT != 32 else "")
         if EPI == 3:
             return f"1:gw{WM * TM * 16}x{TN * 16}u({WM}x{WN}){p3}"
         if EPI == 1:
