@@ -251,7 +251,7 @@ class Video_Caption_Generator:
         B = video.shape[0]
         N = caption.shape[0]
         vid, sid = self._row_ids(B, rep, video_base)
-        seed = self.dropout_seed + 104729 * self.global_step
+        seed = self.dropout_seed + 104729 * self.global_step + 7 * getattr(self, "global_step_dropout_offset", 0)
         state = None
         if reuse_sampler_state:
             ls = ops.sample.last_state
@@ -265,16 +265,17 @@ class Video_Caption_Generator:
         self._ctx = (video, N, logits, ws, keep, seed, vid, sid)
         return nll, lp
 
-    def backward(self):
-        """BPTT into the flat gradient bucket.  Data parallel: the vocab-projection gradients (a third of the
+    def backward(self, accumulate=False, overlap=True):
+        """BPTT into the flat gradient bucket (accumulate=True: on top of what a previous pass left there).  Data parallel: the vocab-projection gradients (a third of the
         bucket) are final after phase 1, so their all-reduce is started there and runs over xGMI beside phase 2;
         apply_gradients() reduces the rest and waits for both."""
         video, N, dlogits, ws, keep, seed, vid, sid = self._ctx
         st = self.store
-        st.grad.zero_()
+        if not accumulate:
+            st.grad.zero_()
         self._pending = []
         self._early = None
-        if dp.world_size() > 1:
+        if dp.world_size() > 1 and overlap:
             ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, phase=1)
             lo = st.offsets["embed_word_W"]
             hi = st.offsets["embed_word_b"] + (int(np.prod(st.shapes["embed_word_b"])) + 63) // 64 * 64
@@ -375,6 +376,50 @@ class Video_Caption_Generator:
         self.backward()
         self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value)
         return StepStats(loss_local / msum, self._sumsq.clone(), msum)
+
+    def mixed_update(self, video, sampled, mask, rewards, baseline, gt_caption, gt_mask, lr, lambda_loss=0.5, clip_norm=5.0,
+                     video_base=0, keep=None, q1=True, smoothing=0.05):
+        """The mixed objective of reinforce_multitask_e2e_attribute_s2vt.py:850 (BASELINE configs[3]):
+            sum_loss = -(1 - lambda) * PG / sum(mask_pg)  +  lambda * model_loss
+        with PG the reward-scaled log-likelihood of the SAMPLED captions (build_loss) and model_loss the
+        cross-entropy loss of build_model on the GROUND-TRUTH captions of the same videos (label smoothing, Q1,
+        weight decay), clip 5, Adam.  Two teacher-forced passes accumulate into one gradient bucket, each with its
+        coefficient already divided by its GLOBAL mask sum (one tiny all-reduce first), so the bucket needs no
+        further normalisation."""
+        video = self._dev(video, torch.float32)
+        cap = self._dev(sampled, torch.int32)
+        mask = self._dev(mask, torch.float32)
+        gcap = self._dev(gt_caption, torch.int32)
+        gmask = self._dev(gt_mask, torch.float32)
+        adv = self._dev(rewards, torch.float32) - self._dev(baseline, torch.float32)
+        B = video.shape[0]
+        rep = cap.shape[0] // B
+        keep = self.dropout_rate if keep is None else keep
+        lam = float(lambda_loss)
+        sums = torch.stack([mask.sum(), gmask.sum()])
+        dp.allreduce_small(sums)                                           # global sum(mask) of both passes
+        # ---- pass 1: policy gradient on the sampled captions
+        coef_pg = (mask * (adv * (1.0 - lam))[:, None] / sums[0]).t().contiguous().view(-1)
+        nll, _ = self._forward_loss(video, cap, coef_pg, 0.0, rep, video_base, keep)
+        loss_pg = torch.dot(coef_pg, nll)
+        self.backward(accumulate=False, overlap=False)
+        # ---- pass 2: cross entropy on the ground truth (tf_s2vt.py:150-166 semantics, as xe_update)
+        Ng = gcap.shape[0]
+        if q1:
+            colsum = gmask.sum(0)
+            dp.allreduce_small(colsum)
+            coef_xe = (colsum[:, None] / float(Ng * self.world_size)).expand(-1, Ng) * self.loss_weight
+        else:
+            coef_xe = gmask.t() * self.loss_weight
+        coef_xe = (coef_xe * (lam / sums[1])).contiguous().view(-1)
+        self.global_step_dropout_offset = 1                                # a different dropout stream than pass 1
+        nll2, _ = self._forward_loss(video, gcap, coef_xe, smoothing, 1, video_base, keep)
+        self.global_step_dropout_offset = 0
+        loss_xe = torch.dot(coef_xe, nll2)
+        self.backward(accumulate=True, overlap=False)
+        one = torch.full((), 1.0 / self.world_size, device=self.device)   # the bucket is already normalised: global "sum(mask)" = 1
+        self.apply_gradients(one, lr, clip_norm, weight_decay=lam * self.decay_value)
+        return StepStats(loss_pg + loss_xe, self._sumsq.clone(), sums[0])
 
     def build_model(self):
         """(loss, video, caption, caption_mask, probs) as tf_s2vt.py:90-167.  Fetching `loss`

@@ -169,3 +169,38 @@ def test_sampler_state_reuse_is_equivalent(gpu, oracle):
     assert outs[0][0] == outs[1][0]
     scale = float(outs[0][1].abs().max())
     assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-5 * scale
+
+
+def test_mixed_pg_xe_objective_vs_float64_autograd(gpu, oracle):
+    """reinforce_multitask_e2e_attribute_s2vt.py:850: -(1-lambda)*PG/sum(mask) + lambda*model_loss, two teacher-forced
+    passes (sampled captions, ground truth) into one bucket, vs float64 autograd with the same dropout masks."""
+    import torch
+    import s2vt_amd
+    from s2vt_amd import model as M
+    from oracle import s2vt_torch as T
+    case = CASES[1]
+    d, p, video, cap, vid, sid, N = _setup(oracle, case)
+    B, rep, keep, lam = case["B"], case["rep"], 0.9, 0.5
+    rng = np.random.default_rng(12)
+    mask = s2vt_amd.hostglue.masks_from_ids(cap)
+    r = rng.random(N).astype(np.float32) * 2; b = np.tile(rng.random(B).astype(np.float32) * 2, rep)
+    gcap = rng.integers(0, d.n_words, (B, d.n_caption_lstm_step)).astype(np.int32); gcap[:, -3:] = 0
+    gmask = s2vt_amd.hostglue.masks_from_ids(gcap)
+    mdl = M.Video_Caption_Generator(d.dim_image, d.n_words, d.word_dim, d.lstm_dim, B, 0, d.n_video_lstm_step,
+                                    d.n_caption_lstm_step, dropout_rate=keep)
+    mdl.store.load(p)
+    s1 = mdl.dropout_seed + 104729 * mdl.global_step
+    drop1 = oracle.dropout_masks(s1, vid, sid, keep, d.lstm_dim, d.n_video_lstm_step, d.n_caption_lstm_step)
+    drop2 = oracle.dropout_masks(s1 + 7, vid[:B], sid[:B], keep, d.lstm_dim, d.n_video_lstm_step, d.n_caption_lstm_step)
+    pt = T.to_torch(p, torch.float64, True)
+    lg1 = T.teacher_forced(pt, torch.as_tensor(np.tile(video, (rep, 1, 1))).double(), cap, drop1, keep)
+    lg2 = T.teacher_forced(pt, torch.as_tensor(video).double(), gcap, drop2, keep)
+    ref = (1 - lam) * T.pg_loss(lg1, cap, mask, r, b) + lam * T.xe_loss(pt, lg2, gcap, gmask, q1=True)
+    ref.backward()
+    st = mdl.mixed_update(video, cap, mask, r, b, gcap, gmask, lr=0.0, lambda_loss=lam, video_base=5)
+    wd = sum(0.5 * float((mdl.store.p[n].double() ** 2).sum()) for n in mdl.store.names if n not in M.UNDECAYED)
+    assert abs(float(st.loss) + lam * mdl.decay_value * wd - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    for n in mdl.store.names:
+        g = mdl.store.g[n].cpu().numpy().astype(np.float64)
+        rg = pt[n].grad.numpy()
+        assert np.abs(g - rg).max() <= 2e-4 * (np.abs(rg).max() + 1e-12) + 1e-9, n
