@@ -1,5 +1,5 @@
 """Beam-search generator: build_generator(beam_size, length_normalization_factor) of final_beam_search.py
-:202-294 with the TopN / Caption bookkeeping of beam_search.py:6-80.
+:202-294 (its bookkeeping: the TopN heaps of Caption objects of beam_search.py:6-80).
 
 The reference runs ONE sess.run per live beam per step (B = 1 graphs, states fed back through the host).  Here
 a step advances ALL live beams in one batch on the device: LSTM1 once (its state never depends on a word, so it
@@ -10,8 +10,7 @@ the score of a finished caption is logprob / len**factor, unfinished ones compet
 """
 from __future__ import annotations
 
-import heapq
-import math
+import bisect
 
 import numpy as np
 import torch
@@ -19,42 +18,37 @@ import torch
 from . import ops
 
 
-class Caption:
+class Hypothesis:
+    """A partial caption: token ids so far, the LSTM2 state row it continues from, log-probability, ranking score."""
     __slots__ = ("sentence", "row", "logprob", "score")
 
     def __init__(self, sentence, row, logprob, score):
         self.sentence, self.row, self.logprob, self.score = sentence, row, logprob, score
 
-    def __lt__(self, other):
-        return self.score < other.score
 
-    def __eq__(self, other):
-        return self.score == other.score
+class BestK:
+    """The k best-scoring hypotheses seen so far (what the reference keeps in its TopN heaps, beam_search.py:44-80):
+    a score-sorted list with bisect insertion; on equal scores the earlier arrival ranks higher."""
 
-
-class TopN:
-    """Maintains the top n elements of an incrementally provided set (beam_search.py:44-80)."""
-
-    def __init__(self, n):
-        self._n, self._data = n, []
+    def __init__(self, k):
+        self.k, self._neg, self._items = k, [], []
 
     def size(self):
-        return len(self._data)
+        return len(self._items)
 
-    def push(self, x):
-        if len(self._data) < self._n:
-            heapq.heappush(self._data, x)
-        else:
-            heapq.heappushpop(self._data, x)
+    def push(self, h):
+        i = bisect.bisect_right(self._neg, -h.score)
+        if i >= self.k:
+            return
+        self._neg.insert(i, -h.score)
+        self._items.insert(i, h)
+        del self._neg[self.k:], self._items[self.k:]
 
-    def extract(self, sort=False):
-        data, self._data = self._data, None
-        if sort:
-            data.sort(reverse=True)
-        return data
+    def best_first(self):
+        return list(self._items)
 
-    def reset(self):
-        self._data = []
+    def clear(self):
+        self._neg, self._items = [], []
 
 
 class BeamSearchGenerator:
@@ -94,14 +88,14 @@ class BeamSearchGenerator:
         m, k = self.m, self.beam_size
         video = m._dev(video, torch.float32).view(1, m.n_video_lstm_step, m.dim_image)
         c1, h1, c2, h2 = self._encode(video)
-        captions, final_captions = TopN(k * k), TopN(k)
+        captions, final_captions = BestK(k * k), BestK(k)
         c1, h1, c2, h2, wi, lp = self._step(c1, h1, c2, h2, [1])                       # <bos>
         for b in range(k):
-            captions.push(Caption([int(wi[0, b])], 0, float(lp[0, b]), float(lp[0, b])))
+            captions.push(Hypothesis([int(wi[0, b])], 0, float(lp[0, b]), float(lp[0, b])))
         exclude = 0
         for _ in range(1, m.n_caption_lstm_step):
-            mid = captions.extract(sort=True)[:k]
-            captions.reset()
+            mid = captions.best_first()[:k]
+            captions.clear()
             if not mid:
                 break
             rows = torch.as_tensor([cap.row for cap in mid], dtype=torch.long, device=m.device)
@@ -116,13 +110,13 @@ class BeamSearchGenerator:
                     if w == 0:
                         if self.lnf > 0:
                             score /= len(sentence) ** self.lnf
-                        final_captions.push(Caption(sentence, r, logprob, score))
+                        final_captions.push(Hypothesis(sentence, r, logprob, score))
                         exclude += 1
                     else:
-                        captions.push(Caption(sentence, r, logprob, score))
+                        captions.push(Hypothesis(sentence, r, logprob, score))
             if exclude == k:
                 break
         if not final_captions.size():
             final_captions = captions
-        best = final_captions.extract(sort=True)[0]
+        best = final_captions.best_first()[0]
         return best.sentence, best.logprob, best.score

@@ -233,7 +233,7 @@ class Video_Caption_Generator:
 
         def fn(v):
             if beam_size > 1:                    # final_beam_search.py:226-294 (B = 1, TopN beams)
-                from .beam_search import BeamSearchGenerator
+                from .beam_generator import BeamSearchGenerator
                 sent, _, _ = BeamSearchGenerator(self, beam_size, length_normalization_factor).generate(v)
                 ids = np.zeros(self.n_caption_lstm_step, np.int64)
                 ids[:len(sent)] = sent[:self.n_caption_lstm_step]

@@ -22,7 +22,7 @@ def _sentence_logprob(mdl, video, sent):
 def test_beam_search_generator(gpu):
     import torch
     from s2vt_amd import model as M
-    from s2vt_amd.beam_search import BeamSearchGenerator
+    from s2vt_amd.beam_generator import BeamSearchGenerator
     torch.manual_seed(0)
     mdl = M.Video_Caption_Generator(24, 60, 12, 20, 1, 0, 3, 7, seed=3)
     mdl.store.p["embed_word_b"][0] += 1.0                      # make <eos> reachable so beams finish
