@@ -205,6 +205,13 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                         int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                         const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase, s2vt_stream stream);
 
+/* Gradient w.r.t. the frame features, for the end-to-end scripts where they are the CNN's output
+ * (e2e_tf_s2vt.py:106-121,163-166: the optimizer differentiates through `video` into Inception-ResNet-v2):
+ * d_video[B, Tv, dim_image] = d_emb @ encode_image_W^T, from the d_emb the preceding s2vt_bptt_bwd (phase 0 or 2)
+ * left in `workspace`.  Unnormalised like the weight gradients (scale by 1/sum(mask) as s2vt_grad_finalize does). */
+int s2vt_bptt_dvideo(const s2vt_dims* d, const s2vt_params* p, int32_t B, int32_t N, float* d_video, void* workspace,
+                      size_t workspace_bytes, s2vt_stream stream);
+
 /* dWemb[idx[r], :] += dE[r, :]  -- gradient of tf.nn.embedding_lookup (tf_s2vt.py:128-134). */
 int s2vt_embed_scatter_add(const float* dE, int32_t ld, const int32_t* idx, int32_t R, int32_t E, float* dWemb,
                            s2vt_stream stream);

@@ -29,6 +29,8 @@ struct TrainWs {
     int32_t *prev, *tgt, *encidx;
     float *G1, *C1, *H1, *O1, *G2, *C2, *H2, *O2;
     float *WoutT, *W2T, *W1T, *dO2, *dZ1, *dZ2, *dX2, *dX1, *dH1, *slab, *dc;
+    float* WencT;        // [E, D] transposed frame embedding, only touched by s2vt_bptt_dvideo
+    int32_t* decidx;     // inverse of encidx: row of dX1 (time-major) for row j*Tv + t of d_video
 };
 
 // Split-K plan of the recurrent data-gradient product dz[M,4H] @ Whh^T[4H,H] (order-free): enough K slabs
@@ -69,6 +71,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.dZ1 = c.take<float>(T * b * 4 * H); w.dZ2 = c.take<float>(T * n * 4 * H);
     w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * b * E); w.dH1 = c.take<float>(T * b * H);
     w.slab = c.take<float>((size_t)kMaxSlabs * n * H); w.dc = c.take<float>(n * H);
+    w.WencT = c.take<float>((size_t)d->dim_image * E); w.decidx = c.take<int32_t>(Tv * b);
     if (out) *out = w;
     return c.off;
 }
@@ -338,6 +341,29 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         HIP_TRY(launch_colsum(w.dX1, E, Tv * B, E, grads->encode_image_b, st));
     }
     if (sd != st) HIP_TRY(fork_to(sd, st, ss.ev[2]));        // join: the caller's stream waits for the side stream's gradients
+    return S2VT_OK;
+}
+
+int s2vt_bptt_dvideo(const s2vt_dims* d, const s2vt_params* p, int32_t B, int32_t N, float* d_video, void* workspace,
+                      size_t workspace_bytes, s2vt_stream stream)
+{
+    if (!dims_ok(d) || !p || !p->encode_image_W || !d_video || !workspace || B <= 0 || N <= 0 || N % B) return S2VT_E_BADARG;
+    Carver c(workspace, workspace_bytes);
+    TrainWs w;
+    carve_train(c, d, B, N, &w);
+    if (!c.ok()) return S2VT_E_WORKSPACE;
+    hipStream_t st = S(stream);
+    const int E = d->word_dim, D = d->dim_image, Tv = d->n_video_lstm_step;
+    // d_video[j*Tv + t, :] = dX1[t*B + j, :] @ encode_image_W^T   (dX1 is what s2vt_bptt_bwd left, time-major)
+    hipLaunchKernelGGL(enc_index_kernel, dim3((B * Tv + 255) / 256), dim3(256), 0, st, w.decidx, Tv, B);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_transpose(p->encode_image_W, E, w.WencT, D, D, E, st));
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.seg[0] = make_seg(w.dX1, E, E, 0, 0, w.decidx);
+    a.nseg = 1;
+    a.W = w.WencT; a.ldw = D; a.M = B * Tv; a.N = D; a.C = d_video; a.ldc = D;
+    HIP_TRY(launch_gemm(a, EPI_STORE, -1, st));
     return S2VT_OK;
 }
 

@@ -131,3 +131,48 @@ class CaptionIndex:
 
     def refs_by_video(self):
         return [self.by_video[v] for v in self.video_ids]
+
+
+# ------------------------------------------------------------------------------------------------
+# frame side of the end-to-end scripts (e2e_tf_s2vt.py:376-412,436-447)
+# ------------------------------------------------------------------------------------------------
+def frame_ticks(frame_cnt: int, num_frame_per_video: int):
+    """Which frame numbers (1-based file names %06d.jpg) a video contributes: evenly spaced from frame 1 with
+    step (frame_cnt - 2) // (n - 1); a video too short for that repeats frame 1 (e2e_tf_s2vt.py:391-395)."""
+    step = (frame_cnt - 2) // (num_frame_per_video - 1) if num_frame_per_video > 1 else 0
+    if step > 0:
+        return list(range(1, min(2 + step * (num_frame_per_video - 1), frame_cnt), step))
+    return [1] * num_frame_per_video
+
+
+def get_video_frame_caption_pair(sent_file, frame_path, num_frame_per_video, prefix=""):
+    """(sents [n,2], {video: [frame file, ...]}) -- get_video_feature_caption_pair of the e2e scripts; every video
+    must yield the same number of frames (the reference asserts it)."""
+    import glob
+    import os
+    sents = read_sentences(sent_file)
+    frames = {}
+    for vid in dict.fromkeys(sents[:, 0].tolist()):
+        vdir = os.path.join(frame_path, vid)
+        cnt = len(glob.glob(os.path.join(vdir, prefix + "*")))
+        frames[vid] = [os.path.join(vdir, f"{prefix}{t:06d}.jpg") for t in frame_ticks(cnt, num_frame_per_video)]
+    lengths = {len(v) for v in frames.values()}
+    if len(lengths) > 1:
+        raise ValueError(f"videos yield different frame counts: {sorted(lengths)}")
+    return sents, frames
+
+
+def image_reading_processing(paths, width=299, height=299, out=None):
+    """paths: [B][Tv] image files -> float32 [B, Tv, 3, height, width] in [-1, 1] (RGB, bicubic resize,
+    2 * (x / 255) - 1: e2e_tf_s2vt.py:436-447; channel-first for the torch CNN).  Decoding uses Pillow -- cv2, which the
+    reference uses, is not in this image; the two bicubic kernels differ in the last bits of a pixel."""
+    from PIL import Image
+    B, Tv = len(paths), len(paths[0])
+    if out is None:
+        out = np.empty((B, Tv, 3, height, width), np.float32)
+    for i, row in enumerate(paths):
+        for j, f in enumerate(row):
+            with Image.open(f) as im:
+                a = np.asarray(im.convert("RGB").resize((width, height), Image.BICUBIC), np.float32)
+            out[i, j] = (2.0 * (a / 255.0) - 1.0).transpose(2, 0, 1)
+    return out

@@ -1,0 +1,120 @@
+"""CNN in the loop: the end-to-end scripts (e2e_tf_s2vt.py, reinforcement_e2e.py,
+reinforce_multitask_e2e_attribute_loss.py -- BASELINE configs[4]).
+
+The reference builds Inception-ResNet-v2 into every graph: frames [B, Tv, 299, 299, 3] -> base network with
+is_training=False batch norm -> global average pool -> slim.dropout(keep 0.9; on in build_model / build_loss /
+build_multinomial_sampler, off in build_sampler / build_generator) -> video [B, Tv, 1536] -> the captioner; one Adam
+and one tf.clip_by_global_norm(., 10) span the CNN's and the captioner's variables (e2e_tf_s2vt.py:106-121,533-536;
+reinforcement_e2e.py:958-971).
+
+Here the captioner is the hand-written HIP path (model.Video_Caption_Generator) and the CNN is a torch module on
+MIOpen (irv2.InceptionResnetV2 or any [n, 3, H, W] -> [n, dim_image] module); the seam between them is one tensor
+each way:
+
+    features = cnn(frames) --(detached, dropout applied)--> sample / teacher-forced forward / BPTT      [HIP]
+    d_features = model.video_grad() * 1/sum(mask)   (s2vt_bptt_dvideo)  --> features.backward(d_features) [autograd]
+
+The CNN's parameters and gradients live in two flat fp32 buffers (the modules hold views), so the data-parallel
+all-reduce is one collective, the squared norm one dot product handed to the captioner's apply_gradients() as
+`extra_sumsq` (so both halves are clipped by the SAME global norm), and the update one s2vt_adam_tf launch.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import dist as dp
+from . import ops
+
+
+class EndToEnd:
+    def __init__(self, model, cnn: torch.nn.Module, feature_keep: float | None = None, seed: int = 0):
+        self.model, self.cnn = model, cnn.to(model.device)
+        self.keep = model.dropout_rate if feature_keep is None else feature_keep      # slim.dropout(net, self.dropout_rate, ..)
+        self.seed = seed
+        params = [p for p in self.cnn.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in params)
+        dev = model.device
+        self.theta = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:                                     # parameters and their .grad become views of the flat buffers
+            k = p.numel()
+            self.theta[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.theta[off:off + k].view_as(p)
+            p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+        self.params = params
+        self._gen = torch.Generator(device=dev)
+
+    # ---------------------------------------------------------------- features
+    def extract(self, frames, dropout: bool, track: bool = False):
+        """frames [B, Tv, 3, H, W] fp32 in [-1, 1] -> (video [B, Tv, D] contiguous & detached, autograd handle or None)."""
+        B, Tv = frames.shape[:2]
+        x = frames.to(self.model.device, torch.float32).reshape(B * Tv, *frames.shape[2:])
+        with torch.set_grad_enabled(track):
+            f = self.cnn(x)
+            if dropout and self.keep < 1.0:
+                self._gen.manual_seed(self.seed + 15485863 * (self.model.global_step + 1))
+                keepmask = torch.rand(f.shape, generator=self._gen, device=f.device) < self.keep
+                f = f * keepmask / self.keep
+            f = f.reshape(B, Tv, -1)
+        return f.detach().contiguous(), (f if track else None)
+
+    # ---------------------------------------------------------------- CNN half of the update
+    def _cnn_grads(self, handle, weight_decay, with_attr):
+        def extra(gscale):
+            m = self.model
+            dv = m.video_grad() * gscale                       # d loss / d video, normalised by the GLOBAL sum(mask)
+            if with_attr and getattr(m, "_attr_ctx", None) is not None:
+                dz, ascale = m._attr_ctx                        # attribute head: z = mean_t(video) @ attr_W + b
+                WT = ops.transpose(m.store.p["attr_W"])
+                dmean = ops.gemm([ops.operand(dz)], WT, None, M=dz.shape[0])
+                dv += (dmean * (ascale / dv.shape[1]))[:, None, :]
+            self.grad.zero_()
+            handle.backward(dv)
+            dp.allreduce_small(self.grad)
+            if weight_decay:
+                self.grad.add_(self.theta, alpha=weight_decay)
+            return torch.dot(self.grad, self.grad).reshape(1)
+        return extra
+
+    def _cnn_apply(self, lr, clip_norm):
+        m = self.model
+        ops.adam_tf(self.theta, self.grad, self.m, self.v, m._sumsq, clip_norm, lr, m.global_step)
+
+    # ---------------------------------------------------------------- training steps
+    def xe_step(self, frames, caption, caption_mask, lr, clip_norm=10.0, video_base=0):
+        """One step of train() in e2e_tf_s2vt.py:482-700: label-smoothed XE through the CNN; weight decay on EVERY
+        trainable variable (the always-true predicate at :199)."""
+        video, h = self.extract(frames, dropout=True, track=True)
+        st = self.model.xe_update(video, caption, caption_mask, lr, clip_norm=clip_norm, video_base=video_base,
+                                  extra_sumsq=self._cnn_grads(h, self.model.decay_value, False), decay_all=True)
+        self._cnn_apply(lr, clip_norm)
+        return st
+
+    def reinforce_step(self, frames, reward_fn, lr, K=1, clip_norm=10.0, video_base=0, true_labels=None, sample_seed=0):
+        """One step of train() in reinforcement_e2e.py:1085-1140: sample (feature dropout ON, :399) and greedy
+        (OFF, :466) through the CNN, reward_fn(samples[K*B,Tc], greedy[B,Tc]) -> (r[K*B], b[B]) on the host, then the
+        REINFORCE update through the CNN (dropout ON, :308), clip 10 over all variables, one Adam."""
+        m = self.model
+        video_s, h = self.extract(frames, dropout=True, track=True)
+        samples, _ = m.sample(video_s, K, False, seed=sample_seed, video_base=video_base)
+        video_g, _ = self.extract(frames, dropout=False)
+        _, greedy = m.sample(video_g, 0, True, video_base=video_base)
+        is_eos = samples == 0
+        mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()
+        r, b = reward_fn(samples, greedy)
+        r = torch.as_tensor(r, dtype=torch.float32)
+        b = torch.as_tensor(b, dtype=torch.float32).repeat(K)
+        st = m.reinforce_update(video_s, samples, mask, r, b, lr, clip_norm=clip_norm, video_base=video_base,
+                                true_labels=true_labels, extra_sumsq=self._cnn_grads(h, 0.0, true_labels is not None))
+        self._cnn_apply(lr, clip_norm)
+        st.samples, st.greedy = samples, greedy
+        return st
+
+    def generate(self, frames, video_base=0):
+        """build_generator / build_sampler through the CNN (dropout off): greedy ids [B, Tc]."""
+        video, _ = self.extract(frames, dropout=False)
+        return self.model.sample(video, 0, True, video_base=video_base)[1]

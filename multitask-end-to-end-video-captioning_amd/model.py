@@ -285,11 +285,22 @@ class Video_Caption_Generator:
         else:
             ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid)
 
-    def apply_gradients(self, mask_sum, lr, clip_norm, weight_decay=0.0, attr_scale=None):
+    def video_grad(self):
+        """d(loss * sum(mask)) / d(video) [B, Tv, dim_image] of the pass backward() just ran -- the gradient the
+        end-to-end scripts push into the CNN (e2e_tf_s2vt.py:106-121).  Unnormalised, like the bucket before
+        apply_gradients()."""
+        video, N, _, ws, *_ = self._ctx
+        return ops.bptt_dvideo(self.dims, self.store.params, video.shape[0], N, ws)
+
+    def apply_gradients(self, mask_sum, lr, clip_norm, weight_decay=0.0, attr_scale=None, extra_sumsq=None, decay_all=False):
         """All-reduce (RCCL, one flat bucket + sum(mask) in its tail), 1/sum(mask), weight decay,
         tf.clip_by_global_norm, TF-form Adam (reinforcement_multisampling_tf_s2vt.py:643-652).
         attr_scale: constant normaliser of the attribute-head gradients (their range of the bucket is
-        touched by the multilabel loss only, so it is finalised with its own scale)."""
+        touched by the multilabel loss only, so it is finalised with its own scale).
+        extra_sumsq: callable(gscale) -> device scalar, the squared norm of gradients held OUTSIDE the bucket (the CNN of
+        the end-to-end scripts) that tf.clip_by_global_norm sees in the same list; it is called once 1/sum(mask) is
+        known.  decay_all: the e2e scripts' always-true weight-decay predicate (e2e_tf_s2vt.py:199) -- the LSTM biases
+        are decayed as well."""
         st = self.store
         early = getattr(self, "_early", None)
         if early is not None and dp.world_size() > 1:
@@ -313,12 +324,14 @@ class Video_Caption_Generator:
         if a0 < nd:
             self._ascale.fill_(1.0 if attr_scale is None else float(attr_scale))
             ops.grad_finalize(st.grad[a0:nd], st.theta[a0:nd], self._ascale, weight_decay, self._sumsq)
-        ops.grad_finalize(st.grad[nd:st.numel], st.theta[nd:], self._gscale, 0.0, self._sumsq)
+        ops.grad_finalize(st.grad[nd:st.numel], st.theta[nd:], self._gscale, weight_decay if decay_all else 0.0, self._sumsq)
+        if extra_sumsq is not None:
+            self._sumsq += extra_sumsq(self._gscale)
         self.global_step += 1
         ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, self._sumsq, clip_norm, lr, self.global_step)
 
     def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
-                         true_labels=None, reuse_sampler_state=False):
+                         true_labels=None, reuse_sampler_state=False, extra_sumsq=None):
         """build_loss + the REINFORCE objective and train_op of train()
         (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc],
         rewards / baseline [N], rows sample-major over the B videos.
@@ -346,15 +359,17 @@ class Video_Caption_Generator:
             y = self._dev(true_labels, torch.float32)
             Bg = video.shape[0] * self.world_size
             mean, z, bce = ops.attr_head_fwd(video, self.store.p["attr_W"], self.store.p["attr_b"], y)
-            ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
+            dz = ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
             attr_scale = self.alpha / float(self.label_dim * Bg)
+            self._attr_ctx = (dz, attr_scale)                   # for callers that differentiate through `video` (e2e.py)
             attr_loss = bce.sum() * attr_scale
-        self.apply_gradients(msum, lr, clip_norm, attr_scale=attr_scale)
+        self.apply_gradients(msum, lr, clip_norm, attr_scale=attr_scale, extra_sumsq=extra_sumsq)
         st = StepStats(loss_local / msum, self._sumsq.clone(), msum)
         st.attr_loss = attr_loss
         return st
 
-    def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, q1=True, smoothing=0.05, video_base=0, keep=None):
+    def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, q1=True, smoothing=0.05, video_base=0, keep=None,
+                  extra_sumsq=None, decay_all=False):
         """build_model + train_op of tf_s2vt.py:90-167,445-448 (label smoothing 0.05, Q1 batch-mean
         semantics, weight decay on the non-'bias' variables, clip 10)."""
         video = self._dev(video, torch.float32)
@@ -374,7 +389,7 @@ class Video_Caption_Generator:
         msum = mask.sum()
         loss_local = torch.dot(coef, nll)
         self.backward()
-        self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value)
+        self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value, extra_sumsq=extra_sumsq, decay_all=decay_all)
         return StepStats(loss_local / msum, self._sumsq.clone(), msum)
 
     def mixed_update(self, video, sampled, mask, rewards, baseline, gt_caption, gt_mask, lr, lambda_loss=0.5, clip_norm=5.0,

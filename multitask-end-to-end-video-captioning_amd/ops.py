@@ -199,6 +199,14 @@ def bptt_bwd(dims: Dims, params: Params, grads: Params, video, N: int, dlogits, 
           "s2vt_bptt_bwd")
 
 
+def bptt_dvideo(dims: Dims, params: Params, B: int, N: int, ws):
+    """Gradient w.r.t. the frame features [B, Tv, dim_image] after bptt_bwd on `ws` (end-to-end CNN fine-tuning)."""
+    import torch
+    out = torch.empty(B, dims.n_video_lstm_step, dims.dim_image, device=ws.device, dtype=torch.float32)
+    check(lib().s2vt_bptt_dvideo(C.byref(dims), C.byref(params), B, N, _ptr(out), _ptr(ws), ws.numel(), _stream()), "s2vt_bptt_dvideo")
+    return out
+
+
 def grad_finalize(g, theta, gscale, weight_decay, sumsq):
     _chk_f32(g, theta, gscale, sumsq)
     check(lib().s2vt_grad_finalize(_ptr(g), _ptr(theta), g.numel(), _ptr(gscale), float(weight_decay), _ptr(sumsq), _stream()),

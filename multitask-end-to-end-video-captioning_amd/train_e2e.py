@@ -1,0 +1,93 @@
+"""End-to-end training driver (CNN in the loop): the counterpart of train() in e2e_tf_s2vt.py:482-720.
+
+    python -m s2vt_amd.train_e2e --train-sents S --frames DIR --vocab V [--cnn-npz inception_resnet_v2.npz]
+
+Per step the reference reads B x 5 jpgs, runs sess.run([train_op, tf_loss]) on the Inception-ResNet-v2 + S2VT graph
+(label-smoothed XE, weight decay on every variable, clip 10 on the joint norm, Adam, lr 1e-5 halved every 40000
+steps, batch 16).  Here: data.image_reading_processing -> e2e.EndToEnd.xe_step (torch/MIOpen CNN, HIP captioner).
+The slim checkpoint is read from an .npz dump of its variables (name -> array; TF itself is not in this image).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+
+from . import data, hostglue
+from .train_common import Config, epoch_batches, learning_rate, optimistic_restore, save_checkpoint
+
+
+def e2e_config(**kw):
+    base = dict(start_learning_rate=1e-5, decay_steps=40000, clip_norm=10.0, batch_size=16, n_caption_lstm_step=35,
+                model_name="e2e_s2vt_model")
+    base.update(kw)
+    return Config(**base)
+
+
+def save_cnn(trainer, cfg: Config, epoch: int):
+    os.makedirs(cfg.model_path, exist_ok=True)
+    path = os.path.join(cfg.model_path, f"{cfg.model_name}-cnn-{epoch}.npz")
+    np.savez(path, **{k: v.detach().cpu().numpy() for k, v in trainer.cnn.state_dict().items()})
+    return path
+
+
+def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, width=299, height=299, restore=None,
+          cnn_variables=None, log=print):
+    import torch
+    from . import e2e, irv2, model as M
+    wordtoix, _ = hostglue.preProBuildWordVocab(vocabulary)
+    if model is None:
+        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, cfg.batch_size,
+                                          cfg.n_video_lstm_step + cfg.n_caption_lstm_step, cfg.n_video_lstm_step,
+                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed)
+    if restore:
+        log(f"restored: {optimistic_restore(model, restore)}")
+    if cnn is None:
+        cnn = irv2.InceptionResnetV2()
+        if cnn_variables is not None:
+            log(f"cnn variables restored: {len(cnn.load_slim_checkpoint(cnn_variables))}")
+    trainer = e2e.EndToEnd(model, cnn, seed=cfg.seed)
+    rng = random.Random(cfg.seed)
+    history = []
+    for epoch in range(cfg.n_epochs):
+        losses = []
+        for it, idx in enumerate(epoch_batches(len(sents), cfg.batch_size, rng)):
+            if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
+                break
+            t0 = time.time()
+            vid, sentence = sents[idx, 0], sents[idx, 1].tolist()
+            frames = data.image_reading_processing([video_frames[v] for v in vid], width, height)
+            captions_ind, captions_mask = hostglue.sentence_padding_toix(sentence, wordtoix, cfg.n_caption_lstm_step)
+            st = trainer.xe_step(torch.from_numpy(frames), np.asarray(captions_ind, np.int32), captions_mask,
+                                 lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm)
+            losses.append(float(st.loss))
+            log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
+                f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")
+        entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None,
+                 "checkpoint": save_checkpoint(model, cfg, epoch), "cnn_checkpoint": save_cnn(trainer, cfg, epoch)}
+        history.append(entry)
+        log(f"Epoch {epoch} is done: {entry}")
+    return trainer, history
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train-sents", required=True); ap.add_argument("--frames", required=True)
+    ap.add_argument("--vocab", required=True); ap.add_argument("--cnn-npz"); ap.add_argument("--restore")
+    ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=16)
+    ap.add_argument("--model-path", default="./new_e2e_models")
+    a = ap.parse_args()
+    cfg = e2e_config(n_epochs=a.epochs, batch_size=a.batch_size, model_path=a.model_path)
+    sents, frames = data.get_video_frame_caption_pair(a.train_sents, a.frames, cfg.n_video_lstm_step)
+    variables = None
+    if a.cnn_npz:
+        with np.load(a.cnn_npz) as z:
+            variables = {k: z[k] for k in z.files}
+    train(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, cnn_variables=variables)
+
+
+if __name__ == "__main__":
+    main()

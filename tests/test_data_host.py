@@ -56,3 +56,32 @@ def test_caption_index(tmp_path):
     assert sents.shape == (3, 2) and sents[2, 0] == "vid1"
     ix = data.CaptionIndex(sents)
     assert ix.get_captions("vid1") == ["a man is cooking", "someone cooks food"] and ix.video_ids == ["vid1", "vid2"]
+
+
+def test_frame_ticks_and_image_pipeline(tmp_path):
+    """Frame sampling rule and image preprocessing of the end-to-end scripts (e2e_tf_s2vt.py:388-398,436-447)."""
+    from PIL import Image
+    import s2vt_amd
+    from s2vt_amd import data
+    assert data.frame_ticks(30, 5) == [1, 8, 15, 22, 29]                 # step (30-2)//4 = 7
+    assert data.frame_ticks(6, 5) == [1, 2, 3, 4, 5]
+    assert data.frame_ticks(5, 5) == [1] * 5                             # too short: step 0 -> frame 1 repeated
+    assert data.frame_ticks(11, 5) == [1, 3, 5, 7, 9]
+    rng = np.random.default_rng(0)
+    sent = tmp_path / "s.txt"
+    with open(sent, "w") as f:
+        for v, n in (("vidA", 12), ("vidB", 7)):
+            os.makedirs(tmp_path / "frames" / v)
+            for k in range(1, n + 1):
+                Image.fromarray(rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)).save(tmp_path / "frames" / v / f"{k:06d}.jpg")
+            f.write(f"{v}\ta man is walking\n{v}\ta person walks\n")
+    sents, frames = data.get_video_frame_caption_pair(str(sent), str(tmp_path / "frames"), 3)
+    assert sents.shape == (4, 2) and list(frames) == ["vidA", "vidB"]
+    assert [os.path.basename(p) for p in frames["vidA"]] == ["000001.jpg", "000006.jpg", "000011.jpg"]
+    assert [os.path.basename(p) for p in frames["vidB"]] == ["000001.jpg", "000003.jpg", "000005.jpg"]
+    x = data.image_reading_processing([frames["vidA"], frames["vidB"]], width=16, height=12)
+    assert x.shape == (2, 3, 3, 12, 16) and x.dtype == np.float32 and -1.0 <= x.min() and x.max() <= 1.0
+    # a solid-colour image survives decode + resize: 2 * (v / 255) - 1 per channel, RGB order
+    Image.new("RGB", (40, 40), (255, 0, 128)).save(tmp_path / "solid.png")
+    y = data.image_reading_processing([[str(tmp_path / "solid.png")]], 8, 8)[0, 0]
+    assert np.allclose(y[0], 1.0) and np.allclose(y[1], -1.0) and np.allclose(y[2], 2 * 128 / 255 - 1, atol=1e-6)

@@ -48,3 +48,37 @@ def test_xe_then_rl_drivers(tmp_path):
     # restored variables came from the XE checkpoint under the reference's TF names
     with np.load(hist[-1]["checkpoint"]) as z:
         assert "s2vt/LSTM1/basic_lstm_cell/weights" in z.files and "Wemb" in z.files
+
+
+def test_e2e_driver_frames_to_checkpoint(tmp_path):
+    """train_e2e.train on a synthetic frame corpus (jpg files in the reference's directory layout) with a small
+    stand-in CNN: frames -> CNN -> HIP captioner -> joint update; the loss falls, both checkpoints are written."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from PIL import Image
+    import s2vt_amd
+    from s2vt_amd import data, train_e2e
+    rng = np.random.default_rng(1)
+    vocab = ["<en_unk>", "a", "red", "green", "blue", "square", "is", "shown"]
+    colours = {"red": (220, 30, 30), "green": (30, 220, 30), "blue": (30, 30, 220)}
+    sent = tmp_path / "sents.txt"
+    with open(sent, "w") as f:
+        for v in range(9):
+            name = list(colours)[v % 3]
+            os.makedirs(tmp_path / "frames" / f"vid{v}")
+            for k in range(1, 9):
+                img = np.clip(np.asarray(colours[name])[None, None, :] + rng.integers(-20, 20, (24, 24, 3)), 0, 255).astype(np.uint8)
+                Image.fromarray(img).save(tmp_path / "frames" / f"vid{v}" / f"{k:06d}.jpg")
+            f.write(f"vid{v}\ta {name} square is shown\nvid{v}\ta {name} square\n")
+    cfg = train_e2e.e2e_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=8,
+                               batch_size=6, start_learning_rate=2e-2, model_path=str(tmp_path / "m"))
+    sents, frames = data.get_video_frame_caption_pair(str(sent), str(tmp_path / "frames"), 3)
+    torch.manual_seed(0)
+    cnn = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, stride=2), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
+                              torch.nn.Linear(8, 24), torch.nn.ReLU())
+    trainer, hist = train_e2e.train(cfg, sents, frames, vocab, cnn=cnn, width=24, height=24, log=lambda *_: None)
+    assert hist[-1]["loss"] < 0.8 * hist[0]["loss"]
+    assert os.path.exists(hist[-1]["checkpoint"]) and os.path.exists(hist[-1]["cnn_checkpoint"])
+    g = trainer.generate(torch.from_numpy(data.image_reading_processing([frames["vid0"], frames["vid1"]], 24, 24)))
+    assert g.shape == (2, 8)
