@@ -86,6 +86,17 @@ bool can_vec(const GemmArgs& a)
         if (!aligned16(sg.ptr) || (sg.ld & 3) || (sg.k & 3)) return false;
     }
     if (a.splits > 1 && (a.kper & 3)) return false;
+    // the vector path addresses every operand by 32-bit byte offsets from its base (raw-buffer loads, 2 GiB window);
+    // gathered segments (rowidx / rowkey) must fit that window too -- their extent is the caller's table
+    size_t krows = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const ASeg& sg = a.seg[s];
+        if (sg.kw + sg.k > (int)krows) krows = (size_t)(sg.kw + sg.k);
+        if (!sg.ptr || sg.k <= 0 || sg.rowidx || sg.rowkey) continue;
+        const size_t rows = sg.rowmod > 0 ? (size_t)sg.rowmod : (size_t)a.M;
+        if (rows * sg.ld * 4 >= (1ull << 31)) return false;
+    }
+    if (krows * a.ldw * 4 >= (1ull << 31)) return false;
     return true;
 }
 
@@ -261,3 +272,15 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
 }
 
 }  // namespace s2vt
+
+#ifdef S2VT_STAMP
+// dev build only: read and reset the per-segment clock sums of gemm_kernel (tools/stamp_loop.py)
+extern "C" int s2vt_stamp_read(unsigned long long* out16)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(s2vt::s2vt_stamp_acc), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(s2vt::s2vt_stamp_acc), z, sizeof(z)) == hipSuccess ? 0 : -4;
+}
+#endif
+

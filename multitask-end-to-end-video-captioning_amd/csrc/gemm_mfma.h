@@ -89,6 +89,34 @@ __device__ __forceinline__ void gload16(f32x4& d, const float* p)
 {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
 }
+// Raw-buffer form of the ring load: address = descriptor base + per-lane byte offset + wave-uniform byte offset, and
+// a lane whose offset is >= the descriptor's num_records gets ZEROS back without touching memory -- so a chunk
+// element out of range (row >= M, k beyond the segment, column >= N) costs a compare + select of the OFFSET (or
+// nothing at all, when the condition is loop-invariant) instead of a 64-bit address computation and select.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOob = 0x80000000u;                       // = num_records of every descriptor built here
+__device__ __forceinline__ i32x4 make_rsrc(const float* base)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(base);
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(u >> 32) & 0xffffu));   // stride 0, no swizzle
+    r[2] = (int)kOob;                                                             // num_records (bytes)
+    r[3] = 0x00020000;                                                            // gfx9 raw buffer, 32-bit elements
+    return r;
+}
+__device__ __forceinline__ void bload16(f32x4& d, uint32_t voff, i32x4 rsrc, uint32_t soff)
+{
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {
@@ -107,6 +135,22 @@ __device__ __forceinline__ const float* uniform(const float* p)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
     return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
 }
+
+#ifdef S2VT_STAMP
+// Dev build only (tools/stamp_loop.py): per-segment shader-clock sums of the main loop, one s_memtime per boundary.
+static __device__ unsigned long long s2vt_stamp_acc[16];
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define S2VT_STAMP_AT(i) do { const unsigned long long t_ = stamp_now(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define S2VT_STAMP_AT(i)
+#endif
 
 template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2, int BKT = 32>
 struct GemmCfg {
@@ -167,6 +211,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     constexpr int A4 = Cfg::A4, B4 = Cfg::B4;
     constexpr int PF = Cfg::PF;
 
+#ifdef S2VT_STAMP
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = stamp_now();
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [NBUF][BM][SA]
     float* Bs = smem + NBUF * BM * SA;      // [NBUF][BK][SB]
@@ -531,6 +579,167 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             drain_ring();
         }
     } else
+    if constexpr (VEC) {
+      if (nchunks > 0) {
+        // ---- interleaved loop.  One wave per SIMD is the normal occupancy of the step kernels, so whatever is issued
+        // between two barriers but not BETWEEN two MFMAs runs with the matrix pipe idle (s_memtime stamps of the
+        // sequential form: load issue 600 + LDS stores 290 of 2600 clocks per chunk, gw80 tile).  Here the side
+        // work of a chunk is cut into A4+B4 pieces and spliced after fixed MFMAs of the chunk's list (each
+        // 16x16x4 fp32 MFMA leaves ~24 issue clocks free): first half = the buffer loads of chunk c+PF,
+        // middle = the counted vmcnt wait, second half = LDS stores of chunk c+1; fragments are read one k-step
+        // ahead in source order (an asm statement pins LDS reads, so nothing is left to the scheduler).
+        constexpr int KS = BK / 4, MPK = TM * TN, NM = KS * MPK, HALF = NM / 2;
+        const i32x4 rsW = make_rsrc(g.W);
+        const i32x4 rsA0 = make_rsrc(sp0), rsA1 = make_rsrc(sp1), rsA2 = make_rsrc(sp2);
+        const int akq = (tid % (BK / 4)) * 4;
+        uint32_t avo0[A4], avo1[A4], avo2[A4], bvo[B4];
+        int bkr[B4];
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {
+            avo0[i] = aoff0[i] < 0 ? kOob : (uint32_t)(aoff0[i] + akq) * 4u;
+            avo1[i] = aoff1[i] < 0 ? kOob : (uint32_t)(aoff1[i] + akq) * 4u;
+            avo2[i] = aoff2[i] < 0 ? kOob : (uint32_t)(aoff2[i] + akq) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < B4; ++i) {
+            const int idx = tid + i * NT;
+            const int kr = idx / (BN / 4);
+            const int col = (idx % (BN / 4)) * 4;
+            const int grp = col / CG, cc = n0 + col % CG;
+            const bool ok = (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4)) && cc < g.N;
+            bvo[i] = ok ? (uint32_t)(kr * g.ldw + grp * g.gstride + cc) * 4u : kOob;
+            bkr[i] = kr;
+        }
+        // The walk of the NEXT chunk to issue, kept as loop-carried scalars: segment index, k offset inside it and the
+        // derived byte offsets advance by BK per chunk; only a segment change (rare, wave-uniform branch) re-selects
+        // the descriptor and the per-lane row offsets.  Past the end of the walk krem_ = 0: every lane is out of
+        // range and the ring loads return zeros without touching memory.
+        // (macros at kernel scope on plain locals, not lambdas: see S2VT_ISSUE)
+        int wseg_ = -1, koff_ = 0, krem_ = 0;
+        i32x4 rsA_ = rsA0;
+        uint32_t soffA_ = 0u, soffW_ = 0u;
+        uint32_t avo_[A4];
+#pragma unroll
+        for (int i = 0; i < A4; ++i) avo_[i] = kOob;
+#define S2VT_WALK_ENTER()                                                                                \
+        do {                                                                                             \
+            ++wseg_;                                                                                     \
+            while (wseg_ < 3 && (wseg_ == 0 ? nch0 : (wseg_ == 1 ? nch1 : nch2)) == 0) ++wseg_;          \
+            koff_ = 0;                                                                                   \
+            if (wseg_ < 3) {                                                                             \
+                rsA_ = wseg_ == 0 ? rsA0 : (wseg_ == 1 ? rsA1 : rsA2);                                   \
+                krem_ = wseg_ == 0 ? slen0 : (wseg_ == 1 ? slen1 : slen2);                               \
+                const int kw_ = (wseg_ == 0 ? skw0 : (wseg_ == 1 ? skw1 : skw2)) + kbeg;                 \
+                soffA_ = 0u;                                                                             \
+                soffW_ = (uint32_t)kw_ * (uint32_t)g.ldw * 4u;                                           \
+                _Pragma("unroll") for (int i_ = 0; i_ < A4; ++i_)                                        \
+                    avo_[i_] = wseg_ == 0 ? avo0[i_] : (wseg_ == 1 ? avo1[i_] : avo2[i_]);               \
+            } else {                                                                                     \
+                krem_ = 0;                                                                               \
+            }                                                                                            \
+        } while (0)
+        // after the pieces of one chunk have been issued
+#define S2VT_WALK_NEXT()                                                                                 \
+        do {                                                                                             \
+            krem_ -= BK;                                                                                 \
+            soffA_ += (uint32_t)BK * 4u;                                                                 \
+            soffW_ += (uint32_t)BK * (uint32_t)g.ldw * 4u;                                               \
+            if (krem_ <= 0 && wseg_ < 3) S2VT_WALK_ENTER();                                              \
+        } while (0)
+#define S2VT_PIECE_ISSUE(P, SLOT)                                                                        \
+        do {                                                                                             \
+            if constexpr ((P) < A4) {                                                                    \
+                bload16(ra[SLOT][(P) < A4 ? (P) : 0], akq < krem_ ? avo_[(P) < A4 ? (P) : 0] : kOob, rsA_, soffA_); \
+            } else {                                                                                     \
+                constexpr int i_ = (P) - A4 < B4 ? (P) - A4 : 0;                                         \
+                bload16(rb[SLOT][i_], bkr[i_] < krem_ ? bvo[i_] : kOob, rsW, soffW_);                    \
+            }                                                                                            \
+        } while (0)
+        auto land_piece = [&](int buf, auto p_, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
+            constexpr int P = decltype(p_)::value;
+            if constexpr (P < A4) {
+                pin(qa[P]);
+                const f32x4 v = qa[P];
+                const int idx = tid + P * NT;
+                if (A4 * NT == BM * (BK / 4) || idx < BM * (BK / 4)) {
+                    float* d = As + buf * BM * SA + (idx / (BK / 4)) * SA + (idx % (BK / 4)) * 4;
+                    *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
+                    *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
+                }
+            } else {
+                constexpr int i = P - A4;
+                pin(qb[i]);
+                const f32x4 v = qb[i];
+                const int idx = tid + i * NT;
+                if (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4))
+                    *reinterpret_cast<f32x4*>(Bs + buf * BK * SB + (idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4) = v;
+            }
+        };
+        // MFMA after which piece p of each half is spliced
+        auto splice = [](int p) constexpr { return ((2 * p + 1) * HALF) / (2 * LPC); };
+
+        {   // prologue: chunk 0 -> LDS[0]; chunks 1 .. PF-1 in flight in ring slots 1 .. PF-1
+            S2VT_WALK_ENTER();
+            static_for<0, LPC>([&](auto p_) { constexpr int p = decltype(p_)::value; S2VT_PIECE_ISSUE(p, 0); });
+            S2VT_WALK_NEXT();
+            wait_vmcnt<0>();
+            land(0, ra[0], rb[0], 0u, 0u);
+#pragma unroll
+            for (int j = 1; j < PF; ++j) {
+                static_for<0, LPC>([&](auto p_) { constexpr int p = decltype(p_)::value; S2VT_PIECE_ISSUE(p, j); });
+                S2VT_WALK_NEXT();
+            }
+            __syncthreads();
+        }
+        S2VT_STAMP_AT(0);
+        int c = 0;
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                if (more) {
+                    const int buf = c & 1;
+                    const float* a = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
+                    const float* b = Bs + buf * BK * SB + lq * SB + l15;
+                    float av[2][TM], bv[2][TN];
+                    auto read_frag = [&](auto ks_, float (&qa)[TM], float (&qb)[TN]) __attribute__((always_inline)) {
+                        constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) qa[i] = a[i * 16 * SA + ks * 4];
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj)
+                            qb[jj] = b[ks * 4 * SB + (Cfg::GW ? wn * CG + jj * 16 : (jj / TNG) * CG + (wn * TNG + jj % TNG) * 16)];
+                    };
+                    read_frag(std::integral_constant<int, 0>{}, av[0], bv[0]);
+                    static_for<0, NM>([&](auto n_) {
+                        constexpr int n = decltype(n_)::value, ks = n / MPK, r = n % MPK, i = r / TN, jj = r % TN;
+                        if constexpr (r == 0 && ks + 1 < KS) {
+                            read_frag(std::integral_constant<int, ks + 1>{}, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);     // hipcc otherwise sinks these reads to their first use
+                        }
+                        if constexpr (n == HALF) wait_vmcnt<WAITN>();
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][i], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+                        static_for<0, LPC>([&](auto p_) {
+                            constexpr int p = decltype(p_)::value;
+                            if constexpr (splice(p) == n) S2VT_PIECE_ISSUE(p, j);
+                            if constexpr (HALF + splice(p) == n)
+                                land_piece((c + 1) & 1, p_, ra[(j + 1) % PF], rb[(j + 1) % PF]);
+                        });
+                    });
+                    S2VT_WALK_NEXT();
+                    __syncthreads();
+                    ++c;
+                    more = c < nchunks;
+                }
+            }
+        }
+        drain_ring();
+        S2VT_STAMP_AT(7);
+#undef S2VT_WALK_ENTER
+#undef S2VT_WALK_NEXT
+#undef S2VT_PIECE_ISSUE
+      }
+    } else
     if (nchunks > 0) {
         // prologue: chunk 0 -> LDS[0]; chunks 1 .. PF-1 in flight in ring slots 1 .. PF-1
         S2VT_ISSUE(0, 0);
@@ -539,6 +748,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
 #pragma unroll
         for (int j = 1; j < PF; ++j) S2VT_ISSUE(j, j);
         __syncthreads();
+        S2VT_STAMP_AT(0);
 
         // Steady state: iteration c has LDS[c&1] = chunk c and ring slot (c+i)%PF = chunk c+i in flight
         // (i = 1..PF-1).  It issues chunk c+PF into the slot chunk c came from, computes the first
@@ -554,20 +764,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             for (int j = 0; j < PF; ++j) {
                 if (more) {
                     S2VT_ISSUE(c + PF, j);
+                    S2VT_STAMP_AT(1);
                     compute(c & 1, K0{}, KH{});
+                    S2VT_STAMP_AT(2);
                     if constexpr (VEC) wait_vmcnt<WAITN>();
+                    S2VT_STAMP_AT(3);
                     land((c + 1) & 1, ra[(j + 1) % PF], rb[(j + 1) % PF], pa[(j + 1) % PF], pb[(j + 1) % PF]);
+                    S2VT_STAMP_AT(4);
                     compute(c & 1, KH{}, K8{});
+                    S2VT_STAMP_AT(5);
 #ifdef S2VT_ABLATE
                     if (!(g.dbg & 8))
 #endif
                     __syncthreads();
+                    S2VT_STAMP_AT(6);
                     ++c;
                     more = c < nchunks;
                 }
             }
         }
         drain_ring();
+        S2VT_STAMP_AT(7);
     }
 
 #undef S2VT_ISSUE
@@ -746,7 +963,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             }
         }
     }
-
+#ifdef S2VT_STAMP
+    S2VT_STAMP_AT(8);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicAdd(&s2vt_stamp_acc[i], st_acc[i]);
+        atomicAdd(&s2vt_stamp_acc[9], 1ull);
+        atomicAdd(&s2vt_stamp_acc[10], (unsigned long long)nchunks);
+    }
+#endif
 }
 
 }  // namespace s2vt

@@ -10,7 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "gemm_mfma.h"      // gload16 / wait_vmcnt / pin / s2vt_zero16: the asm-issued load ring
+#include "gemm_mfma.h"      // bload16 / make_rsrc / wait_vmcnt / pin / static_for: the asm-issued load ring
 
 namespace s2vt {
 
@@ -136,6 +136,128 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
         }
     };
 
+    if constexpr (VEC) {
+      if (nchunks > 0) {
+        // ---- interleaved loop (same structure as gemm_kernel's, see there): the chunk's side work is cut into A4+B4
+        // pieces spliced after fixed MFMAs -- first half the raw-buffer loads of chunk c+PF (out-of-range lanes get
+        // zeros from the bounds check, the per-lane offsets are loop-invariant unless A is gathered), then the
+        // counted vmcnt wait, second half the LDS stores of chunk c+1; fragments are read one k-step ahead.
+        constexpr int KS = BR / 4, MPK = TM * TN, NM = KS * MPK, HALF = NM / 2;
+        const i32x4 rsA = make_rsrc(g.A), rsB = make_rsrc(g.B);
+        uint32_t avo[A4], bvo[B4];
+        int ar[A4], br[B4];
+#pragma unroll
+        for (int i = 0; i < A4; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / (BMo / 4), k = k0 + (idx % (BMo / 4)) * 4;
+            const bool ok = (A4 * NT == BR * (BMo / 4) || idx < BR * (BMo / 4)) && k < g.Kout;
+            ar[i] = ok ? r : (1 << 30);                                  // a row no split ever reaches
+            avo[i] = g.rowidx ? (uint32_t)k * 4u : (uint32_t)(r * g.lda + k) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < B4; ++i) {
+            const int idx = tid + i * NT;
+            const int r = idx / (BNo / 4), n = n0 + (idx % (BNo / 4)) * 4;
+            const bool ok = (B4 * NT == BR * (BNo / 4) || idx < BR * (BNo / 4)) && n < g.N;
+            br[i] = ok ? r : (1 << 30);
+            bvo[i] = (uint32_t)(r * g.ldb + n) * 4u;
+        }
+        int mrem = mend - mbeg;                                          // rows left from the next chunk to issue
+        int mnext = mbeg;
+        uint32_t soffA = g.rowidx ? 0u : (uint32_t)mbeg * (uint32_t)g.lda * 4u, soffB = (uint32_t)mbeg * (uint32_t)g.ldb * 4u;
+        auto issue_piece = [&](auto p_, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
+            constexpr int P = decltype(p_)::value;
+            if constexpr (P < A4) {
+                uint32_t vo = avo[P];
+                if (g.rowidx) {                                          // gathered rows (frame-embedding gradient): index load per chunk
+                    const bool in = ar[P] < mrem;
+                    vo += (uint32_t)(in ? g.rowidx[mnext + ar[P]] : 0) * (uint32_t)g.lda * 4u;
+                }
+                bload16(qa[P], ar[P] < mrem ? vo : kOob, rsA, soffA);
+            } else {
+                constexpr int i = P - A4;
+                bload16(qb[i], br[i] < mrem ? bvo[i] : kOob, rsB, soffB);
+            }
+        };
+        auto walk_next = [&]() __attribute__((always_inline)) {
+            mrem -= BR;
+            mnext += BR;
+            if (!g.rowidx) soffA += (uint32_t)BR * (uint32_t)g.lda * 4u;
+            soffB += (uint32_t)BR * (uint32_t)g.ldb * 4u;
+        };
+        auto land_piece = [&](int buf, auto p_, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
+            constexpr int P = decltype(p_)::value;
+            if constexpr (P < A4) {
+                pin(qa[P]);
+                const int idx = tid + P * NT;
+                if (A4 * NT == BR * (BMo / 4) || idx < BR * (BMo / 4))
+                    *reinterpret_cast<f32x4*>(As + buf * BR * SAo + (idx / (BMo / 4)) * SAo + (idx % (BMo / 4)) * 4) = qa[P];
+            } else {
+                constexpr int i = P - A4;
+                pin(qb[i]);
+                const int idx = tid + i * NT;
+                if (B4 * NT == BR * (BNo / 4) || idx < BR * (BNo / 4))
+                    *reinterpret_cast<f32x4*>(Bs + buf * BR * SBo + (idx / (BNo / 4)) * SBo + (idx % (BNo / 4)) * 4) = qb[i];
+            }
+        };
+        auto splice = [](int p) constexpr { return ((2 * p + 1) * HALF) / (2 * LPC); };
+
+        static_for<0, LPC>([&](auto p_) { issue_piece(p_, ra[0], rb[0]); });
+        walk_next();
+        wait_vmcnt<0>();
+        land(0, ra[0], rb[0]);
+        static_for<0, LPC>([&](auto p_) { issue_piece(p_, ra[1], rb[1]); });
+        walk_next();
+        __syncthreads();
+        int c = 0;
+        bool more = true;
+        while (more) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                if (more) {
+                    const int buf = c & 1;
+                    const float* a = As + buf * BR * SAo + lq * SAo + (wm * TM) * 16 + l15;
+                    const float* b = Bs + buf * BR * SBo + lq * SBo + (wn * TN) * 16 + l15;
+                    float av[2][TM], bv[2][TN];
+                    auto read_frag = [&](auto ks_, float (&qa)[TM], float (&qb)[TN]) __attribute__((always_inline)) {
+                        constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) qa[i] = a[ks * 4 * SAo + i * 16];
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj) qb[jj] = b[ks * 4 * SBo + jj * 16];
+                    };
+                    read_frag(std::integral_constant<int, 0>{}, av[0], bv[0]);
+                    static_for<0, NM>([&](auto n_) {
+                        constexpr int n = decltype(n_)::value, ks = n / MPK, r = n % MPK, i = r / TN, jj = r % TN;
+                        if constexpr (r == 0 && ks + 1 < KS) {
+                            read_frag(std::integral_constant<int, ks + 1>{}, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (n == HALF) wait_vmcnt<WAITN>();
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][i], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+                        static_for<0, LPC>([&](auto p_) {
+                            constexpr int p = decltype(p_)::value;
+                            if constexpr (splice(p) == n) issue_piece(p_, ra[j], rb[j]);
+                            if constexpr (HALF + splice(p) == n) land_piece((c + 1) & 1, p_, ra[(j + 1) % PF], rb[(j + 1) % PF]);
+                        });
+                    });
+                    walk_next();
+                    __syncthreads();
+                    ++c;
+                    more = c < nchunks;
+                }
+            }
+        }
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+#pragma unroll
+            for (int i = 0; i < A4; ++i) pin(ra[j][i]);
+#pragma unroll
+            for (int i = 0; i < B4; ++i) pin(rb[j][i]);
+        }
+      }
+    } else
     if (nchunks > 0) {
         // prologue: chunk 0 -> LDS[0]; chunk 1 in flight in slot 1.  (Chunks beyond the split load zeros.)
         issue(0, ra[0], rb[0]);
