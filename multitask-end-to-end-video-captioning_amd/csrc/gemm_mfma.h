@@ -29,7 +29,6 @@ namespace s2vt {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
-constexpr int SA = BK + 2;
 
 enum { EPI_STORE = 0, EPI_LSTM = 1, EPI_PICK = 2, EPI_LSTM_GW = 3 };
 
@@ -60,7 +59,6 @@ struct GemmArgs {
     int ldc;
     int act;             // 0 none, 1 tanh
     int xcd_map;         // 1: XCD-aware tile order (set by the launcher for skinny-M shapes)
-    int dbg;             // S2VT_ABLATE builds only: timing ablation bits (1 no MFMA, 2 no LDS stores, 4 no global loads, 8 no barrier, 16 no fragment reads)
     int splits;          // >1: order-free split-K over blockIdx.y (backward data path only, nseg == 1)
     int kper;            //     K range per split (multiple of BK)
     size_t slab_stride;  //     floats between the partial-sum slabs of consecutive splits
@@ -82,13 +80,9 @@ struct GemmArgs {
     float* logits_out;          // optional [M, ldc]
 };
 
-// ---- loads the compiler does not schedule (cdna_hip_programming.md §5.7): hipcc sinks ordinary prefetch
-// loads next to their first use and drains them with vmcnt(0); issued as asm they stay where they are
-// written, and the ring is drained with a hand-counted s_waitcnt below.
-__device__ __forceinline__ void gload16(f32x4& d, const float* p)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory");
-}
+// ---- loads the compiler does not schedule (cdna_hip_programming.md §5.7): hipcc sinks ordinary prefetch loads next
+// to their first use and drains them with vmcnt(0); issued as asm they stay where they are written, and the ring is
+// drained with a hand-counted s_waitcnt.
 // Raw-buffer form of the ring load: address = descriptor base + per-lane byte offset + wave-uniform byte offset, and
 // a lane whose offset is >= the descriptor's num_records gets ZEROS back without touching memory -- so a chunk
 // element out of range (row >= M, k beyond the segment, column >= N) costs a compare + select of the OFFSET (or
@@ -123,9 +117,6 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
-// 16 zero bytes in device memory: an out-of-range lane of a ring load reads THESE instead of a clamped
-// in-range address, so its chunk element arrives as zeros and needs no select when it lands in LDS
-static __device__ const float s2vt_zero16[4] __attribute__((aligned(16), used)) = {0.f, 0.f, 0.f, 0.f};
 // a wave-uniform value as an opaque SGPR value (v_readfirstlane): the optimizer cannot look through it
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ const float* uniform(const float* p)
@@ -152,15 +143,26 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define S2VT_STAMP_AT(i)
 #endif
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2, int BKT = 32>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0>
 struct GemmCfg {
-    // K-chunk depth of this configuration (k per barrier): 32 by default; 64 / 128 for the tiles whose chunk holds few
+    // K-chunk depth of this configuration (k per barrier): 32 by default; 64 for the tiles whose chunk holds few
     // MFMAs per wave (M = 64 step kernels: 8 per chunk at 32), where the per-chunk barrier and waits dominate
     static constexpr int BK = BKT;
-    static constexpr int SA = BKT + 2;                        // A rows BK + 2 floats apart: bank = 2*row + k
-    static constexpr int NT = 64 * WM * WN;
+    static constexpr int KQ = BKT / 4;                        // k-steps (MFMAs along k) per chunk
+    // PW > 0: PW extra LOADER waves per workgroup (loads + LDS stores only) beside the WM*WN MFMA waves (fragment reads
+    // + MFMAs only); PW == 0: every wave does both, interleaved.
+    static constexpr int NTC = 64 * WM * WN;                  // MFMA threads
+    static constexpr int NTL = PW > 0 ? 64 * PW : NTC;        // loader threads
+    static constexpr int NT = NTC + 64 * PW;                  // workgroup size
     static constexpr int BM = WM * TM * 16;
     static constexpr int BN = WN * TN * 16;
+    // A image: four planes (one per k % 4) of BM rows of KQ floats, 16-byte groups XOR-swizzled by row (see the
+    // kernel); B image: [BK][SB]
+    static constexpr int RS = KQ;
+    static constexpr int NG4 = KQ / 4;                        // 16-byte groups per plane row (2 or 4)
+    static constexpr int SWZ_SHIFT = NG4 == 2 ? 3 : 2;        // rows that share a bank group differ in bit(s) >= this
+    static constexpr int PL = BM * RS;
+    static constexpr int ABUF = 4 * PL;
     // EPI_LSTM_GW ("gate per wave"): the four waves along N each take ONE gate column group of the same
     // TN*16 hidden units (WN == 4 == NG), so a workgroup is BM rows x TN*16 units and the grid can be cut
     // to ~one workgroup per CU for any M; the gates of a unit meet through LDS in the epilogue.
@@ -169,59 +171,45 @@ struct GemmCfg {
     static constexpr int CG = GW ? TN * 16 : WN * TNG * 16;  // tile columns per group
     static constexpr int ZS = 4 * CG + 4;                    // GW gate-exchange image: floats per row
     static constexpr int SB = (BN % 32 == 16) ? BN : BN + 16;
-    static constexpr int A4 = (BM * (BK / 4) + NT - 1) / NT;   // float4 per thread per chunk
-    static constexpr int B4 = (BK * (BN / 4) + NT - 1) / NT;
-    static constexpr int LOOP_FLOATS = NBUF * (BM * SA + BK * SB);
+    static constexpr int A4 = (BM * KQ + NTL - 1) / NTL;       // float4 per loader thread per chunk
+    static constexpr int B4 = (BK * (BN / 4) + NTL - 1) / NTL;
+    static constexpr int LOOP_FLOATS = 2 * (ABUF + BK * SB);
     static constexpr int LDS_FLOATS = (GW && BM * ZS > LOOP_FLOATS) ? BM * ZS : LOOP_FLOATS;
-    // Prefetch ring depth (chunks in flight per thread).  The skinny-M kernels are bound by operand bytes in
-    // flight per CU: a chunk of a small tile is computed in ~0.2 us while a load takes ~2 us under load, so the
-    // ring must hold ~10 chunks to cover it (measured: 16x16u tile, 4 chunks in flight: the loads cost 30 of
-    // 71 us).  Small tiles have the registers for that (few accumulators); big tiles run two workgroups per CU
-    // and keep the shallow ring.
-#ifndef S2VT_LAND_AT
-#define S2VT_LAND_AT 4   /* k-steps of a chunk computed before the next chunk is landed in LDS (8 = after all) */
-#endif
+    // Prefetch ring depth (chunks in flight per thread), from a register budget: small tiles (few accumulators) get a
+    // deeper ring, big tiles run two workgroups per CU and keep two chunks.
 #ifndef S2VT_PF_BUDGET
 #define S2VT_PF_BUDGET 48
 #endif
-#ifndef S2VT_PF_BUDGET_SKINNY
-#define S2VT_PF_BUDGET_SKINNY 48
-#endif
-#ifndef S2VT_PF_MAX_SKINNY
-#define S2VT_PF_MAX_SKINNY 6
-#endif
-    static constexpr bool SKINNY = TM * TN <= 6;
-    static constexpr int PF_RAW = (SKINNY ? S2VT_PF_BUDGET_SKINNY : S2VT_PF_BUDGET) / (4 * (A4 + B4));
-    static constexpr int PF_CAP = SKINNY ? S2VT_PF_MAX_SKINNY : 6;
-    static constexpr int PF2 = PF_RAW < 2 ? 2 : (PF_RAW > PF_CAP ? PF_CAP : PF_RAW);
-    // NBUF == 3 (fragment-pipelined loop): the ring depth is even so that the fragment register set of a
-    // chunk (chunk & 1) is a compile-time index inside the loop unrolled by PF
-    static constexpr int PF = NBUF == 3 ? (PF2 & ~1) : PF2;
-    static_assert(NBUF == 2 || NBUF == 3, "two or three LDS stages");
+    static constexpr int PF_RAW = (PW > 0 ? 2 : 1) * S2VT_PF_BUDGET / (4 * (A4 + B4));   // loader waves hold no accumulators
+    static constexpr int PF = PF_RAW < 2 ? 2 : (PF_RAW > 6 ? 6 : PF_RAW);
+    static_assert(NG4 == 2 || NG4 == 4, "A planes: two or four b128 groups per row");
     static_assert(GW || TN % NG == 0, "TN must split evenly over the column groups");
     static_assert(!GW || (WN == 4 && NG == 4), "gate-per-wave needs four waves along N");
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int NBUF = 2, int BKT = 32>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0>
+__global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArgs g)
 {
-    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, NBUF, BKT>;
-    constexpr int BK = Cfg::BK, SA = Cfg::SA;                  // (shadow the namespace-scope defaults)
-    constexpr int NT = Cfg::NT, BM = Cfg::BM, BN = Cfg::BN, TNG = Cfg::TNG, CG = Cfg::CG, SB = Cfg::SB;
+    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, BKT, PW>;
+    constexpr int BK = Cfg::BK, KQ = Cfg::KQ, RS = Cfg::RS, PL = Cfg::PL, ABUF = Cfg::ABUF;   // (BK shadows the namespace-scope default)
+    constexpr int NG4 = Cfg::NG4, SWZ_SHIFT = Cfg::SWZ_SHIFT;
+    constexpr int NT = Cfg::NT, NTL = Cfg::NTL, NCW = WM * WN, BM = Cfg::BM, BN = Cfg::BN, TNG = Cfg::TNG, CG = Cfg::CG, SB = Cfg::SB;
     constexpr int A4 = Cfg::A4, B4 = Cfg::B4;
     constexpr int PF = Cfg::PF;
 
 #ifdef S2VT_STAMP
-    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = stamp_now();
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [NBUF][BM][SA]
-    float* Bs = smem + NBUF * BM * SA;      // [NBUF][BK][SB]
+    float* As = smem;                       // [2][4][BM][RS]
+    float* Bs = smem + 2 * ABUF;            // [2][BK][SB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool mma_wave = PW == 0 || wave < NCW;          // this wave owns accumulators
+    const int ltid = PW > 0 ? tid - Cfg::NTC : tid;       // index among the loader threads (negative: not a loader)
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lq = lane >> 4;
 
@@ -264,7 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g.cinit) {
+            if (g.cinit && mma_wave) {
                 const int cu = Cfg::GW ? n0 + j * 16 + l15 : n0 + (wn * TNG + j % TNG) * 16 + l15;   // column within its group
                 const int col = (Cfg::GW ? wn : j / TNG) * g.gstride + cu;
                 const bool cok = cu < g.N;
@@ -282,15 +270,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
 
     // per-thread staging ring: PF chunks in flight between HBM/L2 and the LDS double buffer
     f32x4 ra[PF][A4], rb[PF][B4];
-    unsigned pa[PF], pb[PF];       // validity bits of the ring slots (zero-fill happens when a chunk lands)
     constexpr int LPC = A4 + B4;                                   // asm-issued loads per chunk per thread
     constexpr int WAITN = ((PF - 1) * LPC > 63) ? 63 : (PF - 1) * LPC;
 
-    // ---- wave-uniform description of the K walk: chunk c -> (segment, offset) by scalar arithmetic
+    // ---- wave-uniform description of the K walk: up to three A segments, each a whole number of chunks
     const int kbeg = g.splits > 1 ? (int)blockIdx.y * g.kper : 0;
-    // The three segment descriptors as named scalars: a run-time index into the by-value argument struct
-    // makes hipcc copy the struct to scratch, and scratch loads share vmcnt with the ring (measured: every
-    // chunk then drains the whole prefetch ring, 2.2 us per chunk).
     auto seg_len = [&](const float* ptr, int sk, int i) __attribute__((always_inline)) {
         int k = 0;
         if (i < g.nseg && ptr != nullptr) {
@@ -300,8 +284,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         }
         return k;
     };
-    // (uniform() makes each field an opaque SGPR value: left alone, hipcc turns "sidx == 0 ? seg[0].f : ..."
-    // into a load through a selected ADDRESS, which forces the by-value argument struct into scratch)
+    // The three segment descriptors as named scalars: a run-time index into the by-value argument struct makes hipcc
+    // copy the struct to scratch, and scratch loads share vmcnt with the ring (measured: every chunk then drains the
+    // whole prefetch ring, 2.2 us per chunk).  uniform() makes each field an opaque SGPR value: left alone, hipcc turns
+    // "s == 0 ? seg[0].f : ..." into a load through a selected ADDRESS, with the same effect.  For the same reason
+    // every run-time selection between the per-segment locals below is written at KERNEL scope (macros), never
+    // inside a lambda: between by-reference captures it becomes a load at a run-time offset into the closure.
     const float* const sp0 = uniform(g.seg[0].ptr);
     const float* const sp1 = uniform(g.seg[1].ptr);
     const float* const sp2 = uniform(g.seg[2].ptr);
@@ -309,7 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     const int slen0 = uniform(seg_len(sp0, g.seg[0].k, 0)), slen1 = uniform(seg_len(sp1, g.seg[1].k, 1)),
               slen2 = uniform(seg_len(sp2, g.seg[2].k, 2));
     const int nch0 = (slen0 + BK - 1) / BK, nch1 = (slen1 + BK - 1) / BK, nch2 = (slen2 + BK - 1) / BK;
-    const int cum0 = nch0, cum1 = nch0 + nch1, nchunks = nch0 + nch1 + nch2;
+    const int nchunks = nch0 + nch1 + nch2;
 
     // Row offsets of this thread's A slots for every segment, resolved ONCE (gather / broadcast index
     // loads happen here, never inside the pipelined loop).  -1 marks a row beyond M / an absent segment.
@@ -317,10 +305,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     auto row_offsets = [&](int sl, int rowmod, const int* rowidx, const unsigned long long* rowkey, int ld, int (&ao)[A4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
-            const int idx = tid + i * NT;
-            int m = m0 + idx / (BK / 4);
+            const int idx = ltid + i * NTL;
+            int m = m0 + idx / KQ;
             int off = -1;
-            if (sl > 0 && idx < BM * (BK / 4) && m < g.M) {
+            if (sl > 0 && idx >= 0 && idx < BM * KQ && m < g.M) {
                 if (rowmod > 0) m %= rowmod;
                 if (rowidx) m = rowidx[m];
                 if (rowkey) m = (int)(~(uint32_t)rowkey[m]);
@@ -333,265 +321,46 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     row_offsets(slen1, g.seg[1].rowmod, g.seg[1].rowidx, g.seg[1].rowkey, g.seg[1].ld, aoff1);
     row_offsets(slen2, g.seg[2].rowmod, g.seg[2].rowidx, g.seg[2].rowkey, g.seg[2].ld, aoff2);
 
-    // Issue the global loads of chunk c into a ring slot.  UNCONDITIONAL and always safe: an out-of-range
-    // element (row >= M, k beyond the segment, column >= N, chunk beyond the walk) is loaded from
-    // s2vt_zero16 instead, so it lands as zeros.
-    // (The chunk -> segment selection is done by the S2VT_ISSUE macro at KERNEL scope, on plain local values:
-    // inside a lambda the same "sidx == 0 ? a : b" picks between by-reference captures, which hipcc folds
-    // into a load through a run-time offset into the closure object -- the closure, every local it points
-    // to and the argument struct then live in scratch, and scratch loads share vmcnt with the ring.)
-    auto issue_at = [&](int koff, const float* abase, int sk, int kw, const int (&aro)[A4], f32x4 (&qa)[A4], f32x4 (&qb)[B4],
-                        unsigned& ma, unsigned& mb) __attribute__((always_inline)) {
-#ifdef S2VT_ABLATE
-        if (g.dbg & 4) { ma = 0; mb = 0; return; }
-#endif
-        unsigned va = 0, vb = 0;
-#pragma unroll
-        for (int i = 0; i < A4; ++i) {
-            const int idx = tid + i * NT;
-            const int k = koff + (idx % (BK / 4)) * 4;
-            const int ro = aro[i];
-            if constexpr (VEC) {
-                const bool ok = ro >= 0 && k < sk;
-                gload16(qa[i], ok ? abase + (ro + k) : s2vt_zero16);
-            } else {   // odd shapes (tests): ordinary compiler-scheduled loads, zero-filled right here
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = ro >= 0 && k + e < sk;
-                    const float x = abase[ok ? ro + k + e : 0];
-                    v[e] = ok ? x : 0.f;
-                }
-                qa[i] = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B4; ++i) {
-            const int idx = tid + i * NT;
-            const int kr = idx / (BN / 4);
-            const int col = (idx % (BN / 4)) * 4;
-            const int grp = col / CG, cc = n0 + col % CG;
-            const int k = koff + kr;
-            const bool kok = (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4)) && k < sk;
-            const float* wrow = g.W + (size_t)(kw + (kok ? k : 0)) * g.ldw + grp * g.gstride;
-            if constexpr (VEC) {
-                const bool ok = kok && cc < g.N;
-                gload16(qb[i], ok ? wrow + cc : s2vt_zero16);
-            } else {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = kok && cc + e < g.N;
-                    const float x = wrow[ok ? cc + e : 0];
-                    v[e] = ok ? x : 0.f;
-                }
-                qb[i] = v;
-            }
-        }
-        ma = va;
-        mb = vb;
+    // ---- LDS images.  A is stored as four PLANES, one per lq = k % 4: As[stage][lq][row][k / 4].  The MFMA lane
+    // (l15, lq) consumes A[row l15][k = 4*ks + lq] at k-step ks, so its operands for FOUR consecutive k-steps are 16
+    // contiguous bytes of plane lq: one ds_read_b128 instead of four ds_read_b32.  ds_read_b128 is serviced in 16-lane
+    // groups that pair the l15 ranges of two lq values ({0-3,12-15} of one with {4-11} of the next): conflict-free iff
+    // the 16 rows hit 16 distinct 4-bank groups whatever lq -- planes are a multiple of 64 dwords apart (BM % 16 == 0)
+    // and, rows being only KQ = 8 (16) floats long, the 16-byte group g of row r is stored at g ^ swz(r), swz = the
+    // row bits that would otherwise alias (r >> 3 & 1 for two groups per row, r >> 2 & 3 for four).  No padding.
+    // B stays [k][n] (rows SB == 16 mod 32 floats: conflict-free ds_read_b32).  A float4 of the ring (4 consecutive k
+    // of one row) lands as one dword in each plane (32 consecutive lanes cover 32 distinct banks).
+    auto a_store = [&](int buf, int idx, const f32x4& v) __attribute__((always_inline)) {
+        const int r = idx / KQ, kq = idx % KQ;
+        float* d = As + buf * ABUF + r * RS + (((kq >> 2) ^ ((r >> SWZ_SHIFT) & (NG4 - 1))) << 2) + (kq & 3);
+        d[0] = v[0];
+        d[PL] = v[1];
+        d[2 * PL] = v[2];
+        d[3 * PL] = v[3];
     };
-#define S2VT_ISSUE(CHUNK, SLOT)                                                                          \
-    do {                                                                                                 \
-        const int c_ = (CHUNK);                                                                          \
-        const int cc_ = c_ < nchunks ? c_ : nchunks - 1;                                                 \
-        const int sidx_ = (cc_ >= cum0 ? 1 : 0) + (cc_ >= cum1 ? 1 : 0);                                 \
-        const int cstart_ = sidx_ == 0 ? 0 : (sidx_ == 1 ? cum0 : cum1);                                 \
-        const float* abase_ = sidx_ == 0 ? sp0 : (sidx_ == 1 ? sp1 : sp2);                               \
-        const int sk_ = sidx_ == 0 ? slen0 : (sidx_ == 1 ? slen1 : slen2);                               \
-        const int kw_ = (sidx_ == 0 ? skw0 : (sidx_ == 1 ? skw1 : skw2)) + kbeg;                         \
-        int aro_[A4];                                                                                    \
-        _Pragma("unroll") for (int i_ = 0; i_ < A4; ++i_)                                                \
-            aro_[i_] = sidx_ == 0 ? aoff0[i_] : (sidx_ == 1 ? aoff1[i_] : aoff2[i_]);                    \
-        issue_at((c_ - cstart_) * BK, abase_, sk_, kw_, aro_, ra[SLOT], rb[SLOT], pa[SLOT], pb[SLOT]);   \
-    } while (0)
-
-    // Land a ring slot in an LDS buffer.  The caller has already waited (hand-counted vmcnt) for this
-    // slot's loads; pin() keeps every consumer below that wait.
-    auto land = [&](int buf, f32x4 (&qa)[A4], f32x4 (&qb)[B4], unsigned ma, unsigned mb) __attribute__((always_inline)) {
-#ifdef S2VT_ABLATE
-        if (g.dbg & 2) return;
-#endif
-        float* a = As + buf * BM * SA;
-        float* b = Bs + buf * BK * SB;
-#pragma unroll
-        for (int i = 0; i < A4; ++i) {
-            if constexpr (VEC) pin(qa[i]);
-            f32x4 v = qa[i];
-            const int idx = tid + i * NT;
-            if (A4 * NT == BM * (BK / 4) || idx < BM * (BK / 4)) {
-                float* d = a + (idx / (BK / 4)) * SA + (idx % (BK / 4)) * 4;
-                *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
-                *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B4; ++i) {
-            if constexpr (VEC) pin(qb[i]);
-            f32x4 v = qb[i];
-            const int idx = tid + i * NT;
-            if (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4)) {
-                float* d = b + (idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4;
-                *reinterpret_cast<f32x4*>(d) = v;
-            }
-        }
+    auto b_store = [&](int buf, int idx, const f32x4& v) __attribute__((always_inline)) {
+        *reinterpret_cast<f32x4*>(Bs + buf * BK * SB + (idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4) = v;
     };
+    // this lane's fragment bases inside a stage
+    const int a_frag = lq * PL + ((wm * TM) * 16 + l15) * RS;
+    const int a_swz = (l15 >> SWZ_SHIFT) & (NG4 - 1);    // swz(row) of every fragment row of this lane (rows differ by multiples of 16)
+    const int b_frag = lq * SB + l15;
+    auto b_col = [&](int j) __attribute__((always_inline)) { return Cfg::GW ? wn * CG + j * 16 : (j / TNG) * CG + (wn * TNG + j % TNG) * 16; };
 
-    // The ring's last PF-1 chunks (beyond the walk, never landed) are still in flight when the loop exits.
-    // Wait for them AND keep every ring register formally alive until after that wait: an asm load's
-    // destination is "written" at the asm statement as far as hipcc knows, so a slot that is never read again
-    // is free at once, and hipcc hands it to epilogue values (pure register code may be scheduled above an
-    // asm volatile) that the late-arriving load data then overwrites -- seen as wrong dwords / wild addresses
-    // whenever the operands were cold in cache.
-    auto drain_ring = [&]() __attribute__((always_inline)) {
-        if constexpr (VEC) {
-            wait_vmcnt<0>();
-#pragma unroll
-            for (int j = 0; j < PF; ++j) {
-#pragma unroll
-                for (int i = 0; i < A4; ++i) pin(ra[j][i]);
-#pragma unroll
-                for (int i = 0; i < B4; ++i) pin(rb[j][i]);
-            }
-        }
-    };
-
-    // MFMAs of k-steps [KS0, KS1) of one chunk (hipcc interleaves the fragment reads with the MFMAs).
-    auto compute = [&](int buf, auto ks0_, auto ks1_) __attribute__((always_inline)) {
-        constexpr int KS0 = decltype(ks0_)::value, KS1 = decltype(ks1_)::value;
-#ifdef S2VT_ABLATE
-        if (g.dbg & 16) {
-#pragma unroll
-            for (int ks = KS0; ks < KS1; ++ks)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, 1.0f, acc[i][j], 0, 0, 0);
-            return;
-        }
-        if (g.dbg & 1) {
-            const float* a_ = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
-            const float* b_ = Bs + buf * BK * SB + lq * SB + l15;
-            float sacc = 0.f;
-#pragma unroll
-            for (int ks = KS0; ks < KS1; ++ks) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) sacc += a_[i * 16 * SA + ks * 4];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) sacc += b_[ks * 4 * SB + j * 16];
-            }
-            acc[0][0][0] += sacc;
-            return;
-        }
-#endif
-        const float* a = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
-        const float* b = Bs + buf * BK * SB + lq * SB + l15;
-#pragma unroll
-        for (int ks = KS0; ks < KS1; ++ks) {
-            float av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * SA + ks * 4];
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bv[j] = b[ks * 4 * SB + (Cfg::GW ? wn * CG + j * 16 : (j / TNG) * CG + (wn * TNG + j % TNG) * 16)];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    using K0 = std::integral_constant<int, 0>;
-    using KH = std::integral_constant<int, S2VT_LAND_AT * (BK / 32)>;
-    using K8 = std::integral_constant<int, BK / 4>;
-
-    if constexpr (NBUF == 3) {
-        // ---- fragment-pipelined loop (skinny-M kernels that run at one or two waves per SIMD): THREE LDS
-        // stages and TWO fragment register sets, so that the MFMAs of chunk c read only registers whose
-        // ds_reads were issued a whole iteration earlier, the ds_reads of chunk c+1 go out in one burst
-        // right after the barrier, and chunk c+2 is stored to LDS under the MFMAs:
-        //   global --(ring, PF chunks)--> registers --> LDS[(c+2)%3] --barrier--> fragments[(c+1)&1] --> MFMA(c)
-        constexpr int KS = BK / 4;
-        float fa[2][KS][TM], fb[2][KS][TN];
-        auto read_frags = [&](int buf, float (&qa)[KS][TM], float (&qb)[KS][TN]) __attribute__((always_inline)) {
-#ifdef S2VT_ABLATE
-            if (g.dbg & 16) return;
-#endif
-            const float* a = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
-            const float* b = Bs + buf * BK * SB + lq * SB + l15;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) qa[ks][i] = a[i * 16 * SA + ks * 4];
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    qb[ks][j] = b[ks * 4 * SB + (Cfg::GW ? wn * CG + j * 16 : (j / TNG) * CG + (wn * TNG + j % TNG) * 16)];
-            }
-        };
-        auto mfma_range = [&](float (&qa)[KS][TM], float (&qb)[KS][TN], auto ks0_, auto ks1_) __attribute__((always_inline)) {
-            constexpr int KS0 = decltype(ks0_)::value, KS1 = decltype(ks1_)::value;
-#ifdef S2VT_ABLATE
-            if (g.dbg & 1) return;
-#endif
-#pragma unroll
-            for (int ks = KS0; ks < KS1; ++ks)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[ks][i], qb[ks][j], acc[i][j], 0, 0, 0);
-        };
-        if (nchunks > 0) {
-            // prologue: chunks 0, 1 -> LDS[0], LDS[1]; chunks 2 .. PF in flight (slot = chunk % PF); fragments of chunk 0
-            S2VT_ISSUE(0, 0);
-            S2VT_ISSUE(1, 1);
-            if constexpr (VEC) wait_vmcnt<0>();
-            land(0, ra[0], rb[0], pa[0], pb[0]);
-            land(1, ra[1], rb[1], pa[1], pb[1]);
-#pragma unroll
-            for (int x = 2; x <= PF; ++x) S2VT_ISSUE(x, x % PF);
-            __syncthreads();
-            read_frags(0, fa[0], fb[0]);
-            int c = 0, b1 = 1, b2 = 2;          // LDS stages of chunks c+1 and c+2
-            bool more = true;
-            while (more) {
-#pragma unroll
-                for (int j = 0; j < PF; ++j) {
-                    if (more) {
-                        read_frags(b1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
-                        S2VT_ISSUE(c + 1 + PF, (j + 1) % PF);
-                        mfma_range(fa[j & 1], fb[j & 1], K0{}, KH{});
-                        if constexpr (VEC) wait_vmcnt<WAITN>();
-                        land(b2, ra[(j + 2) % PF], rb[(j + 2) % PF], pa[(j + 2) % PF], pb[(j + 2) % PF]);
-                        mfma_range(fa[j & 1], fb[j & 1], KH{}, K8{});
-#ifdef S2VT_ABLATE
-                        if (!(g.dbg & 8))
-#endif
-                        __syncthreads();
-                        ++c;
-                        b1 = b2;                                   // stages advance to (c+1)%3, (c+2)%3
-                        b2 = (b2 == 2) ? 0 : b2 + 1;
-                        more = c < nchunks;
-                    }
-                }
-            }
-            drain_ring();
-        }
-    } else
     if constexpr (VEC) {
       if (nchunks > 0) {
         // ---- interleaved loop.  One wave per SIMD is the normal occupancy of the step kernels, so whatever is issued
-        // between two barriers but not BETWEEN two MFMAs runs with the matrix pipe idle (s_memtime stamps of the
-        // sequential form: load issue 600 + LDS stores 290 of 2600 clocks per chunk, gw80 tile).  Here the side
-        // work of a chunk is cut into A4+B4 pieces and spliced after fixed MFMAs of the chunk's list (each
-        // 16x16x4 fp32 MFMA leaves ~24 issue clocks free): first half = the buffer loads of chunk c+PF,
-        // middle = the counted vmcnt wait, second half = LDS stores of chunk c+1; fragments are read one k-step
-        // ahead in source order (an asm statement pins LDS reads, so nothing is left to the scheduler).
-        constexpr int KS = BK / 4, MPK = TM * TN, NM = KS * MPK, HALF = NM / 2;
+        // between two barriers but not BETWEEN two MFMAs runs with the matrix pipe idle (s_memtime stamps of a
+        // sequential issue / compute / land form: load issue 600 + LDS stores 290 of 2600 clocks per chunk, gw80
+        // tile).  Here the side work of a chunk is cut into A4+B4 pieces spliced after fixed MFMAs of the chunk's
+        // list (each 16x16x4 fp32 MFMA leaves ~24 issue clocks free): first half = the raw-buffer loads of chunk
+        // c+PF, middle = the counted vmcnt wait, second half = the LDS stores of chunk c+1 into the stage nobody
+        // reads; fragments are read ahead in source order, fenced by sched_barrier (hipcc otherwise sinks the reads
+        // to their first use) -- A four k-steps ahead (b128), B one.
+        constexpr int NG4 = KQ / 4, MPK = TM * TN, NM = KQ * MPK, HALF = NM / 2;
         const i32x4 rsW = make_rsrc(g.W);
         const i32x4 rsA0 = make_rsrc(sp0), rsA1 = make_rsrc(sp1), rsA2 = make_rsrc(sp2);
-        const int akq = (tid % (BK / 4)) * 4;
+        const int akq = (ltid % KQ) * 4;
         uint32_t avo0[A4], avo1[A4], avo2[A4], bvo[B4];
         int bkr[B4];
 #pragma unroll
@@ -602,20 +371,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         }
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
-            const int idx = tid + i * NT;
+            const int idx = ltid + i * NTL;
             const int kr = idx / (BN / 4);
             const int col = (idx % (BN / 4)) * 4;
             const int grp = col / CG, cc = n0 + col % CG;
-            const bool ok = (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4)) && cc < g.N;
+            const bool ok = (B4 * NTL == BK * (BN / 4) || idx < BK * (BN / 4)) && cc < g.N;
             bvo[i] = ok ? (uint32_t)(kr * g.ldw + grp * g.gstride + cc) * 4u : kOob;
             bkr[i] = kr;
         }
-        // The walk of the NEXT chunk to issue, kept as loop-carried scalars: segment index, k offset inside it and the
-        // derived byte offsets advance by BK per chunk; only a segment change (rare, wave-uniform branch) re-selects
-        // the descriptor and the per-lane row offsets.  Past the end of the walk krem_ = 0: every lane is out of
-        // range and the ring loads return zeros without touching memory.
-        // (macros at kernel scope on plain locals, not lambdas: see S2VT_ISSUE)
-        int wseg_ = -1, koff_ = 0, krem_ = 0;
+        // The walk of the NEXT chunk to issue, as loop-carried scalars: segment, rows of k left in it, byte offsets.
+        // They advance by BK per chunk; only a segment change (rare, wave-uniform branch) re-selects the descriptor
+        // and the per-lane row offsets.  Past the end of the walk krem_ = 0: every lane is out of range and the ring
+        // loads return zeros without touching memory.
+        int wseg_ = -1, krem_ = 0;
         i32x4 rsA_ = rsA0;
         uint32_t soffA_ = 0u, soffW_ = 0u;
         uint32_t avo_[A4];
@@ -625,7 +393,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         do {                                                                                             \
             ++wseg_;                                                                                     \
             while (wseg_ < 3 && (wseg_ == 0 ? nch0 : (wseg_ == 1 ? nch1 : nch2)) == 0) ++wseg_;          \
-            koff_ = 0;                                                                                   \
             if (wseg_ < 3) {                                                                             \
                 rsA_ = wseg_ == 0 ? rsA0 : (wseg_ == 1 ? rsA1 : rsA2);                                   \
                 krem_ = wseg_ == 0 ? slen0 : (wseg_ == 1 ? slen1 : slen2);                               \
@@ -638,8 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
                 krem_ = 0;                                                                               \
             }                                                                                            \
         } while (0)
-        // after the pieces of one chunk have been issued
-#define S2VT_WALK_NEXT()                                                                                 \
+#define S2VT_WALK_NEXT() /* after the pieces of one chunk have been issued */                            \
         do {                                                                                             \
             krem_ -= BK;                                                                                 \
             soffA_ += (uint32_t)BK * 4u;                                                                 \
@@ -659,39 +425,122 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             constexpr int P = decltype(p_)::value;
             if constexpr (P < A4) {
                 pin(qa[P]);
-                const f32x4 v = qa[P];
-                const int idx = tid + P * NT;
-                if (A4 * NT == BM * (BK / 4) || idx < BM * (BK / 4)) {
-                    float* d = As + buf * BM * SA + (idx / (BK / 4)) * SA + (idx % (BK / 4)) * 4;
-                    *reinterpret_cast<float2*>(d) = make_float2(v[0], v[1]);
-                    *reinterpret_cast<float2*>(d + 2) = make_float2(v[2], v[3]);
-                }
+                const int idx = ltid + P * NTL;
+                if (A4 * NTL == BM * KQ || idx < BM * KQ) a_store(buf, idx, qa[P]);
             } else {
                 constexpr int i = P - A4;
                 pin(qb[i]);
-                const f32x4 v = qb[i];
-                const int idx = tid + i * NT;
-                if (B4 * NT == BK * (BN / 4) || idx < BK * (BN / 4))
-                    *reinterpret_cast<f32x4*>(Bs + buf * BK * SB + (idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4) = v;
+                const int idx = ltid + i * NTL;
+                if (B4 * NTL == BK * (BN / 4) || idx < BK * (BN / 4)) b_store(buf, idx, qb[i]);
             }
         };
-        // MFMA after which piece p of each half is spliced
-        auto splice = [](int p) constexpr { return ((2 * p + 1) * HALF) / (2 * LPC); };
+        auto splice = [](int p) constexpr { return ((2 * p + 1) * HALF) / (2 * LPC); };   // MFMA after which piece p of a half goes
 
-        {   // prologue: chunk 0 -> LDS[0]; chunks 1 .. PF-1 in flight in ring slots 1 .. PF-1
+        if constexpr (PW > 0) {
+          // ---- loader / MFMA wave specialisation.  With one MFMA wave per SIMD every buffer load and LDS store the wave
+          // issues itself stalls its MFMA stream for the length of the issue (stamps: ~85 clocks per load, a chunk
+          // half of 20 MFMAs takes 870 instead of 450); here the PW loader waves carry the ring and the LDS stores,
+          // and the MFMA waves issue nothing but fragment reads and MFMAs.  Same protocol as the interleaved loop:
+          // one barrier per chunk, chunk c+1 is stored to the stage nobody reads while chunk c is multiplied.
+          if (!mma_wave) {
+            __builtin_amdgcn_s_setprio(3);     // few, short instructions that everything else waits for: ahead of the MFMA stream
             S2VT_WALK_ENTER();
             static_for<0, LPC>([&](auto p_) { constexpr int p = decltype(p_)::value; S2VT_PIECE_ISSUE(p, 0); });
             S2VT_WALK_NEXT();
             wait_vmcnt<0>();
-            land(0, ra[0], rb[0], 0u, 0u);
+            static_for<0, LPC>([&](auto p_) { land_piece(0, p_, ra[0], rb[0]); });
 #pragma unroll
             for (int j = 1; j < PF; ++j) {
                 static_for<0, LPC>([&](auto p_) { constexpr int p = decltype(p_)::value; S2VT_PIECE_ISSUE(p, j); });
                 S2VT_WALK_NEXT();
             }
             __syncthreads();
+            // Steady state, LDS stores BEFORE the loads: a wave's DS and VMEM instructions leave through one in-order
+            // path, and an LDS store issued right behind five buffer loads sat there ~1000 clocks (stamps) -- behind the
+            // previous iteration's loads, long gone by now, it does not wait.
+            constexpr int WAITL = (PF - 2) * LPC;                  // chunks c+2 .. c+PF-1 may stay in flight
+            int c = 0;
+            bool more = true;
+            while (more) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    if (more) {
+                        wait_vmcnt<WAITL>();
+                        S2VT_STAMP_AT(3);                          // (dev build) loader: ring wait
+                        static_for<0, LPC>([&](auto p_) { land_piece((c + 1) & 1, p_, ra[(j + 1) % PF], rb[(j + 1) % PF]); });
+                        S2VT_STAMP_AT(4);                          // loader: LDS stores
+                        static_for<0, LPC>([&](auto p_) { constexpr int p = decltype(p_)::value; S2VT_PIECE_ISSUE(p, j); });
+                        S2VT_WALK_NEXT();
+                        S2VT_STAMP_AT(2);                          // loader: issue
+                        __syncthreads();
+                        S2VT_STAMP_AT(7);                          // loader: barrier
+                        ++c;
+                        more = c < nchunks;
+                    }
+                }
+            }
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+#pragma unroll
+                for (int i = 0; i < A4; ++i) pin(ra[j][i]);
+#pragma unroll
+                for (int i = 0; i < B4; ++i) pin(rb[j][i]);
+            }
+          } else {
+            __syncthreads();
+            S2VT_STAMP_AT(0);
+            for (int c = 0; c < nchunks; ++c) {
+                const int buf = c & 1;
+                const float* a = As + buf * ABUF + a_frag;
+                const float* b = Bs + buf * BK * SB + b_frag;
+                f32x4 a4[2][TM];
+                float bv[2][TN];
+                auto read_a = [&](auto g4_, f32x4 (&q)[TM]) __attribute__((always_inline)) {
+                    constexpr int g4 = decltype(g4_)::value;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) q[i] = *reinterpret_cast<const f32x4*>(a + i * 16 * RS + ((g4 ^ a_swz) << 2));
+                };
+                auto read_b = [&](auto ks_, float (&q)[TN]) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) q[jj] = b[ks * 4 * SB + b_col(jj)];
+                };
+                read_a(std::integral_constant<int, 0>{}, a4[0]);
+                read_b(std::integral_constant<int, 0>{}, bv[0]);
+                S2VT_STAMP_AT(1);
+                static_for<0, NM>([&](auto n_) {
+                    constexpr int n = decltype(n_)::value, ks = n / MPK, r = n % MPK, i = r / TN, jj = r % TN;
+                    if constexpr (r == 0) {
+                        if constexpr (ks % 4 == 0 && ks / 4 + 1 < NG4)
+                            read_a(std::integral_constant<int, ks / 4 + 1>{}, a4[(ks / 4 + 1) & 1]);
+                        if constexpr (ks + 1 < KQ) read_b(std::integral_constant<int, ks + 1>{}, bv[(ks + 1) & 1]);
+                        if constexpr (ks + 1 < KQ) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+                });
+                S2VT_STAMP_AT(5);
+                __syncthreads();
+                S2VT_STAMP_AT(6);
+            }
+          }
+        } else {
+        // prologue: chunk 0 -> stage 0; chunks 1 .. PF-1 in flight in ring slots 1 .. PF-1
+        S2VT_WALK_ENTER();
+        static_for<0, LPC>([&](auto p_) { constexpr int p = decltype(p_)::value; S2VT_PIECE_ISSUE(p, 0); });
+        S2VT_WALK_NEXT();
+        wait_vmcnt<0>();
+        static_for<0, LPC>([&](auto p_) { land_piece(0, p_, ra[0], rb[0]); });
+#pragma unroll
+        for (int j = 1; j < PF; ++j) {
+            static_for<0, LPC>([&](auto p_) { constexpr int p = decltype(p_)::value; S2VT_PIECE_ISSUE(p, j); });
+            S2VT_WALK_NEXT();
         }
+        __syncthreads();
         S2VT_STAMP_AT(0);
+        // Steady state: iteration c has stage c&1 = chunk c and ring slot (c+i)%PF = chunk c+i in flight (i = 1..PF-1);
+        // it issues chunk c+PF into the slot chunk c came from and lands chunk c+1 in the other stage.  Unrolled by
+        // PF so ring slots are compile-time constants; the only branch is the wave-uniform loop exit.
         int c = 0;
         bool more = true;
         while (more) {
@@ -699,96 +548,154 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
             for (int j = 0; j < PF; ++j) {
                 if (more) {
                     const int buf = c & 1;
-                    const float* a = As + buf * BM * SA + ((wm * TM) * 16 + l15) * SA + lq;
-                    const float* b = Bs + buf * BK * SB + lq * SB + l15;
-                    float av[2][TM], bv[2][TN];
-                    auto read_frag = [&](auto ks_, float (&qa)[TM], float (&qb)[TN]) __attribute__((always_inline)) {
+                    const float* a = As + buf * ABUF + a_frag;
+                    const float* b = Bs + buf * BK * SB + b_frag;
+                    f32x4 a4[2][TM];
+                    float bv[2][TN];
+                    auto read_a = [&](auto g4_, f32x4 (&q)[TM]) __attribute__((always_inline)) {
+                        constexpr int g4 = decltype(g4_)::value;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) q[i] = *reinterpret_cast<const f32x4*>(a + i * 16 * RS + ((g4 ^ a_swz) << 2));
+                    };
+                    auto read_b = [&](auto ks_, float (&q)[TN]) __attribute__((always_inline)) {
                         constexpr int ks = decltype(ks_)::value;
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) qa[i] = a[i * 16 * SA + ks * 4];
-#pragma unroll
-                        for (int jj = 0; jj < TN; ++jj)
-                            qb[jj] = b[ks * 4 * SB + (Cfg::GW ? wn * CG + jj * 16 : (jj / TNG) * CG + (wn * TNG + jj % TNG) * 16)];
+                        for (int jj = 0; jj < TN; ++jj) q[jj] = b[ks * 4 * SB + b_col(jj)];
                     };
-                    read_frag(std::integral_constant<int, 0>{}, av[0], bv[0]);
+                    read_a(std::integral_constant<int, 0>{}, a4[0]);
+                    read_b(std::integral_constant<int, 0>{}, bv[0]);
+                    S2VT_STAMP_AT(1);                              // (dev build) top-of-chunk fragment latency
                     static_for<0, NM>([&](auto n_) {
                         constexpr int n = decltype(n_)::value, ks = n / MPK, r = n % MPK, i = r / TN, jj = r % TN;
-                        if constexpr (r == 0 && ks + 1 < KS) {
-                            read_frag(std::integral_constant<int, ks + 1>{}, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
-                            __builtin_amdgcn_sched_barrier(0);     // hipcc otherwise sinks these reads to their first use
+                        if constexpr (r == 0) {
+                            if constexpr (ks % 4 == 0 && ks / 4 + 1 < NG4)
+                                read_a(std::integral_constant<int, ks / 4 + 1>{}, a4[(ks / 4 + 1) & 1]);
+                            if constexpr (ks + 1 < KQ) read_b(std::integral_constant<int, ks + 1>{}, bv[(ks + 1) & 1]);
+                            if constexpr (ks + 1 < KQ) __builtin_amdgcn_sched_barrier(0);
                         }
-                        if constexpr (n == HALF) wait_vmcnt<WAITN>();
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][i], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+                        if constexpr (n == HALF) {
+                            S2VT_STAMP_AT(2);                      // first half: MFMAs + load issue
+                            wait_vmcnt<WAITN>();
+                            S2VT_STAMP_AT(3);                      // ring wait
+                        }
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
                         static_for<0, LPC>([&](auto p_) {
                             constexpr int p = decltype(p_)::value;
                             if constexpr (splice(p) == n) S2VT_PIECE_ISSUE(p, j);
-                            if constexpr (HALF + splice(p) == n)
-                                land_piece((c + 1) & 1, p_, ra[(j + 1) % PF], rb[(j + 1) % PF]);
+                            if constexpr (HALF + splice(p) == n) land_piece((c + 1) & 1, p_, ra[(j + 1) % PF], rb[(j + 1) % PF]);
                         });
                     });
+                    S2VT_STAMP_AT(5);                              // second half: MFMAs + LDS stores
                     S2VT_WALK_NEXT();
                     __syncthreads();
+                    S2VT_STAMP_AT(6);                              // barrier
                     ++c;
                     more = c < nchunks;
                 }
             }
         }
-        drain_ring();
+        // The ring's last PF-1 chunks (beyond the walk, never landed) are still in flight when the loop exits.  Wait for
+        // them AND keep every ring register formally alive until after that wait: an asm load's destination is
+        // "written" at the asm statement as far as hipcc knows, so a slot that is never read again is free at once,
+        // and hipcc hands it to epilogue values (pure register code may be scheduled above an asm volatile) that the
+        // late-arriving load data then overwrites -- seen as wrong dwords / wild addresses with cold caches.
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+#pragma unroll
+            for (int i = 0; i < A4; ++i) pin(ra[j][i]);
+#pragma unroll
+            for (int i = 0; i < B4; ++i) pin(rb[j][i]);
+        }
         S2VT_STAMP_AT(7);
+        }
 #undef S2VT_WALK_ENTER
 #undef S2VT_WALK_NEXT
 #undef S2VT_PIECE_ISSUE
       }
-    } else
-    if (nchunks > 0) {
-        // prologue: chunk 0 -> LDS[0]; chunks 1 .. PF-1 in flight in ring slots 1 .. PF-1
-        S2VT_ISSUE(0, 0);
-        if constexpr (VEC) wait_vmcnt<0>();
-        land(0, ra[0], rb[0], pa[0], pb[0]);
+    } else {
+        // ---- odd shapes (unaligned pointers / sizes not multiples of 4: tests and tiny problems): the same walk with
+        // ordinary compiler-scheduled scalar loads, zero-filled in registers, one chunk at a time.
+        auto load_chunk = [&](int koff, const float* abase, int sk, int kw, const int (&aro)[A4], f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 1; j < PF; ++j) S2VT_ISSUE(j, j);
-        __syncthreads();
-        S2VT_STAMP_AT(0);
-
-        // Steady state: iteration c has LDS[c&1] = chunk c and ring slot (c+i)%PF = chunk c+i in flight
-        // (i = 1..PF-1).  It issues chunk c+PF into the slot chunk c came from, computes the first
-        // S2VT_LAND_AT k-steps of chunk c, waits until all but the youngest (PF-1) chunks' loads have
-        // returned (vmcnt is in-order), lands chunk c+1 in the OTHER LDS buffer (nobody reads it between
-        // the previous barrier and the next one) so that the LDS stores retire under the remaining MFMAs,
-        // computes the rest, one barrier.  Unrolled by PF so ring slots are compile-time constants; the
-        // only branch is the wave-uniform loop exit.
-        int c = 0;
-        bool more = true;
-        while (more) {
+            for (int i = 0; i < A4; ++i) {
+                const int idx = ltid + i * NTL;
+                const int k = koff + (idx % KQ) * 4;
+                const int ro = aro[i];
+                f32x4 v;
 #pragma unroll
-            for (int j = 0; j < PF; ++j) {
-                if (more) {
-                    S2VT_ISSUE(c + PF, j);
-                    S2VT_STAMP_AT(1);
-                    compute(c & 1, K0{}, KH{});
-                    S2VT_STAMP_AT(2);
-                    if constexpr (VEC) wait_vmcnt<WAITN>();
-                    S2VT_STAMP_AT(3);
-                    land((c + 1) & 1, ra[(j + 1) % PF], rb[(j + 1) % PF], pa[(j + 1) % PF], pb[(j + 1) % PF]);
-                    S2VT_STAMP_AT(4);
-                    compute(c & 1, KH{}, K8{});
-                    S2VT_STAMP_AT(5);
-#ifdef S2VT_ABLATE
-                    if (!(g.dbg & 8))
-#endif
-                    __syncthreads();
-                    S2VT_STAMP_AT(6);
-                    ++c;
-                    more = c < nchunks;
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = ro >= 0 && k + e < sk;
+                    const float x = abase[ok ? ro + k + e : 0];
+                    v[e] = ok ? x : 0.f;
+                }
+                qa[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B4; ++i) {
+                const int idx = ltid + i * NTL;
+                const int kr = idx / (BN / 4);
+                const int col = (idx % (BN / 4)) * 4;
+                const int grp = col / CG, cc = n0 + col % CG;
+                const int k = koff + kr;
+                const bool kok = (B4 * NTL == BK * (BN / 4) || idx < BK * (BN / 4)) && k < sk;
+                const float* wrow = g.W + (size_t)(kw + (kok ? k : 0)) * g.ldw + grp * g.gstride;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = kok && cc + e < g.N;
+                    const float x = wrow[ok ? cc + e : 0];
+                    v[e] = ok ? x : 0.f;
+                }
+                qb[i] = v;
+            }
+        };
+        const int cum0 = nch0, cum1 = nch0 + nch1;
+        for (int c = 0; c < nchunks; ++c) {
+            const int sidx_ = (c >= cum0 ? 1 : 0) + (c >= cum1 ? 1 : 0);
+            const int cstart_ = sidx_ == 0 ? 0 : (sidx_ == 1 ? cum0 : cum1);
+            const float* abase_ = sidx_ == 0 ? sp0 : (sidx_ == 1 ? sp1 : sp2);
+            const int sk_ = sidx_ == 0 ? slen0 : (sidx_ == 1 ? slen1 : slen2);
+            const int kw_ = (sidx_ == 0 ? skw0 : (sidx_ == 1 ? skw1 : skw2)) + kbeg;
+            int aro_[A4];
+#pragma unroll
+            for (int i_ = 0; i_ < A4; ++i_) aro_[i_] = sidx_ == 0 ? aoff0[i_] : (sidx_ == 1 ? aoff1[i_] : aoff2[i_]);
+            if (ltid >= 0) load_chunk((c - cstart_) * BK, abase_, sk_, kw_, aro_, ra[0], rb[0]);
+            __syncthreads();                                       // everyone is done reading the previous chunk
+            if (ltid >= 0) {
+#pragma unroll
+                for (int i = 0; i < A4; ++i) {
+                    const int idx = ltid + i * NTL;
+                    if (A4 * NTL == BM * KQ || idx < BM * KQ) a_store(0, idx, ra[0][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < B4; ++i) {
+                    const int idx = ltid + i * NTL;
+                    if (B4 * NTL == BK * (BN / 4) || idx < BK * (BN / 4)) b_store(0, idx, rb[0][i]);
                 }
             }
+            __syncthreads();
+            const float* a = As + a_frag;
+            const float* b = Bs + b_frag;
+            if (mma_wave)
+#pragma unroll
+            for (int ks = 0; ks < KQ; ++ks) {
+                float av[TM], bw[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * RS + ((((ks >> 2) ^ a_swz) << 2) | (ks & 3))];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bw[j] = b[ks * 4 * SB + b_col(j)];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[j], acc[i][j], 0, 0, 0);
+            }
         }
-        drain_ring();
-        S2VT_STAMP_AT(7);
     }
-
-#undef S2VT_ISSUE
     // ------------------------------------------------------------------ epilogues
+    if constexpr (PW > 0 && EPI != EPI_LSTM_GW) {
+        if (!mma_wave) return;                 // loader waves hold no results (an ended wave no longer counts at barriers)
+    }
     if constexpr (EPI == EPI_STORE) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -860,6 +767,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
         constexpr int ZS = Cfg::ZS;
         const int H = g.N;
         __syncthreads();                       // every wave is done reading the operand buffers
+        if (mma_wave)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -967,9 +875,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g)
     S2VT_STAMP_AT(8);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) atomicAdd(&s2vt_stamp_acc[i], st_acc[i]);
-        atomicAdd(&s2vt_stamp_acc[9], 1ull);
-        atomicAdd(&s2vt_stamp_acc[10], (unsigned long long)nchunks);
+        for (int i = 0; i < 14; ++i) atomicAdd(&s2vt_stamp_acc[i], st_acc[i]);
+        atomicAdd(&s2vt_stamp_acc[14], 1ull);
+        atomicAdd(&s2vt_stamp_acc[15], (unsigned long long)nchunks);
     }
 #endif
 }

@@ -51,9 +51,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Staging ring: PF chunks between global memory and the LDS double buffer.  VEC: loads are inline asm (hipcc
-    // would sink ordinary loads next to their LDS store and drain them with vmcnt(0)), waited for with a
-    // hand-counted vmcnt; out-of-range lanes (rows beyond the split, columns beyond the matrix) read s2vt_zero16.
+    // Staging ring: PF chunks between global memory and the LDS double buffer (vector path: asm-issued raw-buffer
+    // loads with a hand-counted vmcnt, below; this scalar form serves unaligned / odd shapes).
     f32x4 ra[PF][A4], rb[PF][B4];
     auto issue = [&](int c, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
         const int m0 = mbeg + c * BR;
@@ -63,21 +62,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
             const int r = idx / (BMo / 4), cc = (idx % (BMo / 4)) * 4;
             const int m = m0 + r, k = k0 + cc;
             const bool inr = (A4 * NT == BR * (BMo / 4) || idx < BR * (BMo / 4)) && m < mend;
-            if constexpr (VEC) {
-                const bool ok = inr && k < g.Kout;
-                const int src = ok ? (g.rowidx ? g.rowidx[m] : m) : 0;
-                gload16(qa[i], ok ? g.A + (size_t)src * g.lda + k : s2vt_zero16);
-            } else {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (inr) {
-                    const int src = g.rowidx ? g.rowidx[m] : m;
-                    const float* p = g.A + (size_t)src * g.lda + k;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (inr) {
+                const int src = g.rowidx ? g.rowidx[m] : m;
+                const float* p = g.A + (size_t)src * g.lda + k;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (k + e < g.Kout) v[e] = p[e];
-                }
-                qa[i] = v;
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < g.Kout) v[e] = p[e];
             }
+            qa[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
@@ -85,19 +78,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
             const int r = idx / (BNo / 4), cc = (idx % (BNo / 4)) * 4;
             const int m = m0 + r, n = n0 + cc;
             const bool inr = (B4 * NT == BR * (BNo / 4) || idx < BR * (BNo / 4)) && m < mend;
-            if constexpr (VEC) {
-                const bool ok = inr && n < g.N;
-                gload16(qb[i], ok ? g.B + (size_t)m * g.ldb + n : s2vt_zero16);
-            } else {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (inr) {
-                    const float* p = g.B + (size_t)m * g.ldb + n;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (inr) {
+                const float* p = g.B + (size_t)m * g.ldb + n;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < g.N) v[e] = p[e];
-                }
-                qb[i] = v;
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) v[e] = p[e];
             }
+            qb[i] = v;
         }
     };
     auto land = [&](int buf, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
@@ -105,14 +93,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
         float* b = Bs + buf * BR * SBo;
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
-            if constexpr (VEC) pin(qa[i]);
             const int idx = tid + i * NT;
             if (A4 * NT == BR * (BMo / 4) || idx < BR * (BMo / 4))
                 *reinterpret_cast<f32x4*>(a + (idx / (BMo / 4)) * SAo + (idx % (BMo / 4)) * 4) = qa[i];
         }
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
-            if constexpr (VEC) pin(qb[i]);
             const int idx = tid + i * NT;
             if (B4 * NT == BR * (BNo / 4) || idx < BR * (BNo / 4))
                 *reinterpret_cast<f32x4*>(b + (idx / (BNo / 4)) * SBo + (idx % (BNo / 4)) * 4) = qb[i];
@@ -261,7 +247,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
     if (nchunks > 0) {
         // prologue: chunk 0 -> LDS[0]; chunk 1 in flight in slot 1.  (Chunks beyond the split load zeros.)
         issue(0, ra[0], rb[0]);
-        if constexpr (VEC) wait_vmcnt<0>();
         land(0, ra[0], rb[0]);
         issue(1, ra[1], rb[1]);
         __syncthreads();
@@ -273,24 +258,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
                 if (more) {
                     issue(c + PF, ra[j], rb[j]);                  // the slot chunk c came from
                     compute(c & 1, 0, BR / 8);
-                    if constexpr (VEC) wait_vmcnt<WAITN>();       // all but the youngest chunk have returned
                     land((c + 1) & 1, ra[(j + 1) % PF], rb[(j + 1) % PF]);
                     compute(c & 1, BR / 8, BR / 4);
                     __syncthreads();
                     ++c;
                     more = c < nchunks;
                 }
-            }
-        }
-        // loads still in flight belong to chunks beyond the split: wait, and keep their registers alive until then
-        if constexpr (VEC) {
-            wait_vmcnt<0>();
-#pragma unroll
-            for (int j = 0; j < PF; ++j) {
-#pragma unroll
-                for (int i = 0; i < A4; ++i) pin(ra[j][i]);
-#pragma unroll
-                for (int i = 0; i < B4; ++i) pin(rb[j][i]);
             }
         }
     }

@@ -11,7 +11,7 @@ from s2vt_amd import ops, _lib
 lib = _lib.lib()
 lib.s2vt_stamp_read.argtypes = [C.POINTER(C.c_ulonglong)]
 lib.s2vt_stamp_read.restype = C.c_int
-NAMES = ["prologue", "issue", "mfma-1st", "vmcnt-wait", "land", "mfma-2nd", "barrier", "drain", "epilogue"]
+NAMES = ["prologue", "frag0-wait", "half-1(mfma+issue)|ld-issue", "vmcnt-wait", "ld-land", "half-2(mfma+land)", "barrier", "drain|ld-barrier", "epilogue", "land0", "land1", "land2", "land3", "land4+"]
 
 
 def read():
@@ -31,13 +31,13 @@ def report(name, fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     s = read()
-    waves, chunks = s[9], s[10]
-    per_wave = [x / waves for x in s[:9]]
-    tot = sum(per_wave)
+    waves, chunks = s[14], s[15]
+    per_wave = [x / waves for x in s[:14]]
+    tot = sum(per_wave[:9])
     cpw = chunks / waves
     loop = sum(per_wave[1:7])
     print(f"{name}: {us:.1f} us/launch, {waves // reps} waves, {cpw:.1f} chunks/wave, {tot:.0f} clk/wave (loop {loop / cpw:.0f} clk/chunk)")
-    print("   " + "  ".join(f"{n}={v:.0f}" + (f"({v / cpw:.0f}/ch)" if 1 <= i <= 6 else "") for i, (n, v) in enumerate(zip(NAMES, per_wave))), flush=True)
+    print("   " + "  ".join(f"{n}={v:.0f}" + (f"({v / cpw:.0f}/ch)" if 1 <= i <= 7 or i >= 9 else "") for i, (n, v) in enumerate(zip(NAMES, per_wave))), flush=True)
 
 
 dev = "cuda"
