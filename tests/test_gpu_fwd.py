@@ -91,7 +91,7 @@ def test_lstm_cell_bitwise(gpu, oracle, M, E, H):
     for keep, code in ((1.0, 0), (0.9, 258), (0.5, 600)):
         mask = None if keep >= 1 else oracle.dropout_mask(77, vid, sid, code, keep, H)
         rc, rh, rout, rg, _ = oracle.lstm1_step(p, x, c, h, mask, keep, want_gates=True)
-        for cfg in range(-1, 16):
+        for cfg in range(-1, 13):
             gc, gh, gout, gg = gpu.lstm_cell_fwd(gpu.operand(_dev(x)), None, _dev(h), _dev(c), _dev(W), _dev(b), M, keep=keep,
                                                  seed=77, video_id=_dev(vid), sample_id=_dev(sid), drop_code=code,
                                                  want_gates=True, tile_cfg=cfg)
@@ -112,7 +112,7 @@ def test_vocab_pick_bitwise(gpu, oracle, M, H, V):
     vid = rng.integers(0, 500, M).astype(np.int32); sid = rng.integers(-1, 4, M).astype(np.int32)
     logits = oracle.xw_plus_b(o2, W, b)
     ref = oracle.pick_tokens(logits, vid, sid, 5, 2024)
-    for cfg in range(-1, 16):
+    for cfg in range(-1, 13):
         tok, gl, _ = gpu.vocab_pick(_dev(o2), _dev(W), _dev(b), _dev(vid), _dev(sid), 5, 2024, want_logits=True, tile_cfg=cfg)
         assert np.array_equal(gl.cpu().numpy(), logits), cfg
         assert np.array_equal(tok.cpu().numpy(), ref), cfg
@@ -123,7 +123,7 @@ def test_vocab_pick_ties_lowest_index(gpu, oracle):
     o2 = np.zeros((M, H), np.float32); W = np.zeros((H, V), np.float32); b = np.zeros(V, np.float32)
     b[[40, 41, 200, 299]] = 3.0                        # exact ties across lanes, sub-tiles and tiles
     vid = np.zeros(M, np.int32); sid = -np.ones(M, np.int32)
-    for cfg in range(-1, 16):
+    for cfg in range(-1, 13):
         tok, _, _ = gpu.vocab_pick(_dev(o2), _dev(W), _dev(b), _dev(vid), _dev(sid), 0, 1, tile_cfg=cfg)
         assert tok.cpu().numpy().tolist() == [40] * M
 

@@ -32,7 +32,7 @@ for M in (384, 320, 64):
     for name, x0, x1, W in (("LSTM2 K=2500", ops.operand(o1), ops.operand(Wemb, rowidx=idx), W2), ("LSTM1 K=1000", ops.operand(None, k=E), None, W1)):
         flops = 2 * M * (W.shape[0] - (E if x1 is None else 0)) * 4 * H
         res = []
-        for cfg in range(16):
+        for cfg in range(12):
             try:
                 t = timeit(lambda: ops.lstm_cell_fwd(x0, x1, h, c, W, b2, M, tile_cfg=cfg))
             except Exception:
@@ -42,7 +42,7 @@ for M in (384, 320, 64):
 vid = torch.zeros(384, dtype=torch.int32, device=dev); sid = torch.zeros(384, dtype=torch.int32, device=dev)
 o2 = torch.randn(384, H, device=dev)
 res = []
-for cfg in range(16):
+for cfg in range(12):
     try:
         t = timeit(lambda: ops.vocab_pick(o2, Wout, bout, vid, sid, 0, 1, tile_cfg=cfg))
     except Exception:
@@ -54,7 +54,7 @@ t = timeit(lambda: ops.vocab_pick(o2, Wout, bout, vid, sidg, 0, 1)); print(f"PIC
 for (M, K, N, nm) in ((6400, 1000, 12000, "logits"), (6400, 12000, 1000, "dO2"), (8000, 4000, 1500, "dX2"), (320, 4000, 1000, "dh slab (no split)")):
     A = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev)
     res = []
-    for cfg in range(16):
+    for cfg in range(12):
         try:
             t = timeit(lambda: ops.gemm([ops.operand(A)], W, None, M=M, tile_cfg=cfg), n=5)
         except Exception:
