@@ -155,3 +155,21 @@ def test_sampler_token_ids_bit_exact(gpu, oracle, case):
     # a different seed changes the samples but never the greedy caption
     s2, g2 = gpu.sample(dims, gpu.make_params(dp), _dev(video), K, seed=2025, video_base=10)
     assert np.array_equal(g2.cpu().numpy(), ref_g) and not np.array_equal(s2.cpu().numpy(), ref_s)
+
+
+def test_operand_beyond_the_2gib_window_uses_the_scalar_path(gpu, oracle):
+    """The vector path addresses each operand by 32-bit byte offsets (raw-buffer loads, 2 GiB window); an operand whose
+    rows reach further must take the scalar path and still be exact.  Rows 2^28 floats apart: row 2 starts at byte 2^31."""
+    import torch
+    M, K, N, ld = 3, 64, 128, 1 << 28
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((M, K)).astype(np.float32); W = rng.standard_normal((K, N)).astype(np.float32)
+    big = torch.empty(M * ld, dtype=torch.float32, device="cuda")
+    view = big.view(M, ld)[:, :K]
+    view.copy_(torch.as_tensor(A))
+    ref = oracle.gemm_chain(A, W)
+    C = gpu.gemm([gpu.operand(view)], _dev(W), None, M=M).cpu().numpy()
+    assert np.array_equal(C, ref)
+    # the same rows packed densely take the vector path: identical bits
+    C2 = gpu.gemm([gpu.operand(_dev(A))], _dev(W), None, M=M).cpu().numpy()
+    assert np.array_equal(C2, ref)
