@@ -12,10 +12,10 @@
 //   unit live in the same lane because the tile takes the same 16 units from all 4 gate column
 //   groups), PICK (vocab logits + Gumbel-max / argmax -> packed 64-bit atomicMax; the logits never
 //   go to HBM).
-// * Tiling: 64-lane waves, WM x WN waves per workgroup, TM x TN 16x16 accumulators per wave,
-//   BK = 32 K-chunk (one 128-B line per A row), global -> registers -> LDS double buffer, one
-//   barrier per chunk.  LDS images are bank-conflict-free for the ds_read_b32 fragment reads:
-//   A rows are 34 floats apart (bank = 2*row + k), B rows are == 16 (mod 32) floats apart.
+// * Tiling: 64-lane waves, WM x WN MFMA waves per workgroup (+ PW loader waves in the step tiles), TM x TN 16x16
+//   accumulators per wave, BK = 32 (64) K-chunk, asm-issued raw-buffer loads -> register ring -> LDS double buffer,
+//   one barrier per chunk, the loads and LDS stores spliced between the MFMAs.  LDS images: A as four k%4 planes
+//   with a row-XOR swizzle (one conflict-free ds_read_b128 feeds four k-steps), B rows == 16 (mod 32) floats apart.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
