@@ -268,6 +268,46 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
             acc[i][j] = v;
         }
 
+    // Epilogue operands that do not depend on the contraction (bias, noise-stream ids) are loaded HERE, under the first
+    // chunk's latency, instead of as a chain of dependent loads in the epilogue; hipcc sinks any plain load to its
+    // first use unless the value is pinned in a register (below).  (Worth ~1 % of the PICK launch.)
+    float ep_bias[TN];
+    int ep_sid[TM][4], ep_vid[TM][4];
+    if constexpr (EPI == EPI_STORE || EPI == EPI_PICK) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cc = n0 + (wn * TNG + j % TNG) * 16 + l15;
+            const int col = EPI == EPI_PICK ? n0 + (wn * TN + j) * 16 + l15 : (j / TNG) * g.gstride + cc;
+            ep_bias[j] = (g.bias && mma_wave && (EPI == EPI_PICK ? col : cc) < g.N) ? g.bias[col] : 0.0f;
+        }
+    }
+    if constexpr (EPI == EPI_PICK) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wm * TM + i) * 16 + lq * 4 + r;
+                const bool mok = mma_wave && m < g.M;
+                ep_sid[i][r] = mok ? g.sample_id[m] : -1;
+                ep_vid[i][r] = mok ? g.video_id[m] : 0;
+            }
+    }
+    auto pin_epilogue_operands = [&]() __attribute__((always_inline)) {
+        if constexpr (EPI == EPI_STORE || EPI == EPI_PICK) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(ep_bias[j]));
+        }
+        if constexpr (EPI == EPI_PICK) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    asm volatile("" : "+v"(ep_sid[i][r]));
+                    asm volatile("" : "+v"(ep_vid[i][r]));
+                }
+        }
+    };
+
     // per-thread staging ring: PF chunks in flight between HBM/L2 and the LDS double buffer
     f32x4 ra[PF][A4], rb[PF][B4];
     constexpr int LPC = A4 + B4;                                   // asm-issued loads per chunk per thread
@@ -530,6 +570,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
         static_for<0, LPC>([&](auto p_) { constexpr int p = decltype(p_)::value; S2VT_PIECE_ISSUE(p, 0); });
         S2VT_WALK_NEXT();
         wait_vmcnt<0>();
+        pin_epilogue_operands();
         static_for<0, LPC>([&](auto p_) { land_piece(0, p_, ra[0], rb[0]); });
 #pragma unroll
         for (int j = 1; j < PF; ++j) {
@@ -702,7 +743,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
             const int cc = n0 + (wn * TNG + j % TNG) * 16 + l15;
             const int col = (j / TNG) * g.gstride + cc;
             if (cc >= g.N) continue;
-            const float bj = g.bias ? g.bias[col] : 0.0f;
+            const float bj = ep_bias[j];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -816,15 +857,15 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
         // SAME four rows (lq*4 + r): quad lane e draws the Philox block of row r = e, the words are exchanged
         // with DPP (detmath.h).  All 64 lanes take part in every exchange (no divergence around it).
         const uint32_t e4 = (uint32_t)l15 & 3u;
+        S2VT_STAMP_AT(9);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mrow = m0 + (wm * TM + i) * 16 + lq * 4;
             int sid[4], vid[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool mok = mrow + r < g.M;
-                sid[r] = mok ? g.sample_id[mrow + r] : -1;
-                vid[r] = mok ? g.video_id[mrow + r] : 0;
+                sid[r] = ep_sid[i][r];
+                vid[r] = ep_vid[i][r];
             }
             const int sid_own = e4 == 0 ? sid[0] : e4 == 1 ? sid[1] : e4 == 2 ? sid[2] : sid[3];
             const int vid_own = e4 == 0 ? vid[0] : e4 == 1 ? vid[1] : e4 == 2 ? vid[2] : vid[3];
@@ -849,7 +890,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                 for (int r = 0; r < 4; ++r) {
                     const int m = mrow + r;
                     if (m < g.M && col < g.N) {
-                        float v = acc[i][j][r] + g.bias[col];
+                        float v = acc[i][j][r] + ep_bias[j];
                         if (g.logits_out) g.logits_out[(size_t)m * g.ldc + col] = v;
                         if (sid[r] >= 0) v = v + gumbel_from_word(word[r]);
                         v = v + 0.0f;  // -0 -> +0 so that the integer order equals the float order
@@ -857,6 +898,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     }
                 }
             }
+            S2VT_STAMP_AT(10);                     // (dev build) noise + per-lane argmax
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mrow + r;
@@ -869,6 +911,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                 }
                 if (l15 == 0 && m < g.M && key != 0ull) atomicMax(&g.pick[m], key);
             }
+            S2VT_STAMP_AT(11);                     // (dev build) lane reduction + atomics
         }
     }
 #ifdef S2VT_STAMP

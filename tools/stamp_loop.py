@@ -56,5 +56,7 @@ for M in (384, 320, 64):
 vid = torch.zeros(384, dtype=torch.int32, device=dev); sid = torch.zeros(384, dtype=torch.int32, device=dev)
 o2 = torch.randn(384, H, device=dev)
 report("PICK M=384", lambda: ops.vocab_pick(o2, Wout, bout, vid, sid, 0, 1))
+sidg = -torch.ones(384, dtype=torch.int32, device=dev)
+report("PICK M=384 greedy rows only", lambda: ops.vocab_pick(o2, Wout, bout, vid, sidg, 0, 1))
 A = torch.randn(6400, 1000, device=dev)
 report("STORE logits 6400x1000x12000", lambda: ops.gemm([ops.operand(A)], Wout, None, M=6400), reps=2)
