@@ -129,11 +129,86 @@ __global__ __launch_bounds__(256) void softmax_nll_kernel(float* logits, int ld,
     }
 }
 
+// The same arithmetic, in the same per-thread order, with the row held in REGISTERS: thread t owns the float4s
+// t, t+256, ... (NV4 of them, V <= 1024*NV4), loads them once, keeps exp(l - max) from the sum pass for the gradient
+// pass -- HBM and L2 see one read and one write of the row, and each element costs one exp instead of two.
+template <int NV4>
+__global__ __launch_bounds__(256) void softmax_nll_reg_kernel(float* logits, int ld, int V, const int32_t* target,
+                                                              const float* coef, float smoothing, float* nll, float* lp_t)
+{
+    __shared__ float sh[8];
+    const int row = blockIdx.x;
+    float* l = logits + (size_t)row * ld;
+    const int tid = threadIdx.x;
+    const int V4 = V >> 2;                        // (V % 4 == 0 on this path)
+    float4 x[NV4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < NV4; ++n) {
+        const int i = tid + n * 256;
+        if (i < V4) {
+            x[n] = reinterpret_cast<const float4*>(l)[i];
+            mx = fmaxf(fmaxf(mx, fmaxf(x[n].x, x[n].y)), fmaxf(x[n].z, x[n].w));
+        }
+    }
+    mx = block_reduce<true>(mx, sh);
+    const int tg = target[row];
+    float lt_part = 0.f;                          // the owner of the target element contributes l[tg]
+    float se = 0.f, sl = 0.f;
+#pragma unroll
+    for (int n = 0; n < NV4; ++n) {
+        const int i = tid + n * 256;
+        if (i < V4) {
+            const float4 v = x[n];
+            const int b = i * 4;
+            if (tg >= b && tg < b + 4) lt_part = tg == b ? v.x : tg == b + 1 ? v.y : tg == b + 2 ? v.z : v.w;
+            sl += (v.x + v.y) + (v.z + v.w);
+            x[n].x = dm_expf(v.x - mx); x[n].y = dm_expf(v.y - mx); x[n].z = dm_expf(v.z - mx); x[n].w = dm_expf(v.w - mx);
+            se += x[n].x + x[n].y + x[n].z + x[n].w;
+        }
+    }
+    se = block_reduce<false>(se, sh);
+    sl = block_reduce<false>(sl, sh);
+    const float lt = block_reduce<false>(lt_part, sh);           // one non-zero term: exact
+    const float lse = mx + dm_logf(se);
+    const float qoff = smoothing / (float)V;
+    if (tid == 0) {
+        const float v = -(1.0f - smoothing) * (lt - lse) - qoff * (sl - (float)V * lse);
+        if (nll) nll[row] = v;
+        if (lp_t) lp_t[row] = lt - lse;
+    }
+    const float cf = coef[row];
+    const float inv = 1.0f / se;
+#pragma unroll
+    for (int n = 0; n < NV4; ++n) {
+        const int i = tid + n * 256;
+        if (i < V4) {
+            float4 v;
+            v.x = cf * (x[n].x * inv - qoff);
+            v.y = cf * (x[n].y * inv - qoff);
+            v.z = cf * (x[n].z * inv - qoff);
+            v.w = cf * (x[n].w * inv - qoff);
+            const int b = i * 4;
+            if (tg >= b && tg < b + 4) {
+                const float d = cf * (1.0f - smoothing);
+                if (tg == b) v.x -= d; else if (tg == b + 1) v.y -= d; else if (tg == b + 2) v.z -= d; else v.w -= d;
+            }
+            reinterpret_cast<float4*>(l)[i] = v;
+        }
+    }
+}
+
 hipError_t launch_softmax_nll(float* logits, int ld, int R, int V, const int32_t* target, const float* coef,
                               float smoothing, float* nll, float* lp_t, hipStream_t st)
 {
     if (R <= 0) return hipSuccess;
-    hipLaunchKernelGGL(softmax_nll_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, nll, lp_t);
+    const bool vec = (ld & 3) == 0 && (V & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+    if (vec && V <= 1024 * 4)
+        hipLaunchKernelGGL(softmax_nll_reg_kernel<4>, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, nll, lp_t);
+    else if (vec && V <= 1024 * 12)
+        hipLaunchKernelGGL(softmax_nll_reg_kernel<12>, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, nll, lp_t);
+    else
+        hipLaunchKernelGGL(softmax_nll_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, nll, lp_t);
     return hipGetLastError();
 }
 
