@@ -27,8 +27,9 @@ from . import ops
 
 
 class EndToEnd:
-    def __init__(self, model, cnn: torch.nn.Module, feature_keep: float | None = None, seed: int = 0):
+    def __init__(self, model, cnn: torch.nn.Module, feature_keep: float | None = None, seed: int = 0, channels_last: bool = False):
         self.model, self.cnn = model, cnn.to(model.device)
+        self.channels_last = channels_last                   # feed the CNN NHWC activations (MIOpen picks its NHWC kernels)
         self.keep = model.dropout_rate if feature_keep is None else feature_keep      # slim.dropout(net, self.dropout_rate, ..)
         self.seed = seed
         params = [p for p in self.cnn.parameters() if p.requires_grad]
@@ -53,6 +54,8 @@ class EndToEnd:
         """frames [B, Tv, 3, H, W] fp32 in [-1, 1] -> (video [B, Tv, D] contiguous & detached, autograd handle or None)."""
         B, Tv = frames.shape[:2]
         x = frames.to(self.model.device, torch.float32).reshape(B * Tv, *frames.shape[2:])
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
         with torch.set_grad_enabled(track):
             f = self.cnn(x)
             if dropout and self.keep < 1.0:

@@ -22,12 +22,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--size", type=int, default=299)
     ap.add_argument("--out", default="")
+    ap.add_argument("--channels-last", action="store_true")
     a = ap.parse_args()
     B, Tv, Tc, V = a.batch, 5, 20, 12000
     torch.manual_seed(0)
     mdl = M.Video_Caption_Generator(1536, V, 500, 1000, B, Tv + Tc, Tv, Tc, dropout_rate=0.9)
     net = irv2.InceptionResnetV2()
-    tr = e2e.EndToEnd(mdl, net)
+    tr = e2e.EndToEnd(mdl, net, channels_last=a.channels_last)
     rng = np.random.default_rng(0)
     frames = torch.as_tensor(rng.uniform(-1, 1, (B, Tv, 3, a.size, a.size)).astype(np.float32)).cuda()
     cap = rng.integers(2, V, (B, Tc)).astype(np.int32); cap[:, 12:] = 0
