@@ -201,9 +201,11 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
                   int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                   const int32_t* sample_id, void* workspace, size_t workspace_bytes, s2vt_stream stream);
 
-/* The same in two parts for data-parallel callers: phase 1 = the vocab projection only (dW/db of embed_word and the
- * gradient w.r.t. LSTM2's outputs) -- after it the embed_word gradients are final, so their all-reduce can run
- * under phase 2 (everything else).  phase 0 = s2vt_bptt_bwd. */
+/* The same in parts, for data-parallel callers that start the all-reduce of a gradient slice as soon as it is final and
+ * let it run under the rest of the backward:  phase 1 = the vocab projection (embed_word_W / _b final; also the
+ * gradient w.r.t. LSTM2's outputs);  3 = LSTM2's recurrence and weight gradients (lstm2_W / _b final);  4 = everything
+ * after (input gradients, LSTM1, Wemb, frame embedding);  2 = 3 + 4;  0 = s2vt_bptt_bwd.  Call them in the order
+ * 1, 3, 4 (or 1, 2) on the same workspace. */
 int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
                         int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                         const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase, s2vt_stream stream);

@@ -255,7 +255,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                         int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                         const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase, s2vt_stream stream)
 {
-    if (phase < 0 || phase > 2) return S2VT_E_BADARG;
+    if (phase < 0 || phase > 4) return S2VT_E_BADARG;
     if (!dims_ok(d) || !params_ok(p) || !params_ok(grads) || !video || !dlogits || !workspace || B <= 0 || N <= 0 || N % B)
         return S2VT_E_BADARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
@@ -270,11 +270,14 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
     const size_t NH = (size_t)N * H;
     const int K2 = 2 * H + E, K1 = E + H;
 
-    // phase 1 = the vocab projection (its gradients are final after it: a data-parallel caller starts their
-    // all-reduce while phase 2, everything else, still runs); phase 0 = both
+    // Phases, for data-parallel callers that start a slice's all-reduce as soon as its gradients are final:
+    //   1 = the vocab projection (embed_word_W / _b final);  3 = LSTM2's recurrence + its weight gradients (lstm2_W / _b
+    //   final);  4 = everything after (dX2, LSTM1, Wemb, frame embedding);  2 = 3 + 4;  0 = all.
+    const bool do_vocab = phase == 0 || phase == 1, do_l2 = phase == 0 || phase == 2 || phase == 3,
+               do_rest = phase == 0 || phase == 2 || phase == 4;
     SideStream& ss = side_stream();
-    hipStream_t sd = ss.ok ? ss.s : st;                     // weight-gradient work that may run beside a recurrence
-    if (phase != 2) {
+    hipStream_t sd = (ss.ok && phase == 0) ? ss.s : st;      // weight-gradient work that may run beside a recurrence (whole-pass calls only)
+    if (do_vocab) {
         // transposed weight copy for the data-gradient product + the vocab projection
         hipStream_t sv = phase == 0 ? sd : st;              // (phase 1: its gradients must be final on the caller's stream)
         if (sv != st) HIP_TRY(fork_to(st, sv, ss.ev[0]));
@@ -284,11 +287,11 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         HIP_TRY(launch_transpose(p->embed_word_W, V, w.WoutT, H, H, V, st));
         HIP_TRY(nn_bwd(dlogits, V, w.WoutT, H, w.dO2, H, Tc * N, H, V, 1, 0, st));
     }
-    if (phase == 1) return S2VT_OK;
+    const SlabPlan sp2 = slab_plan(N, H), sp1 = slab_plan(B, H);
+    if (do_l2) {
     HIP_TRY(launch_transpose(p->lstm2_W, 4 * H, w.W2T, K2, K2, 4 * H, st));
     HIP_TRY(launch_transpose(p->lstm1_W, 4 * H, w.W1T, K1, K1, 4 * H, st));
     // ---- LSTM2 back through time
-    const SlabPlan sp2 = slab_plan(N, H), sp1 = slab_plan(B, H);
     for (int t = T - 1; t >= 0; --t) {
         HIP_TRY(launch_lstm_bwd_pointwise(w.G2 + (size_t)t * 4 * NH, w.C2 + (t + 1) * NH, w.C2 + t * NH,
                                           t == T - 1 ? nullptr : w.slab, sp2.nslab, NH,
@@ -311,6 +314,8 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         HIP_TRY(launch_gemm_tn(e, sd));
         HIP_TRY(launch_colsum(w.dZ2, 4 * H, T * N, 4 * H, grads->lstm2_b, sd));
     }
+    }
+    if (!do_rest) return S2VT_OK;
     // d[out1 ; embed] for every step at once
     HIP_TRY(nn_bwd(w.dZ2, 4 * H, w.W2T, K2, w.dX2, H + E, T * N, H + E, 4 * H, 1, 0, st));
     // ---- LSTM1 back through time, on the B per-video rows: the gradient w.r.t. its dropped output is

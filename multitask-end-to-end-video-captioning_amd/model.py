@@ -266,9 +266,10 @@ class Video_Caption_Generator:
         return nll, lp
 
     def backward(self, accumulate=False, overlap=True):
-        """BPTT into the flat gradient bucket (accumulate=True: on top of what a previous pass left there).  Data parallel: the vocab-projection gradients (a third of the
-        bucket) are final after phase 1, so their all-reduce is started there and runs over xGMI beside phase 2;
-        apply_gradients() reduces the rest and waits for both."""
+        """BPTT into the flat gradient bucket (accumulate=True: on top of what a previous pass left there).  Data parallel:
+        the bucket is laid out [... lstm1_W | lstm2_W | embed_word_W | embed_word_b | ...]; the vocab-projection
+        gradients are final after phase 1 and LSTM2's after phase 3, so their all-reduces are started there and run
+        over xGMI beside the rest of the backward; apply_gradients() reduces what is left and waits for all of them."""
         video, N, dlogits, ws, keep, seed, vid, sid = self._ctx
         st = self.store
         if not accumulate:
@@ -276,12 +277,18 @@ class Video_Caption_Generator:
         self._pending = []
         self._early = None
         if dp.world_size() > 1 and overlap:
-            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, phase=1)
-            lo = st.offsets["embed_word_W"]
-            hi = st.offsets["embed_word_b"] + (int(np.prod(st.shapes["embed_word_b"])) + 63) // 64 * 64
-            self._early = (lo, hi)
-            self._pending.append(dp.allreduce_async(st.grad[lo:hi]))
-            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, phase=2)
+            def span(first, last):
+                return st.offsets[first], st.offsets[last] + (int(np.prod(st.shapes[last])) + 63) // 64 * 64
+            args = (self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid)
+            ops.bptt_bwd(*args, phase=1)
+            lo1, hi1 = span("embed_word_W", "embed_word_b")
+            self._pending.append(dp.allreduce_async(st.grad[lo1:hi1]))
+            ops.bptt_bwd(*args, phase=3)
+            lo2, hi2 = span("lstm2_W", "lstm2_W")
+            assert hi2 == lo1, "bucket layout: lstm2_W sits right below embed_word_W"
+            self._pending.append(dp.allreduce_async(st.grad[lo2:hi2]))
+            self._early = (lo2, hi1)                       # [lo2, hi1) is already on its way
+            ops.bptt_bwd(*args, phase=4)
         else:
             ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid)
 

@@ -204,3 +204,38 @@ def test_mixed_pg_xe_objective_vs_float64_autograd(gpu, oracle):
         g = mdl.store.g[n].cpu().numpy().astype(np.float64)
         rg = pt[n].grad.numpy()
         assert np.abs(g - rg).max() <= 2e-4 * (np.abs(rg).max() + 1e-12) + 1e-9, n
+
+
+def test_backward_phases_sum_to_the_whole_pass(gpu, oracle):
+    """s2vt_bptt_bwd_phase 1, 3, 4 (the data-parallel split: each slice's all-reduce starts when its phase ends) leaves
+    the same gradients as the single call; after phase 1 only the vocab projection is touched, after 3 also LSTM2."""
+    import torch
+    case = CASES[1]
+    d, p, video, cap, vid, sid, N = _setup(oracle, case)
+    dims = gpu.make_dims(d.dim_image, d.n_words, d.word_dim, d.lstm_dim, d.n_video_lstm_step, d.n_caption_lstm_step)
+    dp_ = {k: _dev(v) for k, v in p.items()}
+    params = gpu.make_params(dp_)
+    rng = np.random.default_rng(2)
+    coef = _dev(rng.standard_normal(N * d.n_caption_lstm_step).astype(np.float32))
+
+    def run(phases):
+        logits, ws = gpu.teacher_forced_fwd(dims, params, _dev(video), _dev(cap), N, 0.9, 99, _dev(vid), _dev(sid))
+        gpu.softmax_nll_fwd_bwd(logits, _dev(cap).t().contiguous().view(-1), coef, 0.0)
+        g = {k: torch.zeros_like(v) for k, v in dp_.items()}
+        grads = gpu.make_params(g)
+        snaps = []
+        for ph in phases:
+            gpu.bptt_bwd(dims, params, grads, _dev(video), N, logits, ws, 0.9, 99, _dev(vid), _dev(sid), phase=ph)
+            snaps.append({k: v.clone() for k, v in g.items()})
+        return g, snaps
+    whole, _ = run([0])
+    parts, snaps = run([1, 3, 4])
+    for k in whole:
+        ref = whole[k].cpu().numpy(); got = parts[k].cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-5 * (np.abs(ref).max() + 1e-12) + 1e-9, k
+    touched1 = {k for k, v in snaps[0].items() if float(v.abs().sum()) > 0}
+    assert touched1 == {"embed_word_W", "embed_word_b"}
+    touched3 = {k for k, v in snaps[1].items() if float(v.abs().sum()) > 0}
+    assert touched3 == {"embed_word_W", "embed_word_b", "lstm2_W", "lstm2_b"}
+    for k in ("lstm2_W", "lstm2_b", "embed_word_W"):
+        assert torch.equal(snaps[1][k], parts[k])                 # final when their phase returns
