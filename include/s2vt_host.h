@@ -39,7 +39,7 @@ void s2vt_cider_destroy(s2vt_cider* h);
 
 /* Score N candidate rows of Tc token ids (decode_captions semantics, cider_evaluation.py:122-143: the caption is
  * the ids BEFORE the first eos_id; an empty caption scores against the references like any other) against the
- * references of video_of_row[n].  out[n] = CIDEr-D * 10 as the reference's reward.  n_threads <= 0: all cores.
+ * references of video_of_row[n].  out[n] = CIDEr-D * 10 as the reference's reward.  n_threads <= 1: the calling thread (a 384-caption batch takes ~3 ms); > 1: OpenMP threads.
  * Returns 0, or -1 on bad arguments (a video index out of range included). */
 int s2vt_cider_score(const s2vt_cider* h, const int32_t* ids, int32_t N, int32_t Tc, int32_t eos_id,
                      const int32_t* video_of_row, float* out, int32_t n_threads);

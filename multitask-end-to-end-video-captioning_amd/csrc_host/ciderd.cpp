@@ -49,11 +49,18 @@ void count_ngrams(const int32_t* w, int len, Counts& c)
         for (int i = 0; i + n <= len; ++i) c[make_key(w + i, n)] += 1.0f;
 }
 
-struct Vec {
-    std::vector<std::pair<Key, double>> g[kN];   // tf-idf weights per n
-    double norm[kN];
-    double length;                               // number of bigrams (the published scorer's "length")
+// One video's references as an inverted index: the distinct n-grams of all its references, sorted, each with the
+// list of (reference, tf-idf weight) pairs that contain it -- a candidate n-gram costs ONE binary search per video
+// instead of one hash probe per reference, and scoring allocates nothing.
+struct Posting { uint32_t ref; double w; };
+struct VideoIndex {
+    std::vector<Key> keys;                 // sorted
+    std::vector<uint32_t> begin;           // keys.size() + 1 offsets into post
+    std::vector<Posting> post;
+    std::vector<double> norm;              // [n_refs][kN]
+    std::vector<double> length;            // [n_refs]
 };
+inline bool key_less(const Key& x, const Key& y) { return x.a < y.a || (x.a == y.a && x.b < y.b); }
 
 }  // namespace
 
@@ -61,23 +68,12 @@ struct s2vt_cider {
     int32_t n_videos;
     double ref_len;                                              // log(number of videos)
     std::unordered_map<Key, float, KeyHash> df;                  // document frequency (documents = videos)
-    std::vector<std::vector<Vec>> refs;                          // per video: one Vec per reference
-    std::vector<std::vector<std::unordered_map<Key, double, KeyHash>>> ref_maps;   // same weights, hashed, per n merged
+    std::vector<VideoIndex> videos;
 
-    void to_vec(const Counts& c, Vec& v) const
+    double idf(const Key& k) const
     {
-        for (int n = 0; n < kN; ++n) { v.g[n].clear(); v.norm[n] = 0.0; }
-        v.length = 0.0;
-        for (const auto& kv : c) {
-            const int n = key_len(kv.first) - 1;
-            auto it = df.find(kv.first);
-            const double d = std::log(std::max(1.0, it == df.end() ? 0.0 : (double)it->second));
-            const double g = (double)kv.second * (ref_len - d);
-            v.g[n].push_back({kv.first, g});
-            v.norm[n] += g * g;
-            if (n == 1) v.length += kv.second;
-        }
-        for (int n = 0; n < kN; ++n) v.norm[n] = std::sqrt(v.norm[n]);
+        auto it = df.find(k);
+        return ref_len - std::log(std::max(1.0, it == df.end() ? 0.0 : (double)it->second));
     }
 };
 
@@ -107,17 +103,34 @@ s2vt_cider* s2vt_cider_create(const int32_t* tokens, const int64_t* offsets, con
             for (const auto& kv : c) seen.emplace(kv.first, 1);
         for (const auto& kv : seen) h->df[kv.first] += 1.0f;
     }
-    h->refs.resize(n_videos);
-    h->ref_maps.resize(n_videos);
+    h->videos.resize(n_videos);
     for (int v = 0; v < n_videos; ++v) {
-        h->refs[v].resize(counts[v].size());
-        h->ref_maps[v].resize(counts[v].size());
-        for (size_t i = 0; i < counts[v].size(); ++i) {
-            h->to_vec(counts[v][i], h->refs[v][i]);
-            auto& m = h->ref_maps[v][i];
-            for (int n = 0; n < kN; ++n)
-                for (const auto& kg : h->refs[v][i].g[n]) m.emplace(kg.first, kg.second);
+        VideoIndex& vi = h->videos[v];
+        const size_t nr = counts[v].size();
+        vi.norm.assign(nr * kN, 0.0);
+        vi.length.assign(nr, 0.0);
+        struct Item { Key k; uint32_t ref; double w; };
+        std::vector<Item> items;
+        for (size_t i = 0; i < nr; ++i)
+            for (const auto& kv : counts[v][i]) {
+                const int n = key_len(kv.first) - 1;
+                const double g = (double)kv.second * h->idf(kv.first);
+                items.push_back({kv.first, (uint32_t)i, g});
+                vi.norm[i * kN + n] += g * g;
+                if (n == 1) vi.length[i] += kv.second;
+            }
+        for (double& x : vi.norm) x = std::sqrt(x);
+        std::sort(items.begin(), items.end(), [](const Item& x, const Item& y) {
+            return key_less(x.k, y.k) || (x.k == y.k && x.ref < y.ref);
+        });
+        for (size_t i = 0; i < items.size(); ++i) {
+            if (i == 0 || !(items[i].k == items[i - 1].k)) {
+                vi.keys.push_back(items[i].k);
+                vi.begin.push_back((uint32_t)vi.post.size());
+            }
+            vi.post.push_back({items[i].ref, items[i].w});
         }
+        vi.begin.push_back((uint32_t)vi.post.size());
     }
     return h;
 }
@@ -132,38 +145,65 @@ int s2vt_cider_score(const s2vt_cider* h, const int32_t* ids, int32_t N, int32_t
     if (!h || !ids || !video_of_row || !out || N < 0 || Tc <= 0) return -1;
     for (int n = 0; n < N; ++n)
         if (video_of_row[n] < 0 || video_of_row[n] >= h->n_videos) return -1;
+    size_t max_refs = 0;
+    for (const VideoIndex& vi : h->videos) max_refs = std::max(max_refs, vi.length.size());
+    // ~30 index probes per caption (a 384-caption batch scores in ~3 ms on one core): threads only on request --
+    // inside a process that also hosts torch's OpenMP pool a parallel region costs more than it saves
 #ifdef _OPENMP
-    const int nt = n_threads > 0 ? n_threads : omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 8) num_threads(nt)
+    const int nt = n_threads > 1 ? n_threads : 1;
+#pragma omp parallel num_threads(nt) if (nt > 1)
 #endif
-    for (int r = 0; r < N; ++r) {
-        const int32_t* w = ids + (size_t)r * Tc;
-        int len = 0;
-        while (len < Tc && w[len] != eos_id) ++len;                 // words before the first <eos>
-        Counts c;
-        count_ngrams(w, len, c);
-        Vec hv;
-        h->to_vec(c, hv);
-        const auto& refs = h->refs[video_of_row[r]];
-        const auto& maps = h->ref_maps[video_of_row[r]];
-        double score[kN] = {0, 0, 0, 0};
-        for (size_t i = 0; i < refs.size(); ++i) {
-            const Vec& rv = refs[i];
-            const double delta = hv.length - rv.length;
-            const double pen = std::exp(-(delta * delta) / (2.0 * kSigma * kSigma));
-            for (int n = 0; n < kN; ++n) {
-                double val = 0.0;
-                for (const auto& kg : hv.g[n]) {
-                    auto it = maps[i].find(kg.first);
-                    if (it != maps[i].end()) val += std::min(kg.second, it->second) * it->second;
+    {
+        std::vector<Key> keys((size_t)kN * Tc);             // per-thread scratch, allocated once per call
+        std::vector<double> val(max_refs * kN);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int r = 0; r < N; ++r) {
+            const int32_t* w = ids + (size_t)r * Tc;
+            int len = 0;
+            while (len < Tc && w[len] != eos_id) ++len;             // words before the first <eos>
+            // the candidate's n-grams, sorted (all n together; shorter n-grams have zero low slots and sort first)
+            int nk = 0;
+            for (int n = 1; n <= kN; ++n)
+                for (int i = 0; i + n <= len; ++i) keys[nk++] = make_key(w + i, n);
+            std::sort(keys.begin(), keys.begin() + nk, key_less);
+            const VideoIndex& vi = h->videos[video_of_row[r]];
+            const size_t nr = vi.length.size();
+            std::fill(val.begin(), val.begin() + nr * kN, 0.0);
+            double hnorm2[kN] = {0, 0, 0, 0}, hlen = 0.0;
+            for (int i = 0; i < nk;) {
+                int j = i + 1;
+                while (j < nk && keys[j] == keys[i]) ++j;
+                const Key k = keys[i];
+                const int n = key_len(k) - 1;
+                const double g = (double)(j - i) * h->idf(k);
+                hnorm2[n] += g * g;
+                if (n == 1) hlen += (double)(j - i);
+                auto it = std::lower_bound(vi.keys.begin(), vi.keys.end(), k, key_less);
+                if (it != vi.keys.end() && *it == k) {
+                    const size_t ki = (size_t)(it - vi.keys.begin());
+                    for (uint32_t q = vi.begin[ki]; q < vi.begin[ki + 1]; ++q)
+                        val[(size_t)vi.post[q].ref * kN + n] += std::min(g, vi.post[q].w) * vi.post[q].w;
                 }
-                if (hv.norm[n] != 0.0 && rv.norm[n] != 0.0) val /= hv.norm[n] * rv.norm[n];
-                score[n] += val * pen;
+                i = j;
             }
+            double hnorm[kN];
+            for (int n = 0; n < kN; ++n) hnorm[n] = std::sqrt(hnorm2[n]);
+            double score[kN] = {0, 0, 0, 0};
+            for (size_t i = 0; i < nr; ++i) {
+                const double delta = hlen - vi.length[i];
+                const double pen = std::exp(-(delta * delta) / (2.0 * kSigma * kSigma));
+                for (int n = 0; n < kN; ++n) {
+                    double v = val[i * kN + n];
+                    if (hnorm[n] != 0.0 && vi.norm[i * kN + n] != 0.0) v /= hnorm[n] * vi.norm[i * kN + n];
+                    score[n] += v * pen;
+                }
+            }
+            double avg = (score[0] + score[1] + score[2] + score[3]) / kN;
+            if (nr) avg /= (double)nr;
+            out[r] = (float)(avg * 10.0);
         }
-        double avg = (score[0] + score[1] + score[2] + score[3]) / kN;
-        if (!refs.empty()) avg /= (double)refs.size();
-        out[r] = (float)(avg * 10.0);
     }
     return 0;
 }

@@ -260,6 +260,8 @@ class Video_Caption_Generator:
             state = (ls[0], ls[1])
         logits, ws = ops.teacher_forced_fwd(self.dims, self.store.params, video, caption, N, keep, seed, vid, sid,
                                             sampler_state=state)
+        if callable(coef_tm):            # host work (the reward) runs here, beside the forward just queued on the GPU
+            coef_tm = coef_tm()
         target = caption.t().contiguous().view(-1)
         nll, lp = ops.softmax_nll_fwd_bwd(logits, target, coef_tm, smoothing)
         self._ctx = (video, N, logits, ws, keep, seed, vid, sid)
@@ -338,7 +340,7 @@ class Video_Caption_Generator:
         ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, self._sumsq, clip_norm, lr, self.global_step)
 
     def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
-                         true_labels=None, reuse_sampler_state=False, extra_sumsq=None):
+                         true_labels=None, reuse_sampler_state=False, extra_sumsq=None, reward_fn=None):
         """build_loss + the REINFORCE objective and train_op of train()
         (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc],
         rewards / baseline [N], rows sample-major over the B videos.
@@ -346,17 +348,26 @@ class Video_Caption_Generator:
         with the current weights -- its LSTM1 trajectory is reused (the reference recomputes the whole unroll in
         build_loss).  With true_labels [B, label_dim] the multitask objective of
         reinforce_multitask_e2e_attribute_loss.py:957 is used instead:
-            -(1-alpha) * PG / sum(mask) + alpha * sum(bce) / (label_dim * B)."""
+            -(1-alpha) * PG / sum(mask) + alpha * sum(bce) / (label_dim * B).
+        reward_fn: callable() -> (rewards [N], baseline [N]) evaluated on the host AFTER the teacher-forced forward has
+        been queued on the GPU (which does not need them), so a host-side scorer (CIDEr-D) runs under it; `rewards` /
+        `baseline` are ignored then."""
         video = self._dev(video, torch.float32)
         cap = self._dev(sampled, torch.int32)
         mask = self._dev(mask, torch.float32)
-        adv = self._dev(rewards, torch.float32) - self._dev(baseline, torch.float32)
         rep = cap.shape[0] // video.shape[0]
         multitask = true_labels is not None and self.label_dim > 0
         pg_w = (1.0 - self.alpha) if multitask else 1.0
-        coef = (mask * (adv * pg_w)[:, None]).t().contiguous().view(-1)
+        made = {}
+
+        def make_coef():
+            r, b = reward_fn() if reward_fn is not None else (rewards, baseline)
+            adv = self._dev(r, torch.float32) - self._dev(b, torch.float32)
+            made["coef"] = (mask * (adv * pg_w)[:, None]).t().contiguous().view(-1)
+            return made["coef"]
         keep = self.dropout_rate if keep is None else keep
-        nll, _ = self._forward_loss(video, cap, coef, 0.0, rep, video_base, keep, reuse_sampler_state)
+        nll, _ = self._forward_loss(video, cap, make_coef, 0.0, rep, video_base, keep, reuse_sampler_state)
+        coef = made["coef"]
         msum = mask.sum()
         loss_local = torch.dot(coef, nll)
         self.backward()

@@ -6,8 +6,8 @@ Step of the reference                                   | here
 9 sess.run of the sampler graphs (:743-753), each       | model.sample(video, K, with_greedy=True): ONE call,
   re-encoding the batch, vstack on the host (:757-764)  |   one encode, rows already sample-major
 decode_captions_masks: ids -> strings + mask (:783-784) | mask on the device (cumsum of <eos>), no strings
-get_captions scan + evaluate_captions_cider x2 (:787-803| reward.CiderD.score_ids on the int32 ids (C++, threads),
-  pyciderevalcap on strings)                            |   references indexed per video once
+get_captions scan + evaluate_captions_cider x2 (:787-803| reward.CiderD.score_ids on the int32 ids (C++ inverted index, ~3 ms,
+  pyciderevalcap on strings)                            |   under the GPU's teacher-forced forward); references indexed once
 features tiled x8 on the host (:779-782)                | never tiled: rows address video n % B
 sess.run([train_op, sum_loss]) (:823)                   | model.reinforce_update (forward with dropout, reward-scaled
                                                         |   NLL, BPTT, all-reduce, clip 5, Adam, lr 1e-6 * 0.5^(step//1000))
@@ -61,10 +61,16 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
             is_eos = samples == 0
             mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()        # 1 up to and incl. the first <eos>
             rows = np.asarray([train_corpus.index.row[v] for v in vid], np.int32)
-            r = scorer.score_ids(samples.cpu().numpy(), np.tile(rows, K))               # [K*B], sample-major like the ids
-            b = scorer.score_ids(greedy_words.cpu().numpy(), rows)                      # [B]
-            st = model.reinforce_update(video, samples, mask, r, hostglue.tile_baseline(b, K),
-                                        lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm, reuse_sampler_state=True)
+            s_host, g_host = samples.cpu().numpy(), greedy_words.cpu().numpy()
+            rb = {}
+
+            def rewards():                  # runs on the host while the GPU does the teacher-forced forward
+                rb["r"] = scorer.score_ids(s_host, np.tile(rows, K))                     # [K*B], sample-major like the ids
+                rb["b"] = scorer.score_ids(g_host, rows)                                # [B]
+                return rb["r"], hostglue.tile_baseline(rb["b"], K)
+            st = model.reinforce_update(video, samples, mask, None, None, lr=learning_rate(cfg, model.global_step),
+                                        clip_norm=cfg.clip_norm, reuse_sampler_state=True, reward_fn=rewards)
+            r, b = rb["r"], rb["b"]
             losses.append(float(st.loss)); adv.append(float(r.mean() - b.mean()))
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} loss: {losses[-1]:.5f} "
                 f"r: {r.mean():.4f} b: {b.mean():.4f} Elapsed time: {time.time() - t0:.3f}")
