@@ -1,0 +1,35 @@
+"""Dev helper: wall time of the REAL training loop (train_rl.train: feature batches, sampler, host CIDEr-D reward,
+update) at the bench dimensions on a synthetic corpus, next to the GPU-only step of bench.py."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import s2vt_amd
+from s2vt_amd import data, train_common as tc, train_rl
+
+rng = np.random.default_rng(0)
+V, nvid, refs_per, D, Tv = 12000, 640, 20, 1536, 5
+vocab = ["<en_unk>"] + [f"w{i}" for i in range(V - 3)]
+p = 1 / np.arange(1, len(vocab) + 1); p /= p.sum()
+sents = []
+for v in range(nvid):
+    for _ in range(refs_per):
+        sents.append((f"vid{v}", " ".join(vocab[i] for i in rng.choice(len(vocab), size=rng.integers(4, 12), p=p))))
+corpus = tc.Corpus.__new__(tc.Corpus)
+corpus.captions = np.asarray(sents)
+corpus.features = data.FeatureStore(np.abs(rng.standard_normal((nvid, Tv, D)) * 0.5).astype(np.float32), [f"vid{v}" for v in range(nvid)])
+corpus.vocabulary = vocab
+corpus.index = data.CaptionIndex(corpus.captions)
+cfg = train_rl.rl_config(n_caption_lstm_step=20, n_epochs=1, batch_size=64, multisample=5, max_steps_per_epoch=int(sys.argv[1]) if len(sys.argv) > 1 else 30,
+                         model_path="/tmp/rl_timing")
+times = []
+
+
+def log(msg):
+    if "Elapsed time" in msg:
+        times.append(float(msg.rsplit(":", 1)[1]))
+
+
+t0 = time.time()
+train_rl.train(cfg, corpus, None, log=log)
+print(f"{len(times)} steps; median wall per step {1e3 * np.median(times[3:]):.2f} ms (first {1e3 * times[0]:.0f} ms); loop total {time.time() - t0:.1f} s")
