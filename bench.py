@@ -161,7 +161,7 @@ def main():
         if dom:
             ach = dom["total_flops"] / (dom["total_ms"] * 1e-3) / 1e12
             cls = {0: "contraction+store", 1: "fused LSTM cell (4-gate GEMM + pointwise epilogue)", 2: "vocab logits + Gumbel-max pick",
-                   3: "weight-gradient TN contraction"}[dom["kernel_class"]]
+                   3: "weight-gradient TN contraction", 4: "contraction+store, W^T operand (backward data gradients)"}[dom["kernel_class"]]
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             if os.path.exists(pmc):

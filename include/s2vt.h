@@ -121,6 +121,14 @@ int s2vt_gemm(const s2vt_operand* segs, int32_t nseg, const float* W, int32_t ld
               const float* Cinit, int32_t ldcinit, float* C, int32_t ldc, int32_t M, int32_t N, int32_t act_tanh,
               int32_t tile_cfg, s2vt_stream stream);
 
+/* The same contraction with the weight matrix given TRANSPOSED, Wt[N, K] (row n = output column n, K contiguous, row
+ * stride ldw): C = act([seg0;seg1;seg2] @ Wt^T + bias).  This is how the backward data-gradient products read the
+ * forward weights as they lie (dX = dZ @ W^T) -- no transposed copies.  Same ascending-k chain, bit-identical to
+ * s2vt_gemm on the transposed matrix. */
+int s2vt_gemm_nt(const s2vt_operand* segs, int32_t nseg, const float* Wt, int32_t ldw, const float* bias,
+                 const float* Cinit, int32_t ldcinit, float* C, int32_t ldc, int32_t M, int32_t N, int32_t act_tanh,
+                 int32_t tile_cfg, s2vt_stream stream);
+
 /* ---- BasicLSTMCell + DropoutWrapper, one call (tf_s2vt.py:74-77,119-143) --------------------
  * z = [x0 ; x1 ; h_prev] @ W + b ; i,j,f,o = split(z) ; c' = c*sig(f+1) + sig(i)*tanh(j) ;
  * h' = tanh(c')*sig(o) ; out = keep<1 ? (h'/keep)*mask : h'  (mask from the dropout Philox

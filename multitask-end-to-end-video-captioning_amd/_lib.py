@@ -54,6 +54,7 @@ SIGNATURES = {
     "s2vt_math_eval": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp]),
     "s2vt_gumbel_eval": (C.c_int, [_u64, _i32, _i32, _i32, _vp, _i32, _vp]),
     "s2vt_gemm": (C.c_int, [_OP, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "s2vt_gemm_nt": (C.c_int, [_OP, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "s2vt_lstm_cell_fwd": (C.c_int, [_OP, _OP, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _u64, _vp,
                                      _vp, _u32, _i32, _vp]),
     "s2vt_vocab_pick": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _u64, _vp, _vp, _vp, _i32, _vp]),

@@ -105,6 +105,25 @@ int s2vt_math_eval(int fn, const float* x, float* y, int64_t n, s2vt_stream stre
     return S2VT_OK;
 }
 
+int s2vt_gemm_nt(const s2vt_operand* segs, int32_t nseg, const float* Wt, int32_t ldw, const float* bias, const float* Cinit,
+                 int32_t ldcinit, float* C, int32_t ldc, int32_t M, int32_t N, int32_t act_tanh, int32_t tile_cfg,
+                 s2vt_stream stream)
+{
+    if (!segs || nseg < 1 || nseg > 3 || !Wt || !C || M < 0 || N <= 0 || ldc < N) return S2VT_E_BADARG;
+    if (Cinit && ldcinit < N) return S2VT_E_BADARG;
+    ASeg a[3];
+    int kw = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (segs[i].k < 0 || (segs[i].ptr && segs[i].ld < segs[i].k)) return S2VT_E_BADARG;
+        seg_from_operand(a[i], &segs[i], kw);
+        kw += segs[i].k;
+    }
+    if (ldw < kw) return S2VT_E_BADARG;
+    if (M == 0) return S2VT_OK;
+    HIP_TRY(store_call(a, nseg, Wt, ldw, bias, C, ldc, M, N, act_tanh ? 1 : 0, tile_cfg, S(stream), Cinit, ldcinit, true));
+    return S2VT_OK;
+}
+
 int s2vt_gumbel_eval(uint64_t seed, int32_t video, int32_t sample, int32_t step, float* out, int32_t V, s2vt_stream stream)
 {
     if (!out || V <= 0) return S2VT_E_BADARG;

@@ -105,7 +105,7 @@ inline hipError_t pick_call(const float* A, int lda, const float* W, const float
 }
 
 inline hipError_t store_call(const ASeg* segs, int nseg, const float* W, int ldw, const float* bias, float* C, int ldc, int M,
-                      int N, int act, int cfg, hipStream_t st, const float* cinit = nullptr, int ldcinit = 0)
+                      int N, int act, int cfg, hipStream_t st, const float* cinit = nullptr, int ldcinit = 0, bool w_transposed = false)
 {
     GemmArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -114,7 +114,7 @@ inline hipError_t store_call(const ASeg* segs, int nseg, const float* W, int ldw
     a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.gstride = 0; a.bias = bias;
     a.cinit = cinit; a.ldcinit = ldcinit;
     a.C = C; a.ldc = ldc; a.act = act;
-    return launch_gemm(a, EPI_STORE, cfg, st);
+    return launch_gemm(a, w_transposed ? EPI_STORE_NT : (int)EPI_STORE, cfg, st);
 }
 
 // ---- sampler halves (api.hip), shared with the session API (session.hip)

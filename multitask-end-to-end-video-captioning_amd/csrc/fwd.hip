@@ -19,12 +19,12 @@ struct CfgEntry {
     int BM, CG, NT, lds_bytes;
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, int BKT = 32, int PW = 0>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, int BKT = 32, int PW = 0, bool BT = false>
 constexpr CfgEntry make_entry(const char* name)
 {
-    using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true, BKT, PW>;
-    return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true, BKT, PW>,
-                    gemm_kernel<WM, WN, TM, TN, NG, EPI, false, BKT, PW>, C::BM, C::CG, C::NT, C::LDS_FLOATS * 4};
+    using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT>;
+    return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT>,
+                    gemm_kernel<WM, WN, TM, TN, NG, EPI, false, BKT, PW, BT>, C::BM, C::CG, C::NT, C::LDS_FLOATS * 4};
 }
 
 // name = BMxBN(wavesMxwavesN)
@@ -37,6 +37,17 @@ const CfgEntry kStore[] = {
     make_entry<2, 2, 2, 3, 1, EPI_STORE>("64x96(2x2)"),
     make_entry<2, 2, 3, 3, 1, EPI_STORE>("96x96(2x2)"),
     make_entry<2, 2, 3, 4, 1, EPI_STORE>("96x128(2x2)"),
+};
+// the same tiles for C = A . W^T with W given as [N][K] (backward data-gradient products): index-compatible with kStore
+const CfgEntry kStoreNT[] = {
+    make_entry<4, 1, 1, 4, 1, EPI_STORE, 32, 0, true>("nt64x64(4x1)"),
+    make_entry<2, 2, 2, 4, 1, EPI_STORE, 32, 0, true>("nt64x128(2x2)"),
+    make_entry<2, 2, 4, 4, 1, EPI_STORE, 32, 0, true>("nt128x128(2x2)"),
+    make_entry<4, 1, 2, 2, 1, EPI_STORE, 32, 0, true>("nt128x32(4x1)"),
+    make_entry<4, 1, 1, 2, 1, EPI_STORE, 32, 0, true>("nt64x32(4x1)"),
+    make_entry<2, 2, 2, 3, 1, EPI_STORE, 32, 0, true>("nt64x96(2x2)"),
+    make_entry<2, 2, 3, 3, 1, EPI_STORE, 32, 0, true>("nt96x96(2x2)"),
+    make_entry<2, 2, 3, 4, 1, EPI_STORE, 32, 0, true>("nt96x128(2x2)"),
 };
 const CfgEntry kLstm[] = {
     // all four gates of 16 (32) units in one wave
@@ -72,6 +83,7 @@ const CfgEntry* table(int epi, int* n)
 {
     switch (epi) {
         case EPI_STORE: *n = sizeof(kStore) / sizeof(kStore[0]); return kStore;
+        case EPI_STORE_NT: *n = sizeof(kStoreNT) / sizeof(kStoreNT[0]); return kStoreNT;
         case EPI_LSTM: *n = sizeof(kLstm) / sizeof(kLstm[0]); return kLstm;
         default: *n = sizeof(kPick) / sizeof(kPick[0]); return kPick;
     }
@@ -79,9 +91,12 @@ const CfgEntry* table(int epi, int* n)
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-bool can_vec(const GemmArgs& a)
+bool can_vec(const GemmArgs& a, bool bt)
 {
-    if (!aligned16(a.W) || (a.ldw & 3) || (a.N & 3) || (a.gstride & 3)) return false;
+    if (!aligned16(a.W) || (a.ldw & 3) || (!bt && ((a.N & 3) || (a.gstride & 3)))) return false;
+    if (bt)
+        for (int s = 0; s < a.nseg; ++s)
+            if (a.seg[s].kw & 3) return false;           // W^T form: kw is a column offset of 16-byte loads
     for (int s = 0; s < a.nseg; ++s) {
         const ASeg& sg = a.seg[s];
         if (!sg.ptr || sg.k <= 0) continue;
@@ -98,7 +113,7 @@ bool can_vec(const GemmArgs& a)
         const size_t rows = sg.rowmod > 0 ? (size_t)sg.rowmod : (size_t)a.M;
         if (rows * sg.ld * 4 >= (1ull << 31)) return false;
     }
-    if (krows * a.ldw * 4 >= (1ull << 31)) return false;
+    if ((bt ? (size_t)a.N : krows) * a.ldw * 4 >= (1ull << 31)) return false;
     return true;
 }
 
@@ -150,7 +165,7 @@ std::vector<hipEvent_t> g_event_pool;
 
 void set_lds_attrs()
 {
-    for (int epi = 0; epi < 3; ++epi) {
+    for (int epi : {(int)EPI_STORE, (int)EPI_LSTM, (int)EPI_PICK, (int)EPI_STORE_NT}) {
         int n;
         const CfgEntry* t = table(epi, &n);
         for (int i = 0; i < n; ++i) {
@@ -253,8 +268,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     a2.xcd_map = (mt <= 16 && nt >= 8) ? 1 : 0;
     const unsigned gx = a2.xcd_map ? (unsigned)(mt * ceil_div(nt, 8) * 8) : (unsigned)(mt * nt);
     const dim3 grid(gx, (unsigned)(a.splits > 1 ? a.splits : 1), 1);
-    KernelFn fn = can_vec(a) ? e.vec : e.scalar;
-    if (!prof_wants(epi == EPI_LSTM_GW ? EPI_LSTM : epi, cfg)) {
+    KernelFn fn = can_vec(a, epi == EPI_STORE_NT) ? e.vec : e.scalar;
+    const int pcls = epi;                                              // profiler class (0 store, 1 LSTM, 2 pick, 3 = TN kernel, 4 store with W^T)
+    if (!prof_wants(pcls, cfg)) {
         hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a2);
         return hipGetLastError();
     }
@@ -268,7 +284,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a2);
     (void)hipEventRecord(e1, st);
-    prof_record(epi, cfg, e.name, 2.0 * a.M * ksum * cols, e0, e1);
+    prof_record(pcls, cfg, e.name, 2.0 * a.M * ksum * cols, e0, e1);
     return hipGetLastError();
 }
 

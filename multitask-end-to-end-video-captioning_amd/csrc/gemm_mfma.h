@@ -31,6 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 
 enum { EPI_STORE = 0, EPI_LSTM = 1, EPI_PICK = 2, EPI_LSTM_GW = 3 };
+constexpr int EPI_STORE_NT = 4;     // launcher-side id only: EPI_STORE with the W operand given as W^T ([N][K], K contiguous)
 
 struct ASeg {
     const float* ptr;    // [rows, ld] row-major; nullptr = segment absent
@@ -143,7 +144,7 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define S2VT_STAMP_AT(i)
 #endif
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0, bool BT = false>
 struct GemmCfg {
     // K-chunk depth of this configuration (k per barrier): 32 by default; 64 for the tiles whose chunk holds few
     // MFMAs per wave (M = 64 step kernels: 8 per chunk at 32), where the per-chunk barrier and waits dominate
@@ -172,8 +173,13 @@ struct GemmCfg {
     static constexpr int ZS = 4 * CG + 4;                    // GW gate-exchange image: floats per row
     static constexpr int SB = (BN % 32 == 16) ? BN : BN + 16;
     static constexpr int A4 = (BM * KQ + NTL - 1) / NTL;       // float4 per loader thread per chunk
-    static constexpr int B4 = (BK * (BN / 4) + NTL - 1) / NTL;
-    static constexpr int LOOP_FLOATS = 2 * (ABUF + BK * SB);
+    // BT: the W operand is stored transposed, W^T[n][k] with k contiguous (the backward data-gradient products
+    // dY . W^T read the forward weight matrix as it lies): it is loaded, stored and read exactly like A -- float4s
+    // along k, four k % 4 planes [n][k / 4] with the row swizzle, one ds_read_b128 per four k-steps
+    static constexpr int BITEMS = BT ? BN * KQ : BK * (BN / 4);   // float4 items of one B chunk
+    static constexpr int B4 = (BITEMS + NTL - 1) / NTL;
+    static constexpr int BBUF = BT ? 4 * BN * KQ : BK * SB;       // floats per B stage
+    static constexpr int LOOP_FLOATS = 2 * (ABUF + BBUF);
     static constexpr int LDS_FLOATS = (GW && BM * ZS > LOOP_FLOATS) ? BM * ZS : LOOP_FLOATS;
     // Prefetch ring depth (chunks in flight per thread), from a register budget: small tiles (few accumulators) get a
     // deeper ring, big tiles run two workgroups per CU and keep two chunks.
@@ -183,18 +189,19 @@ struct GemmCfg {
     static constexpr int PF_RAW = (PW > 0 ? 2 : 1) * S2VT_PF_BUDGET / (4 * (A4 + B4));   // loader waves hold no accumulators
     static constexpr int PF = PF_RAW < 2 ? 2 : (PF_RAW > 6 ? 6 : PF_RAW);
     static_assert(NG4 == 2 || NG4 == 4, "A planes: two or four b128 groups per row");
+    static_assert(!BT || (EPI == EPI_STORE && NG == 1 && PW == 0), "transposed-W form: plain store tiles only");
     static_assert(GW || TN % NG == 0, "TN must split evenly over the column groups");
     static_assert(!GW || (WN == 4 && NG == 4), "gate-per-wave needs four waves along N");
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0, bool BT = false>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArgs g)
 {
-    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, BKT, PW>;
+    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, BKT, PW, BT>;
     constexpr int BK = Cfg::BK, KQ = Cfg::KQ, RS = Cfg::RS, PL = Cfg::PL, ABUF = Cfg::ABUF;   // (BK shadows the namespace-scope default)
     constexpr int NG4 = Cfg::NG4, SWZ_SHIFT = Cfg::SWZ_SHIFT;
     constexpr int NT = Cfg::NT, NTL = Cfg::NTL, NCW = WM * WN, BM = Cfg::BM, BN = Cfg::BN, TNG = Cfg::TNG, CG = Cfg::CG, SB = Cfg::SB;
-    constexpr int A4 = Cfg::A4, B4 = Cfg::B4;
+    constexpr int A4 = Cfg::A4, B4 = Cfg::B4, BITEMS = Cfg::BITEMS, BBUF = Cfg::BBUF, PLB = BN * KQ;
     constexpr int PF = Cfg::PF;
 
 #ifdef S2VT_STAMP
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][4][BM][RS]
-    float* Bs = smem + 2 * ABUF;            // [2][BK][SB]
+    float* Bs = smem + 2 * ABUF;            // [2][BK][SB]  (BT: [2][4][BN][KQ] planes, as A)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -379,12 +386,21 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
         d[3 * PL] = v[3];
     };
     auto b_store = [&](int buf, int idx, const f32x4& v) __attribute__((always_inline)) {
-        *reinterpret_cast<f32x4*>(Bs + buf * BK * SB + (idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4) = v;
+        if constexpr (BT) {
+            const int r = idx / KQ, kq = idx % KQ;
+            float* d = Bs + buf * BBUF + r * KQ + (((kq >> 2) ^ ((r >> SWZ_SHIFT) & (NG4 - 1))) << 2) + (kq & 3);
+            d[0] = v[0];
+            d[PLB] = v[1];
+            d[2 * PLB] = v[2];
+            d[3 * PLB] = v[3];
+        } else {
+            *reinterpret_cast<f32x4*>(Bs + buf * BBUF + (idx / (BN / 4)) * SB + (idx % (BN / 4)) * 4) = v;
+        }
     };
     // this lane's fragment bases inside a stage
     const int a_frag = lq * PL + ((wm * TM) * 16 + l15) * RS;
     const int a_swz = (l15 >> SWZ_SHIFT) & (NG4 - 1);    // swz(row) of every fragment row of this lane (rows differ by multiples of 16)
-    const int b_frag = lq * SB + l15;
+    const int b_frag = BT ? lq * PLB + l15 * KQ : lq * SB + l15;
     auto b_col = [&](int j) __attribute__((always_inline)) { return Cfg::GW ? wn * CG + j * 16 : (j / TNG) * CG + (wn * TNG + j % TNG) * 16; };
 
     if constexpr (VEC) {
@@ -412,12 +428,19 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
         for (int i = 0; i < B4; ++i) {
             const int idx = ltid + i * NTL;
-            const int kr = idx / (BN / 4);
-            const int col = (idx % (BN / 4)) * 4;
-            const int grp = col / CG, cc = n0 + col % CG;
-            const bool ok = (B4 * NTL == BK * (BN / 4) || idx < BK * (BN / 4)) && cc < g.N;
-            bvo[i] = ok ? (uint32_t)(kr * g.ldw + grp * g.gstride + cc) * 4u : kOob;
-            bkr[i] = kr;
+            if constexpr (BT) {
+                const int cc = n0 + idx / KQ;                            // output column = row of W^T
+                const bool ok = (B4 * NTL == BITEMS || idx < BITEMS) && cc < g.N;
+                bvo[i] = ok ? (uint32_t)(cc * g.ldw + akq) * 4u : kOob;
+                bkr[i] = akq;                                            // first k of this lane's float4 within a chunk
+            } else {
+                const int kr = idx / (BN / 4);
+                const int col = (idx % (BN / 4)) * 4;
+                const int grp = col / CG, cc = n0 + col % CG;
+                const bool ok = (B4 * NTL == BITEMS || idx < BITEMS) && cc < g.N;
+                bvo[i] = ok ? (uint32_t)(kr * g.ldw + grp * g.gstride + cc) * 4u : kOob;
+                bkr[i] = kr;
+            }
         }
         // The walk of the NEXT chunk to issue, as loop-carried scalars: segment, rows of k left in it, byte offsets.
         // They advance by BK per chunk; only a segment change (rare, wave-uniform branch) re-selects the descriptor
@@ -438,7 +461,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                 krem_ = wseg_ == 0 ? slen0 : (wseg_ == 1 ? slen1 : slen2);                               \
                 const int kw_ = (wseg_ == 0 ? skw0 : (wseg_ == 1 ? skw1 : skw2)) + kbeg;                 \
                 soffA_ = 0u;                                                                             \
-                soffW_ = (uint32_t)kw_ * (uint32_t)g.ldw * 4u;                                           \
+                soffW_ = (uint32_t)kw_ * (BT ? 1u : (uint32_t)g.ldw) * 4u;                               \
                 _Pragma("unroll") for (int i_ = 0; i_ < A4; ++i_)                                        \
                     avo_[i_] = wseg_ == 0 ? avo0[i_] : (wseg_ == 1 ? avo1[i_] : avo2[i_]);               \
             } else {                                                                                     \
@@ -449,7 +472,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
         do {                                                                                             \
             krem_ -= BK;                                                                                 \
             soffA_ += (uint32_t)BK * 4u;                                                                 \
-            soffW_ += (uint32_t)BK * (uint32_t)g.ldw * 4u;                                               \
+            soffW_ += (uint32_t)BK * (BT ? 1u : (uint32_t)g.ldw) * 4u;                                   \
             if (krem_ <= 0 && wseg_ < 3) S2VT_WALK_ENTER();                                              \
         } while (0)
 #define S2VT_PIECE_ISSUE(P, SLOT)                                                                        \
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                 constexpr int i = P - A4;
                 pin(qb[i]);
                 const int idx = ltid + i * NTL;
-                if (B4 * NTL == BK * (BN / 4) || idx < BK * (BN / 4)) b_store(buf, idx, qb[i]);
+                if (B4 * NTL == BITEMS || idx < BITEMS) b_store(buf, idx, qb[i]);
             }
         };
         auto splice = [](int p) constexpr { return ((2 * p + 1) * HALF) / (2 * LPC); };   // MFMA after which piece p of a half goes
@@ -533,7 +556,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
             for (int c = 0; c < nchunks; ++c) {
                 const int buf = c & 1;
                 const float* a = As + buf * ABUF + a_frag;
-                const float* b = Bs + buf * BK * SB + b_frag;
+                const float* b = Bs + buf * BBUF + b_frag;
                 f32x4 a4[2][TM];
                 float bv[2][TN];
                 auto read_a = [&](auto g4_, f32x4 (&q)[TM]) __attribute__((always_inline)) {
@@ -590,9 +613,10 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                 if (more) {
                     const int buf = c & 1;
                     const float* a = As + buf * ABUF + a_frag;
-                    const float* b = Bs + buf * BK * SB + b_frag;
+                    const float* b = Bs + buf * BBUF + b_frag;
                     f32x4 a4[2][TM];
                     float bv[2][TN];
+                    f32x4 b4[2][TN];                                   // BT: B fragments in groups of four k-steps, like A
                     auto read_a = [&](auto g4_, f32x4 (&q)[TM]) __attribute__((always_inline)) {
                         constexpr int g4 = decltype(g4_)::value;
 #pragma unroll
@@ -603,15 +627,26 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
                         for (int jj = 0; jj < TN; ++jj) q[jj] = b[ks * 4 * SB + b_col(jj)];
                     };
+                    auto read_bg = [&](auto g4_, f32x4 (&q)[TN]) __attribute__((always_inline)) {
+                        constexpr int g4 = decltype(g4_)::value;
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj) q[jj] = *reinterpret_cast<const f32x4*>(b + b_col(jj) * KQ + ((g4 ^ a_swz) << 2));
+                    };
                     read_a(std::integral_constant<int, 0>{}, a4[0]);
-                    read_b(std::integral_constant<int, 0>{}, bv[0]);
+                    if constexpr (BT) read_bg(std::integral_constant<int, 0>{}, b4[0]);
+                    else read_b(std::integral_constant<int, 0>{}, bv[0]);
                     S2VT_STAMP_AT(1);                              // (dev build) top-of-chunk fragment latency
                     static_for<0, NM>([&](auto n_) {
                         constexpr int n = decltype(n_)::value, ks = n / MPK, r = n % MPK, i = r / TN, jj = r % TN;
                         if constexpr (r == 0) {
                             if constexpr (ks % 4 == 0 && ks / 4 + 1 < NG4)
                                 read_a(std::integral_constant<int, ks / 4 + 1>{}, a4[(ks / 4 + 1) & 1]);
-                            if constexpr (ks + 1 < KQ) read_b(std::integral_constant<int, ks + 1>{}, bv[(ks + 1) & 1]);
+                            if constexpr (BT) {
+                                if constexpr (ks % 4 == 0 && ks / 4 + 1 < NG4)
+                                    read_bg(std::integral_constant<int, ks / 4 + 1>{}, b4[(ks / 4 + 1) & 1]);
+                            } else if constexpr (ks + 1 < KQ) {
+                                read_b(std::integral_constant<int, ks + 1>{}, bv[(ks + 1) & 1]);
+                            }
                             if constexpr (ks + 1 < KQ) __builtin_amdgcn_sched_barrier(0);
                         }
                         if constexpr (n == HALF) {
@@ -619,7 +654,10 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                             wait_vmcnt<WAITN>();
                             S2VT_STAMP_AT(3);                      // ring wait
                         }
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+                        if constexpr (BT)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], b4[(ks / 4) & 1][jj][ks % 4], acc[i][jj], 0, 0, 0);
+                        else
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
                         static_for<0, LPC>([&](auto p_) {
                             constexpr int p = decltype(p_)::value;
                             if constexpr (splice(p) == n) S2VT_PIECE_ISSUE(p, j);
@@ -675,18 +713,31 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
             for (int i = 0; i < B4; ++i) {
                 const int idx = ltid + i * NTL;
-                const int kr = idx / (BN / 4);
-                const int col = (idx % (BN / 4)) * 4;
-                const int grp = col / CG, cc = n0 + col % CG;
-                const int k = koff + kr;
-                const bool kok = (B4 * NTL == BK * (BN / 4) || idx < BK * (BN / 4)) && k < sk;
-                const float* wrow = g.W + (size_t)(kw + (kok ? k : 0)) * g.ldw + grp * g.gstride;
                 f32x4 v;
+                if constexpr (BT) {
+                    const int cc = n0 + idx / KQ;
+                    const int k = koff + (idx % KQ) * 4;
+                    const bool rok = (B4 * NTL == BITEMS || idx < BITEMS) && cc < g.N;
+                    const float* wrow = g.W + (size_t)(rok ? cc : 0) * g.ldw + kw;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool ok = kok && cc + e < g.N;
-                    const float x = wrow[ok ? cc + e : 0];
-                    v[e] = ok ? x : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = rok && k + e < sk;
+                        const float x = wrow[ok ? k + e : 0];
+                        v[e] = ok ? x : 0.f;
+                    }
+                } else {
+                    const int kr = idx / (BN / 4);
+                    const int col = (idx % (BN / 4)) * 4;
+                    const int grp = col / CG, cc = n0 + col % CG;
+                    const int k = koff + kr;
+                    const bool kok = (B4 * NTL == BITEMS || idx < BITEMS) && k < sk;
+                    const float* wrow = g.W + (size_t)(kw + (kok ? k : 0)) * g.ldw + grp * g.gstride;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool ok = kok && cc + e < g.N;
+                        const float x = wrow[ok ? cc + e : 0];
+                        v[e] = ok ? x : 0.f;
+                    }
                 }
                 qb[i] = v;
             }
@@ -712,7 +763,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
                 for (int i = 0; i < B4; ++i) {
                     const int idx = ltid + i * NTL;
-                    if (B4 * NTL == BK * (BN / 4) || idx < BK * (BN / 4)) b_store(0, idx, rb[0][i]);
+                    if (B4 * NTL == BITEMS || idx < BITEMS) b_store(0, idx, rb[0][i]);
                 }
             }
             __syncthreads();
@@ -725,7 +776,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
                 for (int i = 0; i < TM; ++i) av[i] = a[i * 16 * RS + ((((ks >> 2) ^ a_swz) << 2) | (ks & 3))];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bw[j] = b[ks * 4 * SB + b_col(j)];
+                for (int j = 0; j < TN; ++j)
+                    bw[j] = BT ? b[b_col(j) * KQ + ((((ks >> 2) ^ a_swz) << 2) | (ks & 3))] : b[ks * 4 * SB + b_col(j)];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -28,8 +28,7 @@ struct TrainWs {
     float *emb, *Xp1;
     int32_t *prev, *tgt, *encidx;
     float *G1, *C1, *H1, *O1, *G2, *C2, *H2, *O2;
-    float *WoutT, *W2T, *W1T, *dO2, *dZ1, *dZ2, *dX2, *dX1, *dH1, *slab, *dc;
-    float* WencT;        // [E, D] transposed frame embedding, only touched by s2vt_bptt_dvideo
+    float *dO2, *dZ1, *dZ2, *dX2, *dX1, *dH1, *slab, *dc;
     int32_t* decidx;     // inverse of encidx: row of dX1 (time-major) for row j*Tv + t of d_video
 };
 
@@ -56,7 +55,7 @@ SlabPlan slab_plan(int M, int H)
 
 size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
 {
-    const size_t H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
+    const size_t H = d->lstm_dim, E = d->word_dim, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
     const size_t T = Tv + Tc, n = N, b = B;
     TrainWs w;
     w.emb = c.take<float>(b * Tv * E);
@@ -66,12 +65,11 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.O1 = c.take<float>(T * n * H);
     w.G2 = c.take<float>(T * n * 4 * H); w.C2 = c.take<float>((T + 1) * n * H); w.H2 = c.take<float>((T + 1) * n * H);
     w.O2 = c.take<float>(T * n * H);
-    w.WoutT = c.take<float>(V * H); w.W2T = c.take<float>(4 * H * (2 * H + E)); w.W1T = c.take<float>(4 * H * (E + H));
     w.dO2 = c.take<float>(Tc * n * H);
     w.dZ1 = c.take<float>(T * b * 4 * H); w.dZ2 = c.take<float>(T * n * 4 * H);
     w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * b * E); w.dH1 = c.take<float>(T * b * H);
     w.slab = c.take<float>((size_t)kMaxSlabs * n * H); w.dc = c.take<float>(n * H);
-    w.WencT = c.take<float>((size_t)d->dim_image * E); w.decidx = c.take<int32_t>(Tv * b);
+    w.decidx = c.take<int32_t>(Tv * b);
     if (out) *out = w;
     return c.off;
 }
@@ -114,15 +112,16 @@ bool params_ok(const s2vt_params* p)
            p->embed_word_W && p->embed_word_b;
 }
 
-// order-free NN product for the backward data path: C[s] = A[:, Ks] @ W[Ks, :]  (split-K slabs)
-hipError_t nn_bwd(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int splits,
+// order-free product for the backward data path: C[s] = A[:, Ks] @ Wt[:, Ks]^T with Wt = the FORWARD weight block as it
+// lies in memory ([N rows][K columns], row stride ldw) -- no transposed copies (split-K slabs when splits > 1)
+hipError_t nn_bwd(const float* A, int lda, const float* Wt, int ldw, float* C, int ldc, int M, int N, int K, int splits,
                   size_t slab_stride, hipStream_t st)
 {
     GemmArgs a;
     std::memset(&a, 0, sizeof(a));
     a.seg[0] = make_seg(A, lda, K, 0);
     a.nseg = 1;
-    a.W = W; a.ldw = ldw; a.M = M; a.N = N; a.C = C; a.ldc = ldc;
+    a.W = Wt; a.ldw = ldw; a.M = M; a.N = N; a.C = C; a.ldc = ldc;
     if (splits > 1) {
         a.splits = splits;
         a.kper = ((K + splits - 1) / splits + BK - 1) / BK * BK;
@@ -130,7 +129,7 @@ hipError_t nn_bwd(const float* A, int lda, const float* W, int ldw, float* C, in
         a.slab_stride = slab_stride;
     }
     static const int cfg_ = [] { const char* e = getenv("S2VT_SLAB_CFG"); return e ? atoi(e) : -1; }();     // dev knob
-    return launch_gemm(a, EPI_STORE, splits > 1 ? cfg_ : -1, st);
+    return launch_gemm(a, EPI_STORE_NT, splits > 1 ? cfg_ : -1, st);
 }
 
 }  // namespace
@@ -268,7 +267,6 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
     if (!c.ok()) return S2VT_E_WORKSPACE;
     hipStream_t st = S(stream);
     const size_t NH = (size_t)N * H;
-    const int K2 = 2 * H + E, K1 = E + H;
 
     // Phases, for data-parallel callers that start a slice's all-reduce as soon as its gradients are final:
     //   1 = the vocab projection (embed_word_W / _b final);  3 = LSTM2's recurrence + its weight gradients (lstm2_W / _b
@@ -284,13 +282,10 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         TnArgs a{w.O2 + (size_t)Tv * NH, nullptr, H, dlogits, V, grads->embed_word_W, V, Tc * N, H, V, 1};
         HIP_TRY(launch_gemm_tn(a, sv));
         HIP_TRY(launch_colsum(dlogits, V, Tc * N, V, grads->embed_word_b, sv));
-        HIP_TRY(launch_transpose(p->embed_word_W, V, w.WoutT, H, H, V, st));
-        HIP_TRY(nn_bwd(dlogits, V, w.WoutT, H, w.dO2, H, Tc * N, H, V, 1, 0, st));
+        HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2, H, Tc * N, H, V, 1, 0, st));
     }
     const SlabPlan sp2 = slab_plan(N, H), sp1 = slab_plan(B, H);
     if (do_l2) {
-    HIP_TRY(launch_transpose(p->lstm2_W, 4 * H, w.W2T, K2, K2, 4 * H, st));
-    HIP_TRY(launch_transpose(p->lstm1_W, 4 * H, w.W1T, K1, K1, 4 * H, st));
     // ---- LSTM2 back through time
     for (int t = T - 1; t >= 0; --t) {
         HIP_TRY(launch_lstm_bwd_pointwise(w.G2 + (size_t)t * 4 * NH, w.C2 + (t + 1) * NH, w.C2 + t * NH,
@@ -299,7 +294,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                                           w.dc, w.dZ2 + (size_t)t * 4 * NH, N, H, keep, seed, 512u + (uint32_t)t, video_id,
                                           sample_id, st));
         if (t > 0) {
-            HIP_TRY(nn_bwd(w.dZ2 + (size_t)t * 4 * NH, 4 * H, w.W2T + (H + E), K2, w.slab, H, N, H, 4 * H, sp2.splits, NH, st));
+            HIP_TRY(nn_bwd(w.dZ2 + (size_t)t * 4 * NH, 4 * H, p->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, w.slab, H, N, H, 4 * H, sp2.splits, NH, st));
         }
     }
     // dZ2 is complete: LSTM2's weight gradients go to the side stream, beside dX2 and LSTM1's recurrence
@@ -317,7 +312,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
     }
     if (!do_rest) return S2VT_OK;
     // d[out1 ; embed] for every step at once
-    HIP_TRY(nn_bwd(w.dZ2, 4 * H, w.W2T, K2, w.dX2, H + E, T * N, H + E, 4 * H, 1, 0, st));
+    HIP_TRY(nn_bwd(w.dZ2, 4 * H, p->lstm2_W, 4 * H, w.dX2, H + E, T * N, H + E, 4 * H, 1, 0, st));
     // ---- LSTM1 back through time, on the B per-video rows: the gradient w.r.t. its dropped output is
     // first reduced over the rep sample rows of each video (with their dropout masks)
     const size_t BH = (size_t)B * H;
@@ -327,9 +322,9 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                                           t == T - 1 ? nullptr : w.slab, sp1.nslab, BH, w.dH1 + t * BH, H,
                                           t == T - 1 ? nullptr : w.dc, w.dc, w.dZ1 + (size_t)t * 4 * BH, B, H, 1.0f, seed, 0u,
                                           nullptr, nullptr, st));
-        if (t > 0) HIP_TRY(nn_bwd(w.dZ1 + (size_t)t * 4 * BH, 4 * H, w.W1T + E, K1, w.slab, H, B, H, 4 * H, sp1.splits, BH, st));
+        if (t > 0) HIP_TRY(nn_bwd(w.dZ1 + (size_t)t * 4 * BH, 4 * H, p->lstm1_W + (size_t)E * 4 * H, 4 * H, w.slab, H, B, H, 4 * H, sp1.splits, BH, st));
     }
-    HIP_TRY(nn_bwd(w.dZ1, 4 * H, w.W1T, K1, w.dX1, E, Tv * B, E, 4 * H, 1, 0, st));
+    HIP_TRY(nn_bwd(w.dZ1, 4 * H, p->lstm1_W, 4 * H, w.dX1, E, Tv * B, E, 4 * H, 1, 0, st));
 
     // ---- remaining weight gradients: one contraction over all unrolled steps per weight block
     {
@@ -362,13 +357,12 @@ int s2vt_bptt_dvideo(const s2vt_dims* d, const s2vt_params* p, int32_t B, int32_
     // d_video[j*Tv + t, :] = dX1[t*B + j, :] @ encode_image_W^T   (dX1 is what s2vt_bptt_bwd left, time-major)
     hipLaunchKernelGGL(enc_index_kernel, dim3((B * Tv + 255) / 256), dim3(256), 0, st, w.decidx, Tv, B);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(launch_transpose(p->encode_image_W, E, w.WencT, D, D, E, st));
     GemmArgs a;
     std::memset(&a, 0, sizeof(a));
     a.seg[0] = make_seg(w.dX1, E, E, 0, 0, w.decidx);
     a.nseg = 1;
-    a.W = w.WencT; a.ldw = D; a.M = B * Tv; a.N = D; a.C = d_video; a.ldc = D;
-    HIP_TRY(launch_gemm(a, EPI_STORE, -1, st));
+    a.W = p->encode_image_W; a.ldw = E; a.M = B * Tv; a.N = D; a.C = d_video; a.ldc = D;       // encode_image_W [D][E] is W^T as it lies
+    HIP_TRY(launch_gemm(a, EPI_STORE_NT, -1, st));
     return S2VT_OK;
 }
 

@@ -82,6 +82,20 @@ def gemm(segs, W, bias=None, M=None, cinit=None, act_tanh=False, tile_cfg=-1, ou
     return out
 
 
+def gemm_nt(segs, Wt, bias=None, M=None, cinit=None, act_tanh=False, tile_cfg=-1, out=None):
+    """C = act([seg0 ; seg1 ; seg2] @ Wt^T + bias) with Wt [N, K] (K contiguous): the weight matrix as the backward reads it."""
+    _chk_f32(Wt, bias, cinit)
+    assert Wt.dim() == 2 and Wt.stride(1) == 1
+    N = Wt.shape[0]
+    arr = (Operand * len(segs))(*segs)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=Wt.device)
+    check(lib().s2vt_gemm_nt(arr, len(segs), _ptr(Wt), Wt.stride(0), _ptr(bias), _ptr(cinit),
+                             0 if cinit is None else cinit.stride(0), _ptr(out), out.stride(0), M, N, int(act_tanh), tile_cfg,
+                             _stream()), "s2vt_gemm_nt")
+    return out
+
+
 def lstm_cell_fwd(x0, x1, h_prev, c_prev, W, b, M, state_rowmod=0, keep=1.0, seed=0, video_id=None, sample_id=None,
                   drop_code=0, want_gates=False, tile_cfg=-1):
     _chk_f32(h_prev, c_prev, W, b)

@@ -173,3 +173,24 @@ def test_operand_beyond_the_2gib_window_uses_the_scalar_path(gpu, oracle):
     # the same rows packed densely take the vector path: identical bits
     C2 = gpu.gemm([gpu.operand(_dev(A))], _dev(W), None, M=M).cpu().numpy()
     assert np.array_equal(C2, ref)
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES + [(320, 4000, 1000), (100, 64, 36)])
+def test_gemm_nt_bitwise_all_tiles(gpu, oracle, M, K, N):
+    """C = A @ Wt^T with the weight given as [N, K] (the layout the backward data-gradient products read): the same
+    ascending-k chain as the plain form, on every tile configuration, vector and scalar paths, with segments."""
+    rng = np.random.default_rng(M * 31 + N)
+    A = rng.standard_normal((M, K)).astype(np.float32); Wt = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = oracle.bias_add(oracle.gemm_chain(A, np.ascontiguousarray(Wt.T)), b)
+    dA, dWt, db = _dev(A), _dev(Wt), _dev(b)
+    for cfg in range(-1, 8):
+        C = gpu.gemm_nt([gpu.operand(dA)], dWt, db, M=M, tile_cfg=cfg).cpu().numpy()
+        assert np.array_equal(C, ref), f"tile cfg {cfg}"
+    if K >= 8 and K % 8 == 0:                           # two K segments + a carried partial
+        k0 = K // 2
+        Ci = rng.standard_normal((M, N)).astype(np.float32)
+        ref2 = Ci.copy(); oracle.gemm_chain(A, np.ascontiguousarray(Wt.T), ref2)
+        segs = [gpu.operand(_dev(A[:, :k0])), gpu.operand(_dev(A[:, k0:]))]
+        C = gpu.gemm_nt(segs, dWt, None, M=M, cinit=_dev(Ci)).cpu().numpy()
+        assert np.array_equal(C, ref2)

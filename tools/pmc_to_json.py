@@ -8,14 +8,17 @@ src, dst = sys.argv[1], sys.argv[2]
 
 
 def prof_key(kname):
-    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+)>", kname)
+    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+), (true|false)>", kname)
     if m:
-        WM, WN, TM, TN, NG, EPI, _, BKT, PW = [int(x) if x.isdigit() else x for x in m.groups()]
+        WM, WN, TM, TN, NG, EPI, _, BKT, PW = [int(x) for x in m.groups()[:6]] + [0] + [int(x) for x in m.groups()[7:9]]
+        bt = m.groups()[9] == "true"
         sfx = (f"k{BKT}" if BKT != 32 else "") + (f"+{PW}" if PW else "")
         if EPI == 3:
             return f"1:gw{WM * TM * 16}x{TN * 16}u({WM}x{WN}){sfx}"
         if EPI == 1:
             return f"1:{WM * TM * 16}x{WN * (TN // 4) * 16}u({WM}x{WN}){sfx}"
+        if bt:
+            return f"4:nt{WM * TM * 16}x{WN * TN * 16}({WM}x{WN}){sfx}"
         return f"{EPI}:{WM * TM * 16}x{WN * TN * 16}({WM}x{WN}){sfx}"
     m = re.search(r"gemm_tn_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)>", kname)
     if m:
