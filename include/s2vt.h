@@ -20,9 +20,9 @@
  *     v_mfma_f32_16x16x4_f32, transcendental functions are fixed instruction sequences, sampling
  *     is Gumbel-max over Philox4x32-10 -- forward activations, logits and token ids are
  *     bit-identical to oracle/s2vt_oracle.c.  Gradients / reductions are order-free fp32.
- *   - Fast path: pointers 16-byte aligned, leading dimensions and K / N multiples of 4, and every operand within a
- *     2 GiB window of its base pointer (32-bit byte offsets; a gather table passed as rowidx / token ids must fit
- *     the window as well).  Anything else takes a scalar path with identical results.
+ *   - Fast path: pointers 16-byte aligned, leading dimensions and K / N multiples of 4.  Matrices may be any size
+ *     (operands are addressed per tile); a gather table passed as rowidx / token ids, a broadcast block (rowmod)
+ *     and the weight matrix must each fit a 2 GiB window.  Anything else takes a scalar path with identical results.
  */
 #ifndef S2VT_H
 #define S2VT_H

@@ -527,9 +527,9 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     }
     const bool vec = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0 && (a.lda & 3) == 0 &&
                      (a.ldb & 3) == 0 && (a.Kout & 3) == 0 && (a.N & 3) == 0 &&
-                     // the vector path addresses both operands by 32-bit byte offsets from their base (raw-buffer loads,
-                     // 2 GiB window); a gathered A must fit that window too (its extent is the caller's table)
-                     (a.rowidx != nullptr || (size_t)a.Mred * a.lda * 4 < (1ull << 31)) && (size_t)a.Mred * a.ldb * 4 < (1ull << 31);
+                     // the vector path addresses a chunk (32 rows) of each operand by 32-bit byte offsets from a base it
+                     // re-computes per chunk; a gathered A must fit a 2 GiB window (its extent is the caller's table)
+                     (size_t)32 * a.lda * 4 < (1ull << 31) && (size_t)32 * a.ldb * 4 < (1ull << 31);
     if (!prof_wants(3, ci)) {
         hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
         return hipGetLastError();

@@ -110,7 +110,7 @@ bool can_vec(const GemmArgs& a, bool bt)
         const ASeg& sg = a.seg[s];
         if (sg.kw + sg.k > (int)krows) krows = (size_t)(sg.kw + sg.k);
         if (!sg.ptr || sg.k <= 0 || sg.rowidx || sg.rowkey) continue;
-        const size_t rows = sg.rowmod > 0 ? (size_t)sg.rowmod : (size_t)a.M;
+        const size_t rows = sg.rowmod > 0 ? (size_t)sg.rowmod : 256;    // plain segments are addressed per tile (<= 256 rows)
         if (rows * sg.ld * 4 >= (1ull << 31)) return false;
     }
     if ((bt ? (size_t)a.N : krows) * a.ldw * 4 >= (1ull << 31)) return false;

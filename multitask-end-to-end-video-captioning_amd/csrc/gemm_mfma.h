@@ -337,9 +337,16 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
     // "s == 0 ? seg[0].f : ..." into a load through a selected ADDRESS, with the same effect.  For the same reason
     // every run-time selection between the per-segment locals below is written at KERNEL scope (macros), never
     // inside a lambda: between by-reference captures it becomes a load at a run-time offset into the closure.
-    const float* const sp0 = uniform(g.seg[0].ptr);
-    const float* const sp1 = uniform(g.seg[1].ptr);
-    const float* const sp2 = uniform(g.seg[2].ptr);
+    // A plain segment (no broadcast / gather) is addressed from the first row of THIS tile: the 32-bit offsets of the
+    // vector path then span BM rows, whatever the size of the matrix (a 71680 x 9972 logits gradient is 2.9 GB)
+    auto seg_base = [&](int i) __attribute__((always_inline)) -> const float* {
+        const ASeg& sg = g.seg[i];
+        const bool plain = sg.ptr && sg.rowmod <= 0 && !sg.rowidx && !sg.rowkey;
+        return uniform(plain ? sg.ptr + (size_t)m0 * sg.ld : sg.ptr);
+    };
+    const float* const sp0 = seg_base(0);
+    const float* const sp1 = seg_base(1);
+    const float* const sp2 = seg_base(2);
     const int skw0 = uniform(g.seg[0].kw), skw1 = uniform(g.seg[1].kw), skw2 = uniform(g.seg[2].kw);
     const int slen0 = uniform(seg_len(sp0, g.seg[0].k, 0)), slen1 = uniform(seg_len(sp1, g.seg[1].k, 1)),
               slen2 = uniform(seg_len(sp2, g.seg[2].k, 2));
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
             int m = m0 + idx / KQ;
             int off = -1;
             if (sl > 0 && idx >= 0 && idx < BM * KQ && m < g.M) {
+                if (rowmod <= 0 && !rowidx && !rowkey) m -= m0;          // plain segment: relative to the tile's first row (seg_base)
                 if (rowmod > 0) m %= rowmod;
                 if (rowidx) m = rowidx[m];
                 if (rowkey) m = (int)(~(uint32_t)rowkey[m]);

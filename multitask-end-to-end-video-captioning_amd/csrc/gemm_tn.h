@@ -129,7 +129,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
         // zeros from the bounds check, the per-lane offsets are loop-invariant unless A is gathered), then the
         // counted vmcnt wait, second half the LDS stores of chunk c+1; fragments are read one k-step ahead.
         constexpr int KS = BR / 4, MPK = TM * TN, NM = KS * MPK, HALF = NM / 2;
-        const i32x4 rsA = make_rsrc(g.A), rsB = make_rsrc(g.B);
+        // descriptors are re-based on the first row of every chunk (64-bit scalar add), so the 32-bit offsets span one
+        // chunk (32 rows) whatever the size of the matrices
+        i32x4 rsA = make_rsrc(g.rowidx ? g.A : g.A + (size_t)mbeg * g.lda), rsB = make_rsrc(g.B + (size_t)mbeg * g.ldb);
+        auto rebase = [](i32x4& r, uint32_t bytes) __attribute__((always_inline)) {
+            const uint64_t b = (((uint64_t)(uint32_t)r[1] << 32) | (uint32_t)r[0]) + bytes;
+            r[0] = (int)(uint32_t)b;
+            r[1] = (int)(uint32_t)(b >> 32);
+        };
         uint32_t avo[A4], bvo[B4];
         int ar[A4], br[B4];
 #pragma unroll
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
         }
         int mrem = mend - mbeg;                                          // rows left from the next chunk to issue
         int mnext = mbeg;
-        uint32_t soffA = g.rowidx ? 0u : (uint32_t)mbeg * (uint32_t)g.lda * 4u, soffB = (uint32_t)mbeg * (uint32_t)g.ldb * 4u;
+        const uint32_t stepA = g.rowidx ? 0u : (uint32_t)BR * (uint32_t)g.lda * 4u, stepB = (uint32_t)BR * (uint32_t)g.ldb * 4u;
         auto issue_piece = [&](auto p_, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
             constexpr int P = decltype(p_)::value;
             if constexpr (P < A4) {
@@ -159,17 +166,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
                     const bool in = ar[P] < mrem;
                     vo += (uint32_t)(in ? g.rowidx[mnext + ar[P]] : 0) * (uint32_t)g.lda * 4u;
                 }
-                bload16(qa[P], ar[P] < mrem ? vo : kOob, rsA, soffA);
+                bload16(qa[P], ar[P] < mrem ? vo : kOob, rsA, 0u);
             } else {
                 constexpr int i = P - A4;
-                bload16(qb[i], br[i] < mrem ? bvo[i] : kOob, rsB, soffB);
+                bload16(qb[i], br[i] < mrem ? bvo[i] : kOob, rsB, 0u);
             }
         };
         auto walk_next = [&]() __attribute__((always_inline)) {
             mrem -= BR;
             mnext += BR;
-            if (!g.rowidx) soffA += (uint32_t)BR * (uint32_t)g.lda * 4u;
-            soffB += (uint32_t)BR * (uint32_t)g.ldb * 4u;
+            rebase(rsA, stepA);
+            rebase(rsB, stepB);
         };
         auto land_piece = [&](int buf, auto p_, f32x4 (&qa)[A4], f32x4 (&qb)[B4]) __attribute__((always_inline)) {
             constexpr int P = decltype(p_)::value;

@@ -194,3 +194,28 @@ def test_gemm_nt_bitwise_all_tiles(gpu, oracle, M, K, N):
         segs = [gpu.operand(_dev(A[:, :k0])), gpu.operand(_dev(A[:, k0:]))]
         C = gpu.gemm_nt(segs, dWt, None, M=M, cinit=_dev(Ci)).cpu().numpy()
         assert np.array_equal(C, ref2)
+
+
+def test_operands_larger_than_2gib_on_the_vector_path(gpu, oracle):
+    """A 2.46 GB activation matrix (the reference's default B=256, K=8, Tc=35 makes a 2.9 GB logits gradient): the
+    forward contraction addresses it per tile and the weight-gradient contraction per chunk, so both stay on the vector
+    path and stay exact (rows beyond the 2 GiB mark included)."""
+    import torch
+    M, K, N = 300000, 2048, 32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(K, N, device="cuda", generator=g)
+    assert A.numel() * 4 > (1 << 31)
+    C = gpu.gemm([gpu.operand(A)], W, None, M=M)
+    Wh = W.cpu().numpy()
+    for lo in (0, 131072 - 8, 262144 - 8, M - 40):                       # around 1 GiB, 2 GiB and the end
+        rows = slice(lo, lo + 40)
+        ref = oracle.gemm_chain(A[rows].cpu().numpy(), Wh)
+        assert np.array_equal(C[rows].cpu().numpy(), ref), lo
+    # weight-gradient form: C2[k, n] = sum_m A[m, k] * B[m, n] over all 300000 rows (order-free: vs float64)
+    Bm = torch.randn(M, N, device="cuda", generator=g)
+    out = torch.zeros(K, N, device="cuda")
+    gpu.gemm_tn(A, Bm, out, accumulate=False)
+    ref2 = (A.double().t() @ Bm.double()).cpu().numpy()
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.abs(got - ref2).max() <= 2e-4 * np.abs(ref2).max()
