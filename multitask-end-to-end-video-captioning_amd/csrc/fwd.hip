@@ -145,6 +145,9 @@ int choose(const CfgEntry* t, int n, int M, int N, int splits = 1)
 // M = 64: 21 us (64x16u: 39), M = 320: 98 us at K = 2500 (64x16u: 125), M = 384: 102 us (137).
 int choose_lstm(int M)
 {
+    // beyond ~one workgroup per CU (M > 384: several row tiles per weight panel) 64- or 80-row tiles, whichever pads
+    // M less, beat the 96-row ones by 10-30 % (measured at M = 448 ... 2304: the reference's default batch is 2048 / 2304 rows)
+    if (M > 384) return ceil_div(M, 80) * 80 < ceil_div(M, 64) * 64 ? kLstmGw80L : kLstmGwFirst + 3;
     const int rows = ceil_div(ceil_div(M, 4), 16) * 16;       // 16, 32, ... rows per workgroup
     const int step = rows / 16;                                // 1..6 -> gw16 .. gw96
     if (step <= 1) return kLstmGw16k64;

@@ -31,3 +31,9 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / n
 print(f"B={B} K={K} Tc={Tc} V={V}: step {dt * 1e3:.1f} ms -> {K * B * Tc / dt:.0f} sampled tokens/s; loss {float(st.loss):.5f}; "
       f"grad norm {float(st.grad_sumsq.sqrt()):.4f}; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GB")
+from s2vt_amd import ops
+ops.prof_filter(-1, -1); ops.prof_enable(True)
+step(99); torch.cuda.synchronize()
+rows = ops.prof_collect(); ops.prof_enable(False)
+for r_ in sorted(rows, key=lambda r: -r["total_ms"]):
+    print(f"  class {r_['kernel_class']} {r_['name']:<22} launches {r_['launches']:4d}  ms {r_['total_ms']:8.3f}  {r_['total_flops'] / r_['total_ms'] / 1e9:6.1f} TF")
