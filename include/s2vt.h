@@ -335,8 +335,13 @@ int s2vt_dropout_bwd(const float* dout, int32_t ld, float* dh, int32_t M, int32_
                      uint32_t drop_code, const int32_t* video_id, const int32_t* sample_id, s2vt_stream stream);
 
 /* In-place SUM all-reduce of the flat gradient bucket over an existing RCCL communicator (ncclComm_t as
- * void*), on `stream`.  RCCL is resolved at run time; Python hosts use torch.distributed instead. */
+ * void*), on `stream` -- the exchange step of SURVEY.md section 8(e) for C/C++ hosts (Python hosts use
+ * torch.distributed).  The library never loads RCCL itself (a communicator belongs to the instance that made it):
+ * it calls, in this order, the entry point registered with s2vt_set_rccl_allreduce, a `ncclAllReduce` visible in the
+ * global symbol scope, or one from an already loaded librccl; S2VT_E_BADARG if there is none. */
 int s2vt_allreduce_grads(float* bucket, int64_t n, void* rccl_comm, s2vt_stream stream);
+/* Register the `ncclAllReduce` of the host's own RCCL (needed when it was loaded RTLD_LOCAL); NULL unregisters. */
+int s2vt_set_rccl_allreduce(void* nccl_allreduce_fn_ptr);
 
 #ifdef __cplusplus
 }

@@ -248,22 +248,33 @@ int s2vt_dropout_bwd(const float* dout, int32_t ld, float* dh, int32_t M, int32_
     return S2VT_OK;
 }
 
+// ncclAllReduce of the RCCL instance that OWNS the caller's communicator.  A communicator must never be handed to a
+// second copy of the library, so nothing is ever loaded here: (1) an entry point registered by the host
+// (s2vt_set_rccl_allreduce -- needed when the host loaded its RCCL with RTLD_LOCAL, as torch does), else (2) a symbol
+// already visible in the global scope, else (3) an ALREADY LOADED librccl (RTLD_NOLOAD), else an error.
+static std::atomic<void*> g_rccl_allreduce{nullptr};
+
+int s2vt_set_rccl_allreduce(void* nccl_allreduce_fn_ptr)
+{
+    g_rccl_allreduce.store(nccl_allreduce_fn_ptr);
+    return S2VT_OK;
+}
+
 int s2vt_allreduce_grads(float* bucket, int64_t n, void* rccl_comm, s2vt_stream stream)
 {
     if (!bucket || n < 0 || !rccl_comm) return S2VT_E_BADARG;
-    // RCCL is resolved at run time: the process that owns the communicator has it loaded already
-    // (torch ships its own copy); a C++ host links librccl itself.
-    static nccl_allreduce_fn fn = [] {
-        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
-        if (!sym) {
-            void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (lib) sym = dlsym(lib, "ncclAllReduce");
+    void* sym = g_rccl_allreduce.load();
+    if (!sym) sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    if (!sym) {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            void* lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (lib && (sym = dlsym(lib, "ncclAllReduce"))) break;
         }
-        return reinterpret_cast<nccl_allreduce_fn>(sym);
-    }();
-    if (!fn) return S2VT_E_BADARG;
-    const int rc = fn(bucket, bucket, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, rccl_comm, S(stream));
+    }
+    if (!sym) return S2VT_E_BADARG;              // no RCCL in this process: the communicator cannot be genuine
+    if (n == 0) return S2VT_OK;
+    // ncclDataType_t ncclFloat32 = 7, ncclRedOp_t ncclSum = 0 (rccl.h; part of the NCCL 2.x ABI)
+    const int rc = reinterpret_cast<nccl_allreduce_fn>(sym)(bucket, bucket, (size_t)n, 7, 0, rccl_comm, S(stream));
     return rc == 0 ? S2VT_OK : S2VT_E_HIP;
 }
 

@@ -37,13 +37,13 @@ def allreduce_bucket(grad_flat: torch.Tensor, n_params: int, local_mask_sum, gro
     """In place: grad_flat[:n_params] <- sum over ranks, returns the GLOBAL sum(mask) as a 1-element
     view of the bucket's tail slot (so one collective carries both)."""
     grad_flat[n_params] = local_mask_sum
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         _all_reduce_sum(grad_flat, group)
     return grad_flat[n_params:n_params + 1]
 
 
 def allreduce_small(t: torch.Tensor, group=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         _all_reduce_sum(t, group)
     return t
 
@@ -52,11 +52,24 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _forced() -> bool:
+    import os
+    return os.environ.get("S2VT_DP_FORCE", "0") == "1"
+
+
+def active(group=None) -> bool:
+    """True when the data-parallel exchange runs: more than one rank, or ONE rank with S2VT_DP_FORCE=1 -- which drives
+    the whole collective path (RCCL load, async handles, cross-stream ordering) on a single GPU (tests/test_gpu_rccl.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or _forced()
+
+
 def allreduce_async(t: torch.Tensor, group=None):
     """Start a SUM all-reduce of `t` (a contiguous slice of the gradient bucket) and return a handle whose
     .wait() orders the CURRENT stream after it -- under "nccl" (RCCL) the collective runs on the communicator's
     own stream, beside the kernels launched meanwhile; under "gloo" it is done synchronously (host staging)."""
-    if world_size(group) <= 1:
+    if not active(group):
         return None
     if t.is_cuda and dist.get_backend(group) == "gloo":
         _all_reduce_sum(t, group)

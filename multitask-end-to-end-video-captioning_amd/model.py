@@ -80,18 +80,42 @@ class ParamStore:
             if n in self.p:
                 self.p[n].copy_(torch.as_tensor(np.asarray(a)).to(self.p[n].device))
 
-    def state_dict(self):
-        """Checkpoint with the reference's TF variable names."""
-        return {TF_NAMES[n]: self.p[n].detach().cpu().numpy() for n in self.names}
+    def state_dict(self, global_step=None):
+        """Checkpoint with the reference's TF variable names.  With global_step given, also what tf.train.Saver stores
+        beside the variables (tf_s2vt.py:438, reinforcement_multisampling_tf_s2vt.py:661): the Adam slots
+        `<var>/Adam` (m), `<var>/Adam_1` (v), `beta1_power`, `beta2_power` and the step counter, so a resumed run
+        continues the moments, the bias correction and the learning-rate staircase."""
+        sd = {TF_NAMES[n]: self.p[n].detach().cpu().numpy() for n in self.names}
+        if global_step is not None:
+            for n in self.names:
+                sd[TF_NAMES[n] + "/Adam"] = self._view(self.m, n).detach().cpu().numpy()
+                sd[TF_NAMES[n] + "/Adam_1"] = self._view(self.v, n).detach().cpu().numpy()
+            sd["beta1_power"] = np.float32(0.9 ** (int(global_step) + 1))      # TF keeps beta^(t+1) after t applied steps
+            sd["beta2_power"] = np.float32(0.999 ** (int(global_step) + 1))
+            sd["global_step"] = np.int64(global_step)
+        return sd
 
     def load_state_dict(self, sd: dict):
-        """optimistic_restore: load every variable whose NAME and SHAPE match, ignore the rest."""
+        """optimistic_restore: load every variable whose NAME and SHAPE match, ignore the rest (Adam slots included).
+        Returns the loaded names; `self.restored_step` is the checkpoint's step counter or None."""
         inv = {v: k for k, v in TF_NAMES.items()}
         loaded = []
+        self.restored_step = None
+
+        def put(dst, arr):
+            dst.copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(dst.device))
         for name, arr in sd.items():
-            n = inv.get(name, name)
+            base, slot = name, None
+            for suffix in ("/Adam_1", "/Adam"):
+                if name.endswith(suffix):
+                    base, slot = name[:-len(suffix)], suffix
+                    break
+            n = inv.get(base, base)
             if n in self.p and tuple(np.shape(arr)) == tuple(self.shapes[n]):
-                self.p[n].copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(self.p[n].device))
+                put(self.p[n] if slot is None else self._view(self.m if slot == "/Adam" else self.v, n), arr)
+                loaded.append(name)
+            elif name in ("global_step", "g_step") and np.ndim(arr) == 0:
+                self.restored_step = int(arr)
                 loaded.append(name)
         return loaded
 
@@ -121,10 +145,14 @@ class Placeholder:
 
 
 class Output:
-    """A fetchable value: evaluated by Session.run from the fed placeholders."""
+    """A fetchable value: evaluated by Session.run from the fed placeholders.
+    provides: {other Output: key} -- values of OTHER fetches this one's evaluation yields as a by-product (a train_op
+    evaluates its loss on the way: sess.run([train_op, tf_loss]) is one pass, and the loss is the pre-update one, as in
+    TF where train_op depends on the loss node)."""
 
-    def __init__(self, name, fn, inputs):
+    def __init__(self, name, fn, inputs, provides=None):
         self.name, self.fn, self.inputs = name, fn, inputs
+        self.provides = provides or {}
 
     def __repr__(self):
         return f"<output {self.name}>"
@@ -141,13 +169,22 @@ class Session:
         single = not isinstance(fetches, (list, tuple))
         fl = [fetches] if single else list(fetches)
         feed = feed_dict or {}
-        cache = {}
-        out = []
-        for f in fl:
+        cache, given = {}, {}
+
+        def evaluate(f):
             key = id(f.fn)
             if key not in cache:
+                missing = [p.name for p in f.inputs if p not in feed]
+                if missing:
+                    raise KeyError(f"Session.run: fetch {f.name!r} needs a value for placeholder(s) {missing}")
                 cache[key] = f.fn(*[feed[p] for p in f.inputs])
-            out.append(cache[key][f.name])
+            return cache[key]
+        for f in fl:                                  # state-changing fetches first: what they yield for other fetches is
+            if f.provides:                            # the value those had when the update read them
+                res = evaluate(f)
+                for other, k in f.provides.items():
+                    given[id(other)] = res[k]
+        out = [given[id(f)] if id(f) in given else evaluate(f)[f.name] for f in fl]
         return out[0] if single else out
 
 
@@ -182,6 +219,8 @@ class Video_Caption_Generator:
         self.dropout_seed = seed + 1
         self.world_size = 1
         self.rank = 0
+        import os
+        self.dp_overlap = os.environ.get("S2VT_DP_OVERLAP", "0") == "1"
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._gscale = torch.ones(1, dtype=torch.float32, device=self.device)
         self._ascale = torch.ones(1, dtype=torch.float32, device=self.device)
@@ -197,13 +236,28 @@ class Video_Caption_Generator:
         sid = torch.arange(rep, dtype=torch.int32, device=self.device).repeat_interleave(B)
         return vid.contiguous(), sid.contiguous()
 
+    def _untile(self, v, N):
+        """The reference feeds build_loss the feature block tiled K times, rows k*B+j = video j
+        (reinforcement_multisampling_tf_s2vt.py:779-782).  Returns (the B distinct videos, B) when `v` is such a
+        tiling -- LSTM1 and the frame embedding then run once per video; any other [N, ...] block is N videos."""
+        K = self.multisample
+        if v.shape[0] == N and K > 1 and N % K == 0:
+            B = N // K
+            blocks = v.view(K, B, *v.shape[1:])
+            if bool((blocks == blocks[0]).all()):
+                return blocks[0].contiguous(), B
+        return v.contiguous(), v.shape[0]
+
     # -------------------------------------------------------------------------------- samplers
     def sample(self, video, K, with_greedy=True, seed=None, video_base=0):
         """K multinomial captions per video (+ the greedy caption): (sampled [K*B,Tc], greedy [B,Tc])
         int32 device tensors, sample-major rows.  One encode, no host round trip per step."""
         video = self._dev(video, torch.float32)
-        return ops.sample(self.dims, self.store.params, video, K, self.sample_seed if seed is None else seed, video_base,
-                          with_greedy)
+        out = ops.sample(self.dims, self.store.params, video, K, self.sample_seed if seed is None else seed, video_base,
+                         with_greedy)
+        ws, rows, serial = ops.sample.last_state[0], ops.sample.last_state[1], ops.sample.last_state[4]
+        self._sampler_state = (ws, rows, video, video._version, video.shape[0], self.global_step, serial)
+        return out
 
     def build_sampler(self):
         """Greedy sampler (tf_s2vt.py:217-266): returns (sampled_captions, video)."""
@@ -254,9 +308,15 @@ class Video_Caption_Generator:
         seed = self.dropout_seed + 104729 * self.global_step + 7 * getattr(self, "global_step_dropout_offset", 0)
         state = None
         if reuse_sampler_state:
-            ls = ops.sample.last_state
-            assert ls is not None and ls[2] == video.data_ptr() and ls[3] == B, \
-                "reuse_sampler_state needs a sample() call on this very video tensor right before the update"
+            ls = getattr(self, "_sampler_state", None)
+            # (workspace, rows, the video tensor itself, its version counter, B, weights version): the tensor is held,
+            # so its address cannot be recycled; an in-place write to it or an update of the variables in between
+            # makes the saved LSTM1 trajectory stale
+            ok = (ls is not None and ls[2] is video and ls[3] == video._version and ls[4] == B and ls[5] == self.global_step
+                  and ops.sample.last_state is not None and ops.sample.last_state[4] == ls[6])   # nobody sampled into the shared workspace since
+            if not ok:
+                raise RuntimeError("reuse_sampler_state needs model.sample() on this very video tensor, with the current "
+                                   "weights, as the last sampler call before the update")
             state = (ls[0], ls[1])
         logits, ws = ops.teacher_forced_fwd(self.dims, self.store.params, video, caption, N, keep, seed, vid, sid,
                                             sampler_state=state)
@@ -267,18 +327,23 @@ class Video_Caption_Generator:
         self._ctx = (video, N, logits, ws, keep, seed, vid, sid)
         return nll, lp
 
-    def backward(self, accumulate=False, overlap=True):
-        """BPTT into the flat gradient bucket (accumulate=True: on top of what a previous pass left there).  Data parallel:
-        the bucket is laid out [... lstm1_W | lstm2_W | embed_word_W | embed_word_b | ...]; the vocab-projection
-        gradients are final after phase 1 and LSTM2's after phase 3, so their all-reduces are started there and run
-        over xGMI beside the rest of the backward; apply_gradients() reduces what is left and waits for all of them."""
+    def backward(self, accumulate=False, overlap=None):
+        """BPTT into the flat gradient bucket (accumulate=True: on top of what a previous pass left there).  Data parallel,
+        overlap=True: the bucket is laid out [... lstm1_W | lstm2_W | embed_word_W | embed_word_b | ...]; the
+        vocab-projection gradients are final after phase 1 and LSTM2's after phase 3, so their all-reduces are started
+        there and run over xGMI beside the rest of the backward; apply_gradients() reduces what is left and waits for
+        all of them.  overlap=None takes the model default `self.dp_overlap` (env S2VT_DP_OVERLAP, default OFF = one
+        all-reduce of the whole bucket after the backward: the overlapped form has only been run on hardware with one
+        rank under RCCL, tests/test_gpu_rccl.py -- no multi-GPU box was available to the build)."""
+        if overlap is None:
+            overlap = self.dp_overlap
         video, N, dlogits, ws, keep, seed, vid, sid = self._ctx
         st = self.store
         if not accumulate:
             st.grad.zero_()
         self._pending = []
         self._early = None
-        if dp.world_size() > 1 and overlap:
+        if dp.active() and overlap:
             def span(first, last):
                 return st.offsets[first], st.offsets[last] + (int(np.prod(st.shapes[last])) + 63) // 64 * 64
             args = (self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid)
@@ -312,7 +377,7 @@ class Video_Caption_Generator:
         are decayed as well."""
         st = self.store
         early = getattr(self, "_early", None)
-        if early is not None and dp.world_size() > 1:
+        if early is not None and dp.active():
             lo, hi = early
             st.grad[st.numel] = mask_sum
             pend = getattr(self, "_pending", [])
@@ -337,6 +402,7 @@ class Video_Caption_Generator:
         if extra_sumsq is not None:
             self._sumsq += extra_sumsq(self._gscale)
         self.global_step += 1
+        self._sampler_state = None                 # the variables change: a saved sampler trajectory is stale from here on
         ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, self._sumsq, clip_norm, lr, self.global_step)
 
     def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
@@ -470,10 +536,58 @@ class Video_Caption_Generator:
             logits, _ = ops.teacher_forced_fwd(self.dims, self.store.params, v, c, c.shape[0], self.dropout_rate, seed, vid, sid)
             probs = logits.view(Tc, c.shape[0], -1).clone()
             nll, _ = ops.softmax_nll_fwd_bwd(logits, c.t().contiguous().view(-1), coef, 0.05)
-            wd = sum(0.5 * float((self.store.p[n] ** 2).sum()) for n in self.store.names if n not in UNDECAYED)
-            loss = float(torch.dot(coef, nll) / m.sum()) + self.decay_value * wd
+            th = self.store.theta[:self.store.n_decayed]        # every variable without 'bias' in its TF name (Q3); pad slots are 0
+            loss = float(torch.dot(coef, nll) / m.sum() + (0.5 * self.decay_value) * torch.dot(th, th))
             return {"loss": loss, "probs": probs.cpu().numpy()}
         return Output("loss", fn, [video, caption, caption_mask]), video, caption, caption_mask, Output("probs", fn, [video, caption, caption_mask])
+
+    # ---- the nodes the reference's train() adds around the model's graphs
+    def placeholder(self, name, shape=(None,), dtype=np.float32):
+        """tf.placeholder: `rewards` / `base_line` of reinforcement_multisampling_tf_s2vt.py:628-629."""
+        return Placeholder(name, shape, dtype)
+
+    def exponential_decay(self, start_learning_rate, decay_steps, decay_rate=0.5):
+        """tf.train.exponential_decay(lr, global_step, decay_steps, rate, staircase=True) on the model's own step counter
+        (tf_s2vt.py:440-441, reinforcement_multisampling_tf_s2vt.py:638-640): a fetch (sess.run(learning_rate))
+        with a .value() the train ops read."""
+        def value():
+            return float(start_learning_rate) * float(decay_rate) ** (self.global_step // int(decay_steps))
+        out = Output("learning_rate", lambda: {"learning_rate": value()}, [])
+        out.value = value
+        return out
+
+    def minimize(self, build_model_outputs, learning_rate, clip_norm=10.0):
+        """train_op of tf_s2vt.py:442-445: AdamOptimizer(learning_rate).compute_gradients(tf_loss) ->
+        clip_by_global_norm(10) -> apply_gradients(global_step).  `build_model_outputs` = the tuple build_model()
+        returned; sess.run([train_op, tf_loss], feed_dict={tf_video, tf_caption, tf_caption_mask}) is ONE update, and
+        the loss fetched beside it is the one the update differentiated (same dropout masks, pre-update weights)."""
+        loss, video, caption, caption_mask = build_model_outputs[:4]
+        lr = learning_rate.value if hasattr(learning_rate, "value") else (lambda: float(learning_rate))
+
+        def fn(v, c, m):
+            th = self.store.theta[:self.store.n_decayed]
+            wd = float((0.5 * self.decay_value) * torch.dot(th, th))           # the l2 term of tf_s2vt.py:163-166, pre-update
+            st = self.xe_update(v, c, m, lr(), clip_norm=clip_norm, q1=True, smoothing=0.05)
+            return {"train_op": None, "loss": float(st.loss) + wd}
+        return Output("train_op", fn, [video, caption, caption_mask], provides={loss: "loss"})
+
+    def reinforce_train_op(self, build_loss_outputs, rewards, base_line, learning_rate, clip_norm=5.0):
+        """(train_op, sum_loss) of reinforcement_multisampling_tf_s2vt.py:641-652:
+            norm = sum(loss_masks); sum_loss = -sum(loss * (rewards - base_line)) / norm;
+            clip_by_global_norm(tf.gradients(sum_loss), 5); Adam.apply_gradients(global_step).
+        Fed as there (:821-823): {loss_masks, loss_captions, loss_features (the K-times tiled block), rewards, base_line}."""
+        _, video, caption, caption_mask = build_loss_outputs
+        lr = learning_rate.value if hasattr(learning_rate, "value") else (lambda: float(learning_rate))
+
+        def fn(v, c, m, r, b):
+            v = self._dev(v, torch.float32)
+            c = self._dev(c, torch.int32)
+            v, _ = self._untile(v, c.shape[0])
+            st = self.reinforce_update(v, c, m, np.asarray(r, np.float32).reshape(-1), np.asarray(b, np.float32).reshape(-1), lr(),
+                                       clip_norm=clip_norm)
+            return {"train_op": None, "sum_loss": float(st.loss)}
+        inputs = [video, caption, caption_mask, rewards, base_line]
+        return Output("train_op", fn, inputs), Output("sum_loss", fn, inputs)
 
     def build_loss(self):
         """(loss, video, caption, caption_mask) as reinforcement_multisampling_tf_s2vt.py:227-292.
@@ -486,8 +600,7 @@ class Video_Caption_Generator:
 
         def fn(v, c, m):
             v = self._dev(v, torch.float32); c = self._dev(c, torch.int32); m = self._dev(m, torch.float32)
-            B = v.shape[0] // self.multisample if v.shape[0] == c.shape[0] else v.shape[0]
-            v = v[:B].contiguous()                                  # rows k*B+j repeat video j (:779-782)
+            v, B = self._untile(v, c.shape[0])
             vid, sid = self._row_ids(B, c.shape[0] // B, 0)
             seed = self.dropout_seed + 104729 * self.global_step
             logits, _ = ops.teacher_forced_fwd(self.dims, self.store.params, v, c, c.shape[0], self.dropout_rate, seed, vid, sid)

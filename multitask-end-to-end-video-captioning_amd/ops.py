@@ -159,11 +159,13 @@ def sample(dims: Dims, params: Params, video, K: int, seed: int, video_base: int
     ids = torch.empty(((K + g) * B, dims.n_caption_lstm_step), dtype=torch.int32, device=video.device)
     check(L.s2vt_sample(C.byref(dims), C.byref(params), _ptr(video), B, K, g, seed, video_base, _ptr(ids), _ptr(ws),
                         ws.numel(), _stream()), "s2vt_sample")
-    sample.last_state = (ws, (K + g) * B, video.data_ptr(), B)        # for teacher_forced_fwd(sampler_state=...)
+    sample.serial += 1                                                 # the workspace is shared by every caller: a later call overwrites it
+    sample.last_state = (ws, (K + g) * B, video.data_ptr(), B, sample.serial)   # for teacher_forced_fwd(sampler_state=...)
     return ids[:K * B], (ids[K * B:] if with_greedy else None)
 
 
 sample.last_state = None
+sample.serial = 0
 
 
 def train_workspace(dims: Dims, B: int, N: int, device):

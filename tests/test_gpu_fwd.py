@@ -37,6 +37,7 @@ def test_gumbel_stream_bitwise(gpu, oracle):
 
 SHAPES = [  # M, K, N
     (1, 1, 1), (3, 7, 5), (17, 33, 65), (64, 32, 64), (65, 100, 130), (5, 300, 259), (130, 96, 48), (200, 36, 20),
+    (200, 1000, 388),                                  # several row / column tiles of every configuration, vector path, ragged edges
 ]
 
 
@@ -48,7 +49,7 @@ def test_gemm_bitwise_all_tiles(gpu, oracle, M, K, N):
     b = rng.standard_normal(N).astype(np.float32)
     ref = oracle.bias_add(oracle.gemm_chain(A, W), b)
     dA, dW, db = _dev(A), _dev(W), _dev(b)
-    for cfg in range(-1, 5):
+    for cfg in range(-1, 8):                            # every entry of fwd.hip kStore (64x96, 96x96, 96x128 included)
         C = gpu.gemm([gpu.operand(dA)], dW, db, M=M, tile_cfg=cfg).cpu().numpy()
         assert np.array_equal(C, ref), f"tile cfg {cfg}"
     ref_t = oracle.det_tanh(ref)

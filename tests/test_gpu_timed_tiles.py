@@ -1,0 +1,157 @@
+"""Parity at the shapes bench.py actually times.
+
+The tile choosers (aux.hip launch_gemm_tn, fwd.hip choose / choose_lstm, train.hip slab_plan) pick different kernels
+at BASELINE sizes than at the toy sizes of test_gpu_train.py: the 128x128 / 64x128 weight-gradient tiles, the split-K
+slab products of the backward recurrences + the slab-summing pointwise kernel, the 96x96 / 128x128 store tiles.  Here
+every one of them is compared with float64 -- directly (weight-gradient contraction, with the selected tile read back
+from the in-library launch profiler) and through one full-size REINFORCE update (BASELINE configs[2]: B=64, K=5,
+Tc=20, |V|=12000) and one full-size XE update (configs[1]: B=64) whose loss and EVERY gradient tensor are compared
+with float64 autograd of oracle/s2vt_torch.py on the same inputs and the same Philox dropout masks.
+Tolerances (north_star / DESIGN.md §3): gradients 2e-4 of each tensor's largest entry, losses 1e-3.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+B, K, TC, TV, D, E, H, V = 64, 5, 20, 5, 1536, 500, 1000, 12000
+
+
+def _dev(a, dtype=None):
+    import torch
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _launched_tiles(gpu, fn):
+    """Run fn() with the in-library launch profiler on; return {(class, tile name): launches}."""
+    import torch
+    gpu.prof_filter(-1, -1)
+    gpu.prof_enable(True)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        gpu.prof_enable(False)
+    return out, {(r["kernel_class"], r["name"]): r["launches"] for r in gpu.prof_collect()}
+
+
+# Mred, Kout, N, gathered A, tile the launcher must select
+TN_SHAPES = [
+    (640, 1000, 12000, False, "tn128x128(2x2)"),      # the vocab-projection gradient's shape class (dominant kernel of the step)
+    (6400, 1000, 4000, False, "tn128x128(2x2)"),      # H1^T dZ1 / O1^T dZ2 class, deep reduction: split over blockIdx.y with atomics
+    (1000, 500, 4000, False, "tn64x128(2x2)"),        # emb^T dZ: 128 tiles of 128x128 < 200 -> 64x128
+    (320, 1536, 500, True, "tn64x64(2x2)"),           # frame-embedding gradient: gathered rows (encidx)
+    (777, 1000, 12000, True, "tn128x128(2x2)"),       # gathered + ragged reduction length
+]
+
+
+@pytest.mark.parametrize("Mred,Kout,N,gather,tile", TN_SHAPES)
+def test_weight_gradient_tiles_vs_float64(gpu, Mred, Kout, N, gather, tile):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(Mred + N)
+    rows = Mred + 50 if gather else Mred
+    A = torch.randn(rows, Kout, device="cuda", generator=g)
+    Bm = torch.randn(Mred, N, device="cuda", generator=g)
+    idx = torch.randint(0, rows, (Mred,), device="cuda", generator=g).int() if gather else None
+    C0 = torch.randn(Kout, N, device="cuda", generator=g)
+    Asel = A[idx.long()] if gather else A
+    ref = Asel.double().t() @ Bm.double()
+    scale = float(ref.abs().max())
+    for accumulate in (False, True):
+        out = C0.clone()
+        _, tiles = _launched_tiles(gpu, lambda: gpu.gemm_tn(A, Bm, out, accumulate=accumulate, rowidx=idx))
+        assert (3, tile) in tiles, tiles
+        want = ref + C0.double() if accumulate else ref
+        assert float((out.double() - want).abs().max()) <= 5e-5 * scale, (accumulate, tile)
+
+
+@pytest.fixture(scope="module")
+def fullsize(gpu, oracle):
+    import torch
+    from s2vt_amd import model as M
+    torch.set_num_threads(max(1, (torch.get_num_threads() or 1)))
+    mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, seed=1234, dropout_rate=0.9)
+    rng = np.random.default_rng(7)
+    for n in ("lstm1_b", "lstm2_b", "encode_image_b", "embed_word_b"):         # non-zero biases: every term of the graph is live
+        mdl.store.p[n].copy_(torch.as_tensor(rng.uniform(-.1, .1, mdl.store.shapes[n]).astype(np.float32)))
+    g = torch.Generator().manual_seed(1)
+    video = (torch.randn(B, TV, D, generator=g) * 0.5).abs()
+    return mdl, video
+
+
+def _ref_grads(mdl, video_rows, cap, vid, sid, keep, loss_fn, oracle):
+    """float64 autograd of the restated graph (oracle/s2vt_torch.py) with the product's dropout masks."""
+    import torch
+    from oracle import s2vt_torch as T
+    p = {n: mdl.store.p[n].cpu().numpy() for n in mdl.store.names}
+    dseed = mdl.dropout_seed + 104729 * mdl.global_step
+    drop = oracle.dropout_masks(dseed, vid, sid, keep, H, TV, TC)
+    pt = T.to_torch(p, torch.float64, True)
+    logits = T.teacher_forced(pt, torch.as_tensor(video_rows).double(), cap, drop, keep)
+    loss = loss_fn(T, pt, logits)
+    loss.backward()
+    return float(loss.detach()), {k: v.grad.numpy() for k, v in pt.items()}
+
+
+def _compare(mdl, st, loss, ref_loss, ref_g):
+    assert abs(loss - ref_loss) <= 1e-3 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    gn = 0.0
+    for n in mdl.store.names:
+        g = mdl.store.g[n].cpu().numpy().astype(np.float64)
+        scale = np.abs(ref_g[n]).max() + 1e-30
+        err = np.abs(g - ref_g[n]).max()
+        assert err <= 2e-4 * scale, (n, err, scale)
+        gn += (ref_g[n] ** 2).sum()
+    assert abs(float(st.grad_sumsq) - gn) <= 1e-3 * gn
+
+
+def test_fullsize_reinforce_update_vs_float64_autograd(gpu, oracle, fullsize):
+    """BASELINE configs[2]: one whole REINFORCE update at B=64, K=5, Tc=20, |V|=12000 (lr = 0), sampled captions from the
+    product's own sampler, sampler-state reuse ON as in bench.py.  Exercises tn128x128 / tn64x128, the split-K slab
+    products + slab-summing pointwise kernel at M=320 and M=64, the 96x96 / 128x128 store tiles and their W^T forms."""
+    import torch
+    from s2vt_amd import hostglue
+    mdl, video = fullsize
+    dv = video.cuda()
+    s, _ = mdl.sample(dv, K, True, seed=2024)
+    cap = s.cpu().numpy().astype(np.int32)
+    mask = hostglue.masks_from_ids(cap)
+    rng = np.random.default_rng(3)
+    r = (rng.random(K * B) * 2).astype(np.float32)
+    b = np.tile((rng.random(B) * 2).astype(np.float32), K)
+    vid = np.tile(np.arange(B, dtype=np.int32), K)
+    sid = np.repeat(np.arange(K, dtype=np.int32), B)
+    ref_loss, ref_g = _ref_grads(mdl, np.tile(video.numpy(), (K, 1, 1)), cap, vid, sid, 0.9,
+                                 lambda T, pt, lg: T.pg_loss(lg, cap, mask, r, b), oracle)
+    step0 = mdl.global_step
+    st, tiles = _launched_tiles(gpu, lambda: mdl.reinforce_update(dv, s, _dev(mask), r, b, lr=0.0, clip_norm=5.0,
+                                                                   reuse_sampler_state=True))
+    mdl.global_step = step0
+    for want in [(3, "tn128x128(2x2)"), (3, "tn64x128(2x2)")]:
+        assert want in tiles, tiles
+    assert any(c == 4 and n.startswith("nt64x32") for c, n in tiles) or any(c == 5 for c, n in tiles), tiles   # split-K slabs (or the persistent recurrence)
+    _compare(mdl, st, float(st.loss), ref_loss, ref_g)
+
+
+def test_fullsize_xe_update_vs_float64_autograd(gpu, oracle, fullsize):
+    """BASELINE configs[1]: XE train step at B=64, Tc=20, |V|=12000 (tf_s2vt.py:150-166 with Q1, label smoothing 0.05,
+    weight decay; lr = 0): loss and every gradient vs float64 autograd."""
+    import torch
+    from s2vt_amd import hostglue, model as M
+    mdl, video = fullsize
+    rng = np.random.default_rng(5)
+    ln = 1 + np.minimum(rng.poisson(6, B), TC - 2)                              # MSVD-like lengths
+    cap = rng.integers(2, V, (B, TC)).astype(np.int32)
+    for i in range(B):
+        cap[i, ln[i]:] = 0
+    mask = hostglue.masks_from_ids(cap)
+    vid = np.arange(B, dtype=np.int32); sid = np.zeros(B, np.int32)
+    ref_loss, ref_g = _ref_grads(mdl, video.numpy(), cap, vid, sid, 0.9,
+                                 lambda T, pt, lg: T.xe_loss(pt, lg, cap, mask, q1=True), oracle)
+    step0 = mdl.global_step
+    st = mdl.xe_update(video.cuda(), cap, mask, lr=0.0, clip_norm=10.0, q1=True)
+    mdl.global_step = step0
+    wd = sum(0.5 * float((mdl.store.p[n].double() ** 2).sum()) for n in mdl.store.names if n not in M.UNDECAYED)
+    _compare(mdl, st, float(st.loss) + mdl.decay_value * wd, ref_loss, ref_g)
