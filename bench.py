@@ -3,16 +3,22 @@
 REINFORCE step (BASELINE.json), B=64 per GPU, K=5 samples/video, Tc=20, Tv=5, d=1536, E=500,
 H=1000, |V|=12000, fp32, synthetic inputs already resident in HBM.
 
-One step = frame-embed + encode + K multinomial decodes + 1 greedy decode + PG mask (device) +
-teacher-forced forward on K*B rows with dropout + reward-scaled NLL + BPTT + (all-reduce) +
-global-norm clip + TF-form Adam -- the device work of reinforcement_multisampling_tf_s2vt.py:743-753
-and :823-826.  The reward (external CIDEr-D host code) is replaced by synthetic r, b.
+One step (default workload "rl", BASELINE configs[2]) = frame-embed + encode + K multinomial decodes + 1 greedy decode
++ PG mask (device) + teacher-forced forward on K*B rows with dropout + reward-scaled NLL + BPTT + (all-reduce) +
+global-norm clip + TF-form Adam -- the device work of reinforcement_multisampling_tf_s2vt.py:743-753 and :823-826.  The
+reward (external CIDEr-D host code) is replaced by synthetic r, b.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload rl|xe|multitask]
 N>1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce (weak scaling).
 Prints ONE JSON line on rank 0.
+
+Other single-GPU configurations of BASELINE.json (their own metric names; the default line is unchanged):
+  --workload xe         configs[1]: tf_s2vt.py XE train step, B=64 (label smoothing, Q1, weight decay, clip 10)
+  --workload multitask  configs[3] per-GPU shape: B=32 (256 / 8 GPUs), K=1, attribute-FC head (400 labels) + XE mix
+                        (lambda 0.5) + REINFORCE (reinforce_multitask_e2e_attribute_s2vt.py:850, ..._loss.py:957)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,10 +27,55 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B, K, TC, TV, D, E, H, V = 64, 5, 20, 5, 1536, 500, 1000, 12000
+TC, TV, D, E, H, V = 20, 5, 1536, 500, 1000, 12000
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-# SURVEY §8(d) algorithmic flops: F_seq = 7.68 + 5*28 + 20*52 MFLOP, (4K+1)*B sequence-forwards/step
-FLOPS_PER_STEP = (7.68e6 + 5 * 28e6 + 20 * 52e6) * (4 * K + 1) * B
+# SURVEY §8(d) algorithmic flops per sequence-forward: frame embed 7.68 + 5 encode steps x 28 + 20 decode steps x 52 MFLOP
+F_SEQ = 7.68e6 + 5 * 28e6 + 20 * 52e6
+WORKLOADS = {
+    # name: (B per GPU, K, sequence-forwards per step, tokens per step, metric, description)
+    "rl": dict(B=64, K=5, seqfwd=lambda B, K: (4 * K + 1) * B, tokens=lambda B, K: K * B * TC,
+               metric="sampled caption tokens/sec (REINFORCE step)",
+               desc="reinforcement_multisampling K=5 self-critical REINFORCE step (BASELINE configs[2]): B=64 per GPU, "
+                    "T_vid=5, T_cap=20, d=1536, E=500, H=1000, |V|=12000; synthetic rewards"),
+    "xe": dict(B=64, K=0, seqfwd=lambda B, K: 3 * B, tokens=lambda B, K: B * TC,
+               metric="caption tokens/sec (XE train step)",
+               desc="tf_s2vt XE train step (BASELINE configs[1]): B=64, T_vid=5, T_cap=20, d=1536, E=500, H=1000, |V|=12000; "
+                    "label smoothing 0.05, Q1 batch-mean CE, weight decay, clip 10; MSVD-like caption lengths"),
+    "multitask": dict(B=32, K=1, seqfwd=lambda B, K: 8 * B, tokens=lambda B, K: K * B * TC,
+                      metric="sampled caption tokens/sec (multitask REINFORCE step)",
+                      desc="multitask attribute-FC + XE mix + REINFORCE step, per-GPU shape of BASELINE configs[3]: B=32 "
+                           "(256 / 8 GPUs), K=1, 400 attribute labels, lambda=0.5, alpha=0.05, features precomputed"),
+}
+
+
+def kernel_signature():
+    """Hash of the kernel sources: profiles/*_pmc_traffic.json is stamped with it, and a stamp that does not match the
+    sources this run was built from means the stored HBM-traffic figure is stale -> `traffic: null`."""
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "multitask-end-to-end-video-captioning_amd", "csrc")
+    for f in sorted(os.listdir(cs)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(cs, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def stored_traffic(kernel_class, name):
+    """HBM bytes per launch of (class:tile) from the newest stamped PMC summary under profiles/ (2*FETCH_SIZE +
+    WRITE_SIZE, separate --pmc passes, tools/collect_pmc.sh), or None when there is none for THIS build of the kernels."""
+    prof = os.path.join(ROOT, "profiles")
+    sig = kernel_signature()
+    for f in sorted((x for x in os.listdir(prof) if x.endswith("_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(os.path.join(prof, f)))
+        except Exception:
+            continue
+        if d.get("_stamp", {}).get("kernel_signature") != sig:
+            continue
+        ent = d.get(f"{kernel_class}:{name}")
+        if ent:
+            return ent["bytes_per_launch"], f
+    return None, None
 
 
 def cpu_baseline():
@@ -33,10 +84,10 @@ def cpu_baseline():
     Bounded: a probe (one sampler pass = 1/26 of the step's flops) picks a thread count that is not
     pathological on many-core hosts, and the full step is only run when the probe predicts < 90 s;
     otherwise the probe itself is the sample and the rate is extrapolated by flops."""
-    import numpy as np
     import torch
     from oracle import s2vt_oracle as orc
     from oracle import s2vt_torch as T
+    B, K = 64, 5
     d = orc.Dims(D, V, E, H, TV, TC, 0)
     p = T.to_torch(orc.init_params(d, 1234), torch.float32, True)
     g = torch.Generator().manual_seed(1234)
@@ -76,13 +127,56 @@ def cpu_baseline():
                       f"{K}+1 sampler passes + fwd/bwd at {K * B} rows + clip + Adam, torch-CPU fp32, {cores} threads, {dt:.1f} s/step"}
 
 
+def make_step(workload, mdl, dev, rank, B, K):
+    """Synthetic inputs, resident in HBM, and the step closure of the workload."""
+    import numpy as np
+    import torch
+    g = torch.Generator().manual_seed(1234 + rank)                                        # per-rank data shard
+    video = (torch.randn(B, TV, D, generator=g) * 0.5).abs().to(dev)                      # post-ReLU IRv2 pool features
+    rewards = (torch.rand(max(K, 1) * B, generator=g) * 2).to(dev)
+    baseline = (torch.rand(B, generator=g) * 2).repeat(max(K, 1)).to(dev)
+
+    def pg_mask(s):
+        is_eos = (s == 0)
+        return ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()   # 1 up to and incl. first <eos>
+
+    if workload == "rl":
+        def step(i):
+            s, _greedy = mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
+            return mdl.reinforce_update(video, s, pg_mask(s), rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,
+                                        reuse_sampler_state=True)    # LSTM1 trajectory of the sampler pass (same videos, same weights)
+        return step
+    # ground-truth captions: length 1 + min(Poisson(6), Tc - 2) words (MSVD mean 7.03), tokens U{2..V-1}, then <eos> = 0
+    rng = np.random.default_rng(1234 + rank)
+    ln = 1 + np.minimum(rng.poisson(6, B), TC - 2)
+    cap = rng.integers(2, V, (B, TC)).astype(np.int32)
+    for j in range(B):
+        cap[j, ln[j]:] = 0
+    gt = torch.as_tensor(cap).to(dev)
+    gt_mask = pg_mask(gt)
+    if workload == "xe":
+        def step(i):
+            return mdl.xe_update(video, gt, gt_mask, lr=1e-3, clip_norm=10.0, q1=True, video_base=rank * B)
+        return step
+    labels = (torch.rand(B, mdl.label_dim, generator=g) < 0.02).float().to(dev)           # bag-of-words attribute labels, ~8 of 400 set
+
+    def step(i):
+        s, _greedy = mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
+        return mdl.mixed_update(video, s, pg_mask(s), rewards, baseline, gt, gt_mask, lr=1e-6, lambda_loss=0.5, clip_norm=5.0,
+                                video_base=rank * B, true_labels=labels)
+    return step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=150)      # ~2 s of GPU work at the default workload (SURVEY §8(d) asks >= 50 timed)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="rl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    B, K = wl["B"], wl["K"]
 
     import torch
     import torch.distributed as dist
@@ -106,23 +200,15 @@ def main():
     from s2vt_amd import ops
     s2vt_amd.lib()                                   # no fallback: raises if the HIP library is missing
 
-    mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, device=dev, seed=1234)     # identical replicas
+    multitask = args.workload == "multitask"
+    mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, device=dev, seed=1234, multisample=max(K, 1),
+                                    label_dim=400 if multitask else 0, alpha=0.05 if multitask else 0.0)   # identical replicas
     mdl.world_size, mdl.rank = world, rank
-    g = torch.Generator().manual_seed(1234 + rank)                                        # per-rank data shard
-    video = (torch.randn(B, TV, D, generator=g) * 0.5).abs().to(dev)                      # post-ReLU IRv2 pool features
-    rewards = (torch.rand(K * B, generator=g) * 2).to(dev)
-    baseline = (torch.rand(B, generator=g) * 2).repeat(K).to(dev)
-
-    def step(i):
-        s, _greedy = mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
-        is_eos = (s == 0)
-        mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()   # 1 up to and incl. first <eos>
-        return mdl.reinforce_update(video, s, mask, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,
-                                    reuse_sampler_state=True)    # LSTM1 trajectory of the sampler pass (same videos, same weights)
+    step = make_step(args.workload, mdl, dev, rank, B, K)
 
     # Warm-up: every contraction launch is bracketed by HIP events (in-library, on the launching stream) to get the
     # per-kernel table and find the dominant kernel; inside the timed region only THAT kernel keeps its events
-    # (two events per launch on all ~600 launches of a step cost ~10 % of the step).
+    # (two events per launch on all launches of a step cost ~10 % of the step).
     ops.prof_filter(-1, -1)
     ops.prof_enable(True)
     for i in range(args.warmup):
@@ -134,12 +220,16 @@ def main():
         ops.prof_filter(dom_w["kernel_class"], dom_w["tile_cfg"])
     else:
         ops.prof_filter(3, 0)          # --warmup 0: no table to pick from; the weight-gradient contraction (tn128x128) is the known dominant kernel
+    # per-step durations: one event per step boundary on the launching stream (negligible next to ~600 launches)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         st = step(args.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -155,36 +245,41 @@ def main():
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        value = K * B * TC * world * args.steps / dt
+        value = wl["tokens"](B, K) * world * args.steps / dt
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3) if per_step else None
+        flops_step = F_SEQ * wl["seqfwd"](B, K)
         dom = max(rows, key=lambda r: r["total_ms"]) if rows else None
         roof = None
         if dom:
             ach = dom["total_flops"] / (dom["total_ms"] * 1e-3) / 1e12
             cls = {0: "contraction+store", 1: "fused LSTM cell (4-gate GEMM + pointwise epilogue)", 2: "vocab logits + Gumbel-max pick",
-                   3: "weight-gradient TN contraction", 4: "contraction+store, W^T operand (backward data gradients)"}[dom["kernel_class"]]
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(pmc):
-                ent = json.load(open(pmc)).get(f"{dom['kernel_class']}:{dom['name']}")
-                traffic = ent["bytes_per_launch"] if ent else None        # HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, tools/collect_pmc.sh)
+                   3: "weight-gradient TN contraction", 4: "contraction+store, W^T operand (backward data gradients)",
+                   5: "persistent LSTM recurrence"}.get(dom["kernel_class"], "?")
+            traffic, traffic_src = stored_traffic(dom["kernel_class"], dom["name"])
+            # flops the contraction kernels actually executed per step (hoisting, LSTM1 once per video and sampler-state
+            # reuse execute fewer than the algorithmic count), from the warm-up table
+            executed = sum(r["total_flops"] for r in warm_rows) / max(args.warmup, 1) if warm_rows else None
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": f"{cls}, tile {dom['name']}", "launches": dom["launches"],
                     "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
                     "share_of_step": round(dom["total_ms"] / (dt * 1e3), 3),
-                    "whole_step_frac": round(FLOPS_PER_STEP * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "algorithmic_flops_per_step": flops_step,
+                    "whole_step_frac": round(flops_step * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "executed_flops_per_step": executed,
+                    "executed_flops_frac": round(executed * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if executed else None,
                     "all_kernels_warmup": [{"class": r["kernel_class"], "tile": r["name"], "launches": r["launches"],
                                             "ms": round(r["total_ms"], 2), "tflops": round(r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)}
                                            for r in sorted(warm_rows, key=lambda r: -r["total_ms"])]}
-        out = {"metric": "sampled caption tokens/sec (REINFORCE step)", "value": round(value, 1), "unit": "tokens/s",
+        out = {"metric": wl["metric"], "value": round(value, 1), "unit": "tokens/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+               "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "how": "HIP events per step on the launching stream"},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "reinforcement_multisampling K=5 self-critical REINFORCE step (BASELINE configs[2]): "
-                                      "B=64 per GPU, T_vid=5, T_cap=20, d=1536, E=500, H=1000, |V|=12000; synthetic rewards",
-                          "global_batch": B * world, "samples_per_video": K, "parallelism": f"dp{world}",
-                          "loss": float(st.loss)},
+               "config": {"workload": wl["desc"], "global_batch": B * world, "samples_per_video": K, "parallelism": f"dp{world}",
+                          "dp_overlap": bool(mdl.dp_overlap), "loss": float(st.loss)},
                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "rl":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

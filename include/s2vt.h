@@ -302,6 +302,12 @@ int s2vt_frame_embed_bwd(const s2vt_dims* d, const float* video, const float* d_
 int s2vt_lstm_cell_bwd(const float* gates, const float* c_new, const float* c_prev, const float* dh, const float* dc_in,
                        float* dz, float* dc_prev, int32_t M, int32_t H, s2vt_stream stream);
 
+/* ---- build_generator's word choice exactly as the reference writes it (tf_s2vt.py:208-209): p = exp(l) / sum(exp(l))
+ * WITHOUT a max shift, in fp32, then argmax (first maximum wins; NaN never wins; all-NaN -> 0).  A logit >= 88.72
+ * overflows to inf / inf = NaN and the choice becomes <eos> = 0 instead of argmax(l).  ids [R]; probs [R, V] or NULL. */
+int s2vt_softmax_unshifted_argmax(const float* logits, int32_t ld, int32_t R, int32_t V, int32_t* ids, float* probs,
+                                  s2vt_stream stream);
+
 /* ---- the two objectives by name.  s2vt_xent_smooth_fwd_bwd: tf.losses.softmax_cross_entropy with
  * label_smoothing (tf_s2vt.py:155).  s2vt_pg_nll_fwd_bwd: the reward-scaled NLL of
  * reinforcement_multisampling_tf_s2vt.py:286-291,643-646 -- coef[t*N+n] = adv[n] * mask[n,t] is formed on

@@ -10,7 +10,7 @@ the score of a finished caption is logprob / len**factor, unfinished ones compet
 """
 from __future__ import annotations
 
-import bisect
+import heapq
 
 import numpy as np
 import torch
@@ -19,36 +19,47 @@ from . import ops
 
 
 class Hypothesis:
-    """A partial caption: token ids so far, the LSTM2 state row it continues from, log-probability, ranking score."""
+    """A partial caption: token ids so far, the LSTM2 state row it continues from, log-probability, ranking score.
+    Ordered by score alone, like the reference's Caption (beam_search.py:24-42)."""
     __slots__ = ("sentence", "row", "logprob", "score")
 
     def __init__(self, sentence, row, logprob, score):
         self.sentence, self.row, self.logprob, self.score = sentence, row, logprob, score
 
+    def __lt__(self, other):
+        return self.score < other.score
+
+    def __eq__(self, other):
+        return self.score == other.score
+
+    __hash__ = None
+
 
 class BestK:
-    """The k best-scoring hypotheses seen so far (what the reference keeps in its TopN heaps, beam_search.py:44-80):
-    a score-sorted list with bisect insertion; on equal scores the earlier arrival ranks higher."""
+    """The k best-scoring hypotheses seen so far, with the reference's TopN semantics (beam_search.py:44-80) down to
+    the order among EQUAL scores: a binary min-heap of at most k items (push while not full, push-then-pop-smallest
+    once full), read out by a stable descending sort of the heap array.  Pinned by the push / extract traces in
+    tests/golden/beam_search.json, which were produced by the reference's own class."""
 
     def __init__(self, k):
-        self.k, self._neg, self._items = k, [], []
+        self.k, self._heap = k, []
 
     def size(self):
-        return len(self._items)
+        return len(self._heap)
 
     def push(self, h):
-        i = bisect.bisect_right(self._neg, -h.score)
-        if i >= self.k:
-            return
-        self._neg.insert(i, -h.score)
-        self._items.insert(i, h)
-        del self._neg[self.k:], self._items[self.k:]
+        if len(self._heap) < self.k:
+            heapq.heappush(self._heap, h)
+        else:
+            heapq.heappushpop(self._heap, h)
 
     def best_first(self):
-        return list(self._items)
+        out = list(self._heap)
+        out.sort(reverse=True)
+        return out
 
     def clear(self):
-        self._neg, self._items = [], []
+        self._heap = []
 
 
 class BeamSearchGenerator:
@@ -82,6 +93,25 @@ class BeamSearchGenerator:
         _, lp0 = ops.softmax_nll_fwd_bwd(logits.clone(), zero_t, torch.zeros(n, device=m.device), 0.0)   # lp0 = l[0] - lse
         lse = logits[:, 0] - lp0
         return c1, h1, c2, h2, top_i.cpu().numpy(), (top_l - lse[:, None]).cpu().numpy()
+
+    def generate_unshifted_softmax(self, video):
+        """build_generator with the word choice exactly as tf_s2vt.py:208-209 writes it -- argmax of exp(l) / sum(exp(l))
+        evaluated in fp32 WITHOUT a max shift -- instead of argmax(l): they differ when a logit overflows exp (>= 88.72:
+        inf / inf = NaN, the choice becomes <eos> = 0) or when exp rounds two close logits to the same probability.
+        Returns the Tc word ids (the reference's `break` at :212 never fires)."""
+        m = self.m
+        p, E = m.store.p, m.word_dim
+        video = m._dev(video, torch.float32).view(1, m.n_video_lstm_step, m.dim_image)
+        c1, h1, c2, h2 = self._encode(video)
+        word = torch.ones(1, dtype=torch.int32, device=m.device)                       # <bos>
+        ids = []
+        for _ in range(m.n_caption_lstm_step):
+            c1, h1, _, _ = ops.lstm_cell_fwd(ops.operand(None, k=E), None, h1, c1, p["lstm1_W"], p["lstm1_b"], 1)
+            c2, h2, _, _ = ops.lstm_cell_fwd(ops.operand(h1), ops.operand(p["Wemb"], rowidx=word), h2, c2, p["lstm2_W"], p["lstm2_b"], 1)
+            logits = ops.gemm([ops.operand(h2)], p["embed_word_W"], p["embed_word_b"], M=1)
+            word, _ = ops.softmax_unshifted_argmax(logits)
+            ids.append(word)
+        return torch.cat(ids).cpu().numpy().astype(np.int64)
 
     def generate(self, video):
         """video [1, Tv, d] -> (sentence ids, logprob, score) of the best caption."""

@@ -213,6 +213,58 @@ hipError_t launch_softmax_nll(float* logits, int ld, int R, int V, const int32_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// build_generator's word choice AS THE REFERENCE WRITES IT (tf_s2vt.py:208-209, the quirk switch of SURVEY A9):
+//   p = exp(l) / sum_n exp(l[n])   -- no max shift, fp32 --   then argmax(p), first maximum wins, NaN never wins.
+// A logit >= 88.72 overflows exp to +inf, the sum to +inf, that entry to inf/inf = NaN and every other to 0: the
+// result is index 0 (<eos>), not argmax(l).  Fixed summation order (the oracle restates it): thread t adds elements
+// t, t+256, ... ascending; xor-butterfly 32..1 inside each wave; then ((w0 + w1) + w2) + w3.  One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_unshifted_argmax_kernel(const float* logits, int ld, int V, int32_t* ids,
+                                                                       float* probs)
+{
+    __shared__ float shs[4];
+    __shared__ unsigned long long shk[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* l = logits + (size_t)row * ld;
+    float part = 0.f;
+    for (int i = tid; i < V; i += 256) part = part + dm_expf_ieee(l[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part = part + __shfl_xor(part, o, 64);
+    if ((tid & 63) == 0) shs[tid >> 6] = part;
+    __syncthreads();
+    const float total = ((shs[0] + shs[1]) + shs[2]) + shs[3];
+    // argmax over p >= 0 (or NaN): key = (bits of p) << 32 | ~index orders by value, then by LOWER index; NaN -> no key
+    unsigned long long best = 0ull;
+    for (int i = tid; i < V; i += 256) {
+        const float pv = dm_expf_ieee(l[i]) / total;
+        if (probs) probs[(size_t)row * V + i] = pv;
+        if (pv == pv) {
+            const unsigned long long k = ((unsigned long long)(__float_as_uint(pv + 0.0f) + 1u) << 32) | (uint32_t)(~(uint32_t)i);
+            best = k > best ? k : best;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_xor(best, o, 64);
+        best = ob > best ? ob : best;
+    }
+    if ((tid & 63) == 0) shk[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = shk[0];
+        for (int w = 1; w < 4; ++w) b = shk[w] > b ? shk[w] : b;
+        ids[row] = b == 0ull ? 0 : (int32_t)(~(uint32_t)b);     // every entry NaN: the reducer keeps its initial index 0
+    }
+}
+
+hipError_t launch_softmax_unshifted_argmax(const float* logits, int ld, int R, int V, int32_t* ids, float* probs, hipStream_t st)
+{
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(softmax_unshifted_argmax_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, ids, probs);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // BasicLSTMCell pointwise backward for one step (inverse of the EPI_LSTM epilogue):
 //   dh   = sum_s dh_rec[s] (split-K slabs of dz_{t+1} @ Whh^T) + dout_ext * keepmask / keep
 //   do~  = dh*tanh(c)*so*(1-so);  dc = dc_next + dh*so*(1-tanh(c)^2)

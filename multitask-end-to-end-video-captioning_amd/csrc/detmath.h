@@ -36,6 +36,32 @@ __device__ __forceinline__ float dm_expf(float x)
     return y * __uint_as_float((uint32_t)(ni + 127) << 23);
 }
 
+// exp(x) over the WHOLE fp32 range: same reduction and polynomial as dm_expf, no input clamp, the 2^n scaling applied in
+// two halves so that the result overflows to +inf / underflows to 0 exactly where IEEE fp32 does (x >= 128 ln 2 =
+// 88.7228...).  Only the reference's unshifted softmax (tf_s2vt.py:208-209, `exp(l) / sum(exp(l))`) needs this: there an
+// overflowing logit turns into inf / inf = NaN.
+__device__ __forceinline__ float dm_expf_ieee(float x)
+{
+    if (!(x < 89.0f)) return x != x ? x : __uint_as_float(0x7f800000u);
+    if (x < -104.0f) return 0.0f;
+    const float t = __builtin_fmaf(x, 1.44269504088896341f, 12582912.0f);
+    const float n = t - 12582912.0f;
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507E-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073E-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894E-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459E-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201E-1f);
+    const float rr = r * r;
+    float y = __builtin_fmaf(p, rr, r);
+    y = y + 1.0f;
+    const int ni = (int)n;
+    const int n1 = ni / 2, n2 = ni - n1;                        // |n1|, |n2| <= 76: both factors are normal numbers
+    return (y * __uint_as_float((uint32_t)(n1 + 127) << 23)) * __uint_as_float((uint32_t)(n2 + 127) << 23);
+}
+
 __device__ __forceinline__ float dm_logf(float x)
 {
     const uint32_t b = __float_as_uint(x);

@@ -242,6 +242,14 @@ int s2vt_softmax_nll_fwd_bwd(float* logits, int32_t ld, int32_t R, int32_t V, co
     return S2VT_OK;
 }
 
+int s2vt_softmax_unshifted_argmax(const float* logits, int32_t ld, int32_t R, int32_t V, int32_t* ids, float* probs,
+                                  s2vt_stream stream)
+{
+    if (!logits || !ids || R < 0 || V <= 0 || ld < V) return S2VT_E_BADARG;
+    HIP_TRY(launch_softmax_unshifted_argmax(logits, ld, R, V, ids, probs, S(stream)));
+    return S2VT_OK;
+}
+
 int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
                   int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                   const int32_t* sample_id, void* workspace, size_t workspace_bytes, s2vt_stream stream)

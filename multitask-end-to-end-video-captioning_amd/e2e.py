@@ -47,23 +47,35 @@ class EndToEnd:
             p.grad = self.grad[off:off + k].view_as(p)
             off += k
         self.params = params
-        self._gen = torch.Generator(device=dev)
 
     # ---------------------------------------------------------------- features
-    def extract(self, frames, dropout: bool, track: bool = False):
-        """frames [B, Tv, 3, H, W] fp32 in [-1, 1] -> (video [B, Tv, D] contiguous & detached, autograd handle or None)."""
+    def _feature_dropout(self, f, B, Tv, video_base, draw):
+        """slim.dropout(net, keep) on the pooled features [B*Tv, D] (e2e_tf_s2vt.py:120): (f / keep) * floor(keep + u), u from
+        the library's counter-based dropout stream keyed by (GLOBAL video index, frame, unit) -- so n ranks x B/n videos
+        apply the masks one rank x B would -- with one stream per step and per `draw` (the reference draws independent
+        masks in every graph that has the op: build_multinomial_sampler and build_loss do not share one)."""
+        dev = f.device
+        vid = (torch.arange(B, dtype=torch.int32, device=dev) + int(video_base)).repeat_interleave(Tv).contiguous()
+        frame = torch.arange(Tv, dtype=torch.int32, device=dev).repeat(B).contiguous()
+        seed = self.seed + 15485863 * (self.model.global_step + 1)
+        factor = ops.dropout_bwd(torch.ones_like(f), self.keep, seed, 768 + int(draw), vid, frame)     # = mask / keep
+        return f * factor
+
+    def extract(self, frames, dropout: bool, track: bool = False, video_base: int = 0, draws=(0,)):
+        """frames [B, Tv, 3, H, W] fp32 in [-1, 1] -> (video [B, Tv, D] contiguous & detached, autograd handle or None).
+        With several `draws` the CNN runs ONCE and one (video, handle) pair per independent dropout mask is returned."""
         B, Tv = frames.shape[:2]
         x = frames.to(self.model.device, torch.float32).reshape(B * Tv, *frames.shape[2:])
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
+        outs = []
         with torch.set_grad_enabled(track):
-            f = self.cnn(x)
-            if dropout and self.keep < 1.0:
-                self._gen.manual_seed(self.seed + 15485863 * (self.model.global_step + 1))
-                keepmask = torch.rand(f.shape, generator=self._gen, device=f.device) < self.keep
-                f = f * keepmask / self.keep
-            f = f.reshape(B, Tv, -1)
-        return f.detach().contiguous(), (f if track else None)
+            raw = self.cnn(x)
+            for d in draws:
+                f = self._feature_dropout(raw, B, Tv, video_base, d) if dropout and self.keep < 1.0 else raw
+                f = f.reshape(B, Tv, -1)
+                outs.append((f.detach().contiguous(), (f if track else None)))
+        return outs[0] if len(outs) == 1 else outs
 
     # ---------------------------------------------------------------- CNN half of the update
     def _cnn_grads(self, handle, weight_decay, with_attr):
@@ -91,7 +103,7 @@ class EndToEnd:
     def xe_step(self, frames, caption, caption_mask, lr, clip_norm=10.0, video_base=0):
         """One step of train() in e2e_tf_s2vt.py:482-700: label-smoothed XE through the CNN; weight decay on EVERY
         trainable variable (the always-true predicate at :199)."""
-        video, h = self.extract(frames, dropout=True, track=True)
+        video, h = self.extract(frames, dropout=True, track=True, video_base=video_base)
         st = self.model.xe_update(video, caption, caption_mask, lr, clip_norm=clip_norm, video_base=video_base,
                                   extra_sumsq=self._cnn_grads(h, self.model.decay_value, False), decay_all=True)
         self._cnn_apply(lr, clip_norm)
@@ -102,7 +114,8 @@ class EndToEnd:
         (OFF, :466) through the CNN, reward_fn(samples[K*B,Tc], greedy[B,Tc]) -> (r[K*B], b[B]) on the host, then the
         REINFORCE update through the CNN (dropout ON, :308), clip 10 over all variables, one Adam."""
         m = self.model
-        video_s, h = self.extract(frames, dropout=True, track=True)
+        # one CNN forward, two independent feature-dropout masks: the sampler's (:399) and the loss graph's (:308)
+        (video_s, _), (video_u, h) = self.extract(frames, dropout=True, track=True, video_base=video_base, draws=(0, 1))
         samples, _ = m.sample(video_s, K, False, seed=sample_seed, video_base=video_base)
         video_g, _ = self.extract(frames, dropout=False)
         _, greedy = m.sample(video_g, 0, True, video_base=video_base)
@@ -111,7 +124,7 @@ class EndToEnd:
         r, b = reward_fn(samples, greedy)
         r = torch.as_tensor(r, dtype=torch.float32)
         b = torch.as_tensor(b, dtype=torch.float32).repeat(K)
-        st = m.reinforce_update(video_s, samples, mask, r, b, lr, clip_norm=clip_norm, video_base=video_base,
+        st = m.reinforce_update(video_u, samples, mask, r, b, lr, clip_norm=clip_norm, video_base=video_base,
                                 true_labels=true_labels, extra_sumsq=self._cnn_grads(h, 0.0, true_labels is not None))
         self._cnn_apply(lr, clip_norm)
         st.samples, st.greedy = samples, greedy

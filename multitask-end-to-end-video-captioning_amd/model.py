@@ -280,22 +280,29 @@ class Video_Caption_Generator:
             return {"sampled_captions": s.cpu().numpy().astype(np.int64)}
         return Output("sampled_captions", fn, [video]), video
 
-    def build_generator(self, beam_size=1, length_normalization_factor=0.5):
+    def build_generator(self, beam_size=1, length_normalization_factor=0.5, unshifted_softmax=False):
         """B=1 greedy generator (tf_s2vt.py:169-214): (video, sentence, probs) where sentence is a
-        list of Tc scalar fetches (the reference's `break` at :212 never fires)."""
+        list of Tc scalar fetches (the reference's `break` at :212 never fires).
+        unshifted_softmax=True reproduces the reference's word choice to the letter: argmax of
+        exp(l) / sum(exp(l)) computed in fp32 without a max shift (:208-209) -- NaN, hence <eos>, once a logit
+        reaches 88.72; the default is argmax of the logits, which is what that expression means wherever it is finite."""
         video = Placeholder("video", (1, self.n_video_lstm_step, self.dim_image), np.float32)
+        Tc = self.n_caption_lstm_step
 
         def fn(v):
             if beam_size > 1:                    # final_beam_search.py:226-294 (B = 1, TopN beams)
                 from .beam_generator import BeamSearchGenerator
                 sent, _, _ = BeamSearchGenerator(self, beam_size, length_normalization_factor).generate(v)
-                ids = np.zeros(self.n_caption_lstm_step, np.int64)
-                ids[:len(sent)] = sent[:self.n_caption_lstm_step]
-                return {f"word_{t}": ids[t] for t in range(self.n_caption_lstm_step)}
-            _, g = self.sample(v, 0, True)
-            ids = g.cpu().numpy().astype(np.int64)[0]
-            return {f"word_{t}": ids[t] for t in range(self.n_caption_lstm_step)}
-        sentence = [Output(f"word_{t}", fn, [video]) for t in range(self.n_caption_lstm_step)]
+                ids = np.zeros(Tc, np.int64)
+                ids[:len(sent)] = sent[:Tc]
+            elif unshifted_softmax:
+                from .beam_generator import BeamSearchGenerator
+                ids = BeamSearchGenerator(self, 1).generate_unshifted_softmax(v)
+            else:
+                _, g = self.sample(v, 0, True)
+                ids = g.cpu().numpy().astype(np.int64)[0]
+            return {f"word_{t}": ids[t] for t in range(Tc)}
+        sentence = [Output(f"word_{t}", fn, [video]) for t in range(Tc)]
         return video, sentence, []
 
     # -------------------------------------------------------------------------------- training graphs
@@ -477,14 +484,16 @@ class Video_Caption_Generator:
         return StepStats(loss_local / msum, self._sumsq.clone(), msum)
 
     def mixed_update(self, video, sampled, mask, rewards, baseline, gt_caption, gt_mask, lr, lambda_loss=0.5, clip_norm=5.0,
-                     video_base=0, keep=None, q1=True, smoothing=0.05):
+                     video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None):
         """The mixed objective of reinforce_multitask_e2e_attribute_s2vt.py:850 (BASELINE configs[3]):
             sum_loss = -(1 - lambda) * PG / sum(mask_pg)  +  lambda * model_loss
         with PG the reward-scaled log-likelihood of the SAMPLED captions (build_loss) and model_loss the
         cross-entropy loss of build_model on the GROUND-TRUTH captions of the same videos (label smoothing, Q1,
         weight decay), clip 5, Adam.  Two teacher-forced passes accumulate into one gradient bucket, each with its
         coefficient already divided by its GLOBAL mask sum (one tiny all-reduce first), so the bucket needs no
-        further normalisation."""
+        further normalisation.  With true_labels [B, label_dim] (and a model built with label_dim > 0) the attribute head's
+        term of reinforce_multitask_e2e_attribute_loss.py:957 is added: + alpha * sum(bce) / (label_dim * B_global) --
+        the per-GPU shape of BASELINE configs[3] (attribute FC + XE mix + REINFORCE, K = 1)."""
         video = self._dev(video, torch.float32)
         cap = self._dev(sampled, torch.int32)
         mask = self._dev(mask, torch.float32)
@@ -516,9 +525,19 @@ class Video_Caption_Generator:
         self.global_step_dropout_offset = 0
         loss_xe = torch.dot(coef_xe, nll2)
         self.backward(accumulate=True, overlap=False)
+        attr_scale = attr_loss = None
+        if true_labels is not None and self.label_dim > 0:
+            y = self._dev(true_labels, torch.float32)
+            mean, z, bce = ops.attr_head_fwd(video, self.store.p["attr_W"], self.store.p["attr_b"], y)
+            dz = ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
+            attr_scale = self.alpha / float(self.label_dim * B * self.world_size)
+            self._attr_ctx = (dz, attr_scale)
+            attr_loss = bce.sum() * attr_scale
         one = torch.full((), 1.0 / self.world_size, device=self.device)   # the bucket is already normalised: global "sum(mask)" = 1
-        self.apply_gradients(one, lr, clip_norm, weight_decay=lam * self.decay_value)
-        return StepStats(loss_pg + loss_xe, self._sumsq.clone(), sums[0])
+        self.apply_gradients(one, lr, clip_norm, weight_decay=lam * self.decay_value, attr_scale=attr_scale)
+        st = StepStats(loss_pg + loss_xe, self._sumsq.clone(), sums[0])
+        st.attr_loss = attr_loss
+        return st
 
     def build_model(self):
         """(loss, video, caption, caption_mask, probs) as tf_s2vt.py:90-167.  Fetching `loss`

@@ -206,6 +206,17 @@ def softmax_nll_fwd_bwd(logits, target, coef, smoothing=0.0):
     return nll, lp
 
 
+def softmax_unshifted_argmax(logits, want_probs=False):
+    """tf_s2vt.py:208-209 as written: argmax(exp(l) / sum(exp(l))) in fp32 without a max shift (ids int32 [R], probs)."""
+    _chk_f32(logits)
+    R, V = logits.shape
+    ids = torch.empty(R, dtype=torch.int32, device=logits.device)
+    probs = torch.empty((R, V), dtype=torch.float32, device=logits.device) if want_probs else None
+    check(lib().s2vt_softmax_unshifted_argmax(_ptr(logits), logits.stride(0), R, V, _ptr(ids), _ptr(probs), _stream()),
+          "s2vt_softmax_unshifted_argmax")
+    return ids, probs
+
+
 def bptt_bwd(dims: Dims, params: Params, grads: Params, video, N: int, dlogits, ws, keep=1.0, seed=0, video_id=None,
              sample_id=None, phase=0):
     """phase 0 = the whole backward; 1 = vocab projection only; 2 = the rest (data-parallel overlap)."""

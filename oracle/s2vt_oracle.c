@@ -67,6 +67,30 @@ static inline float det_expf(float x)
     return y * u2f((uint32_t)(ni + 127) << 23);
 }
 
+/* exp(x) over the whole fp32 range (no clamp; 2^n applied in two halves so overflow / underflow happen where IEEE fp32
+ * puts them): used only by the reference's UNSHIFTED softmax, tf_s2vt.py:208-209. */
+static inline float det_expf_ieee(float x)
+{
+    if (!(x < 89.0f)) return x != x ? x : u2f(0x7f800000u);
+    if (x < -104.0f) return 0.0f;
+    const float t = fmaf(x, 1.44269504088896341f, 12582912.0f);
+    const float n = t - 12582912.0f;
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500E-4f;
+    p = fmaf(p, r, 1.3981999507E-3f);
+    p = fmaf(p, r, 8.3334519073E-3f);
+    p = fmaf(p, r, 4.1665795894E-2f);
+    p = fmaf(p, r, 1.6666665459E-1f);
+    p = fmaf(p, r, 5.0000001201E-1f);
+    const float rr = r * r;
+    float y = fmaf(p, rr, r);
+    y = y + 1.0f;
+    const int32_t ni = (int32_t)n;
+    const int32_t n1 = ni / 2, n2 = ni - n1;
+    return (y * u2f((uint32_t)(n1 + 127) << 23)) * u2f((uint32_t)(n2 + 127) << 23);
+}
+
 /* log(x) for normal x > 0, Cephes logf scheme. */
 static inline float det_logf(float x)
 {
@@ -334,6 +358,45 @@ ORC_API void orc_row_losses(const float* logits, int64_t ldl, int64_t M, int64_t
         if (nll) nll[m] = -acc;
         if (lp_target) lp_target[m] = l[target[m]] - lse;
         if (lse_out) lse_out[m] = lse;
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * build_generator's word choice as written (tf_s2vt.py:208-209): probs = exp(l) / reduce_sum(exp(l)) with NO max shift,
+ * then tf.argmax.  fp32; an overflowing logit gives inf / inf = NaN; argmax keeps the FIRST maximum and a NaN never
+ * compares greater, so an all-NaN / NaN-and-zeros row yields index 0.  The sum runs in the product kernel's fixed
+ * order (256 strided partial sums, xor butterfly inside each group of 64, then ((g0 + g1) + g2) + g3) so that the
+ * probabilities are comparable bit for bit.
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_softmax_unshifted_argmax(const float* logits, int64_t ldl, int64_t M, int64_t V, int32_t* ids, float* probs)
+{
+    for (int64_t m = 0; m < M; ++m) {
+        const float* l = logits + m * ldl;
+        float part[256];
+        for (int t = 0; t < 256; ++t) {
+            float s = 0.0f;
+            for (int64_t i = t; i < V; i += 256) s = s + det_expf_ieee(l[i]);
+            part[t] = s;
+        }
+        float grp[4];
+        for (int g = 0; g < 4; ++g) {
+            float a[64], b[64];
+            for (int i = 0; i < 64; ++i) a[i] = part[g * 64 + i];
+            for (int o = 32; o > 0; o >>= 1) {
+                for (int i = 0; i < 64; ++i) b[i] = a[i] + a[i ^ o];
+                for (int i = 0; i < 64; ++i) a[i] = b[i];
+            }
+            grp[g] = a[0];
+        }
+        const float total = ((grp[0] + grp[1]) + grp[2]) + grp[3];
+        int64_t best = 0;
+        float bestv = -3.402823466e+38f;
+        for (int64_t i = 0; i < V; ++i) {
+            const float pv = det_expf_ieee(l[i]) / total;
+            if (probs) probs[m * V + i] = pv;
+            if (pv > bestv) { bestv = pv; best = i; }
+        }
+        ids[m] = (int32_t)best;
     }
 }
 

@@ -158,6 +158,16 @@ def pick_tokens(logits, video_id, sample_id, step, seed):
     return tok
 
 
+def softmax_unshifted_argmax(logits, want_probs=False):
+    """tf_s2vt.py:208-209 as written: argmax(exp(l) / sum(exp(l))), fp32, no max shift (NaN on overflow -> index 0)."""
+    logits = _f32(logits)
+    M, V = logits.shape
+    ids = np.empty(M, np.int32)
+    probs = np.empty((M, V), np.float32) if want_probs else None
+    lib().orc_softmax_unshifted_argmax(_fp(logits), C.c_int64(V), C.c_int64(M), C.c_int64(V), _ip(ids), _fp(probs))
+    return (ids, probs) if want_probs else ids
+
+
 def row_losses(logits, target, smoothing=0.0):
     M, V = logits.shape
     nll = np.empty(M, np.float32); lp = np.empty(M, np.float32); lse = np.empty(M, np.float32)

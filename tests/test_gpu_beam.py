@@ -40,3 +40,37 @@ def test_beam_search_generator(gpu):
     video_ph, sentence, _ = mdl.build_generator(beam_size=3, length_normalization_factor=0.5)
     words = M.Session(mdl).run(sentence, {video_ph: video.cpu().numpy()})
     assert len(words) == 7
+
+
+def test_generator_unshifted_softmax_quirk(gpu, oracle):
+    """SURVEY A9 / tf_s2vt.py:208-209: build_generator picks argmax(exp(l) / sum(exp(l))) with no max shift.  The kernel
+    equals the oracle's restatement bit for bit (probabilities and ids); behind the switch the generator returns <eos>
+    once a logit overflows exp, where the default (argmax of the logits) keeps the overflowing word."""
+    import torch
+    from s2vt_amd import model as M, ops
+    rng = np.random.default_rng(4)
+    for V in (300, 12000, 97):
+        l = (rng.standard_normal((6, V)) * 3).astype(np.float32)
+        l[0, 7] = 95.0                      # overflow: inf / inf = NaN there, 0 elsewhere -> index 0
+        l[1, 7] = 87.5                      # large but finite: still index 7
+        l[2, :] = 0.0; l[2, [40, 41, 90]] = 3.0          # exact ties -> lowest index
+        l[3, :] = -200.0                    # every exp underflows: 0 / 0 = NaN everywhere -> index 0
+        l[4, 5] = 88.9; l[4, 6] = 90.0      # two NaNs
+        ref_ids, ref_p = oracle.softmax_unshifted_argmax(l, True)
+        ids, p = ops.softmax_unshifted_argmax(torch.as_tensor(l).cuda(), want_probs=True)
+        assert ref_ids.tolist()[:5] == [0, 7, 40, 0, 0]
+        assert np.array_equal(ids.cpu().numpy(), ref_ids)
+        assert np.array_equal(p.cpu().numpy().view(np.uint32), ref_p.view(np.uint32))     # NaNs included
+        assert ref_ids[5] == int(np.argmax(l[5]))                                     # ordinary row: the plain argmax
+    mdl = M.Video_Caption_Generator(24, 60, 12, 20, 1, 0, 3, 7, seed=3)
+    video = np.abs(rng.standard_normal((1, 3, 24))).astype(np.float32)
+    sess = M.Session(mdl)
+    vp, sent, _ = mdl.build_generator()
+    vq, sent_q, _ = mdl.build_generator(unshifted_softmax=True)
+    plain = sess.run(sent, {vp: video})
+    assert sess.run(sent_q, {vq: video}) == plain                                     # finite logits: same caption
+    _, g = mdl.sample(video, 0, True)
+    assert plain == g.cpu().numpy()[0].tolist()
+    mdl.store.p["embed_word_b"][9] = 120.0                                            # word 9's logit overflows exp at every step
+    assert sess.run(sent, {vp: video}) == [9] * 7
+    assert sess.run(sent_q, {vq: video}) == [0] * 7

@@ -89,7 +89,7 @@ def _run_e2e(rank, world, port, out):
     torch.manual_seed(3)
     cnn = torch.nn.Sequential(torch.nn.Conv2d(3, 6, 3, stride=2), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
                               torch.nn.Linear(6, 24), torch.nn.ReLU())
-    tr = e2e.EndToEnd(mdl, cnn, feature_keep=1.0)
+    tr = e2e.EndToEnd(mdl, cnn, feature_keep=0.9)          # feature dropout ON: masks keyed by the global video index
     mask = hostglue.masks_from_ids(cap[lo:hi])
     for step in range(2):
         tr.xe_step(torch.as_tensor(frames[lo:hi]), cap[lo:hi], mask, lr=1e-2, video_base=lo)

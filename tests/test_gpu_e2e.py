@@ -161,3 +161,14 @@ def test_feature_dropout_is_slim_dropout(gpu, oracle):
     assert torch.allclose(dropped[kept], clean[kept] / 0.9, rtol=1e-6, atol=0)       # kept units scaled by 1/keep_prob
     again, _ = tr.extract(frames, dropout=True)
     assert torch.equal(again, dropped)                                               # counter-based on (seed, global_step)
+    # the mask is the library's Philox dropout stream keyed by (GLOBAL video, frame, unit): the oracle reproduces it, ...
+    vid = np.repeat(np.arange(64, dtype=np.int32), 3); frame = np.tile(np.arange(3, dtype=np.int32), 64)
+    seed = tr.seed + 15485863 * (mdl.global_step + 1)
+    ref_mask = oracle.dropout_mask(seed, vid, frame, 768, 0.9, 24).reshape(64, 3, 24)
+    assert np.array_equal(kept.cpu().numpy(), (ref_mask != 0) & (clean.cpu().numpy() != 0))
+    # ... a rank holding videos [16, 24) of the global batch applies the very masks the one-rank run applies to them, ...
+    shard, _ = tr.extract(frames[16:24], dropout=True, video_base=16)
+    assert torch.equal(shard, dropped[16:24])
+    # ... and independent draws (the sampler graph's and the loss graph's dropout ops) get independent masks from one CNN pass
+    (d0, _), (d1, _) = tr.extract(frames, dropout=True, draws=(0, 1))
+    assert torch.equal(d0, dropped) and not torch.equal(d1, dropped) and 0.85 < float((d1 != 0).float().mean()) < 0.95
