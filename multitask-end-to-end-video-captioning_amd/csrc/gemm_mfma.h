@@ -186,6 +186,12 @@ struct GemmCfg {
 #ifndef S2VT_PF_BUDGET
 #define S2VT_PF_BUDGET 48
 #endif
+    // B fragments ([k][n] image, one ds_read_b32 per k-step and column subtile) are read PD k-steps ahead of the MFMAs that
+    // consume them.  One k-step ahead is enough when a k-step holds >= 4 MFMAs (>= 128 clocks against ~64-100 of LDS
+    // latency); the thin step tiles (gw16 / gw32 / gw48: 1-3 MFMAs per k-step, ONE dependent accumulator chain at M <= 64)
+    // waited for every fragment -- measured ~78 clocks per MFMA instead of the chain's 40 -- so they read 4 / 2 ahead.
+    static constexpr int MPK_ = TM * TN;
+    static constexpr int PD = MPK_ >= 4 ? 1 : (MPK_ >= 2 ? 2 : 4);
     static constexpr int PF_RAW = (PW > 0 ? 2 : 1) * S2VT_PF_BUDGET / (4 * (A4 + B4));   // loader waves hold no accumulators
     static constexpr int PF = PF_RAW < 2 ? 2 : (PF_RAW > 6 ? 6 : PF_RAW);
     static_assert(NG4 == 2 || NG4 == 4, "A planes: two or four b128 groups per row");
@@ -565,8 +571,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                 const int buf = c & 1;
                 const float* a = As + buf * ABUF + a_frag;
                 const float* b = Bs + buf * BBUF + b_frag;
+                constexpr int PD = Cfg::PD;
                 f32x4 a4[2][TM];
-                float bv[2][TN];
+                float bv[PD + 1][TN];
                 auto read_a = [&](auto g4_, f32x4 (&q)[TM]) __attribute__((always_inline)) {
                     constexpr int g4 = decltype(g4_)::value;
 #pragma unroll
@@ -578,17 +585,17 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     for (int jj = 0; jj < TN; ++jj) q[jj] = b[ks * 4 * SB + b_col(jj)];
                 };
                 read_a(std::integral_constant<int, 0>{}, a4[0]);
-                read_b(std::integral_constant<int, 0>{}, bv[0]);
+                static_for<0, (PD < KQ ? PD : KQ)>([&](auto k_) { read_b(k_, bv[decltype(k_)::value % (PD + 1)]); });
                 S2VT_STAMP_AT(1);
                 static_for<0, NM>([&](auto n_) {
                     constexpr int n = decltype(n_)::value, ks = n / MPK, r = n % MPK, i = r / TN, jj = r % TN;
                     if constexpr (r == 0) {
                         if constexpr (ks % 4 == 0 && ks / 4 + 1 < NG4)
                             read_a(std::integral_constant<int, ks / 4 + 1>{}, a4[(ks / 4 + 1) & 1]);
-                        if constexpr (ks + 1 < KQ) read_b(std::integral_constant<int, ks + 1>{}, bv[(ks + 1) & 1]);
+                        if constexpr (ks + PD < KQ) read_b(std::integral_constant<int, ks + PD>{}, bv[(ks + PD) % (PD + 1)]);
                         if constexpr (ks + 1 < KQ) __builtin_amdgcn_sched_barrier(0);
                     }
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], bv[ks % (PD + 1)][jj], acc[i][jj], 0, 0, 0);
                 });
                 S2VT_STAMP_AT(5);
                 __syncthreads();
@@ -622,8 +629,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     const int buf = c & 1;
                     const float* a = As + buf * ABUF + a_frag;
                     const float* b = Bs + buf * BBUF + b_frag;
+                    constexpr int PD = Cfg::PD;
                     f32x4 a4[2][TM];
-                    float bv[2][TN];
+                    float bv[PD + 1][TN];
                     f32x4 b4[2][TN];                                   // BT: B fragments in groups of four k-steps, like A
                     auto read_a = [&](auto g4_, f32x4 (&q)[TM]) __attribute__((always_inline)) {
                         constexpr int g4 = decltype(g4_)::value;
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     };
                     read_a(std::integral_constant<int, 0>{}, a4[0]);
                     if constexpr (BT) read_bg(std::integral_constant<int, 0>{}, b4[0]);
-                    else read_b(std::integral_constant<int, 0>{}, bv[0]);
+                    else static_for<0, (PD < KQ ? PD : KQ)>([&](auto k_) { read_b(k_, bv[decltype(k_)::value % (PD + 1)]); });
                     S2VT_STAMP_AT(1);                              // (dev build) top-of-chunk fragment latency
                     static_for<0, NM>([&](auto n_) {
                         constexpr int n = decltype(n_)::value, ks = n / MPK, r = n % MPK, i = r / TN, jj = r % TN;
@@ -652,8 +660,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                             if constexpr (BT) {
                                 if constexpr (ks % 4 == 0 && ks / 4 + 1 < NG4)
                                     read_bg(std::integral_constant<int, ks / 4 + 1>{}, b4[(ks / 4 + 1) & 1]);
-                            } else if constexpr (ks + 1 < KQ) {
-                                read_b(std::integral_constant<int, ks + 1>{}, bv[(ks + 1) & 1]);
+                            } else if constexpr (ks + PD < KQ) {
+                                read_b(std::integral_constant<int, ks + PD>{}, bv[(ks + PD) % (PD + 1)]);
                             }
                             if constexpr (ks + 1 < KQ) __builtin_amdgcn_sched_barrier(0);
                         }
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                         if constexpr (BT)
                             acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], b4[(ks / 4) & 1][jj][ks % 4], acc[i][jj], 0, 0, 0);
                         else
-                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[(ks / 4) & 1][i][ks % 4], bv[ks % (PD + 1)][jj], acc[i][jj], 0, 0, 0);
                         static_for<0, LPC>([&](auto p_) {
                             constexpr int p = decltype(p_)::value;
                             if constexpr (splice(p) == n) S2VT_PIECE_ISSUE(p, j);

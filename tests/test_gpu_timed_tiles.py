@@ -155,3 +155,72 @@ def test_fullsize_xe_update_vs_float64_autograd(gpu, oracle, fullsize):
     mdl.global_step = step0
     wd = sum(0.5 * float((mdl.store.p[n].double() ** 2).sum()) for n in mdl.store.names if n not in M.UNDECAYED)
     _compare(mdl, st, float(st.loss) + mdl.decay_value * wd, ref_loss, ref_g)
+
+
+def test_config0_xe_b4_full_dims_vs_float64_autograd(gpu, oracle):
+    """BASELINE configs[0]: the tf_s2vt XE train step on precomputed 5-frame features at B=4 with the real dimensions
+    (d=1536, E=500, H=1000, |V|=12000, Tc=20).  The reference runs it on CPU as a plumbing check; this build has no CPU
+    product path by design, so the same step runs on the HIP path and is checked against the CPU oracle (float64 autograd
+    of oracle/s2vt_torch.py): loss + every gradient, then one real update (lr > 0) moves the variables."""
+    import torch
+    from s2vt_amd import hostglue, model as M
+    Bs = 4
+    mdl = M.Video_Caption_Generator(D, V, E, H, Bs, 0, TV, TC, seed=11, dropout_rate=0.9)
+    rng = np.random.default_rng(17)
+    video = np.abs(rng.standard_normal((Bs, TV, D)) * 0.5).astype(np.float32)
+    cap = rng.integers(2, V, (Bs, TC)).astype(np.int32)
+    for i, n in enumerate((3, 19, 7, 12)):                                      # short, full-length (truncated), typical
+        cap[i, n:] = 0
+    mask = hostglue.masks_from_ids(cap)
+    vid = np.arange(Bs, dtype=np.int32); sid = np.zeros(Bs, np.int32)
+    ref_loss, ref_g = _ref_grads(mdl, video, cap, vid, sid, 0.9, lambda T, pt, lg: T.xe_loss(pt, lg, cap, mask, q1=True), oracle)
+    st = mdl.xe_update(video, cap, mask, lr=0.0, clip_norm=10.0, q1=True)
+    mdl.global_step = 0
+    wd = sum(0.5 * float((mdl.store.p[n].double() ** 2).sum()) for n in mdl.store.names if n not in M.UNDECAYED)
+    _compare(mdl, st, float(st.loss) + mdl.decay_value * wd, ref_loss, ref_g)
+    before = mdl.store.theta.clone()
+    mdl.xe_update(video, cap, mask, lr=1e-3, clip_norm=10.0, q1=True)
+    assert mdl.global_step == 1 and float((mdl.store.theta - before).abs().max()) > 5e-4
+
+
+def test_config3_multitask_b32_full_dims_vs_float64_autograd(gpu, oracle):
+    """BASELINE configs[3], per-GPU shape (B=32 of the 256 over 8 GPUs, K=1, 400 attribute labels, full dimensions): the
+    objective -(1-lambda) PG / sum(mask) + lambda XE(ground truth) + alpha BCE / (A B)
+    (reinforce_multitask_e2e_attribute_s2vt.py:850, reinforce_multitask_e2e_attribute_loss.py:375-380, 957) through
+    mixed_update(true_labels=...): loss and every gradient, attribute head included, vs float64 autograd."""
+    import torch
+    from s2vt_amd import hostglue, model as M
+    from oracle import s2vt_torch as T
+    Bs, A, lam, alpha, keep = 32, 400, 0.5, 0.05, 0.9
+    mdl = M.Video_Caption_Generator(D, V, E, H, Bs, 0, TV, TC, seed=21, dropout_rate=keep, multisample=1, label_dim=A, alpha=alpha)
+    rng = np.random.default_rng(23)
+    for n in ("lstm1_b", "lstm2_b", "encode_image_b", "embed_word_b", "attr_b"):
+        mdl.store.p[n].copy_(torch.as_tensor(rng.uniform(-.1, .1, mdl.store.shapes[n]).astype(np.float32)))
+    video = np.abs(rng.standard_normal((Bs, TV, D)) * 0.5).astype(np.float32)
+    dv = torch.as_tensor(video).cuda()
+    s, _ = mdl.sample(dv, 1, True, seed=77)
+    cap = s.cpu().numpy().astype(np.int32)
+    mask = hostglue.masks_from_ids(cap)
+    ln = 1 + np.minimum(rng.poisson(6, Bs), TC - 2)
+    gcap = rng.integers(2, V, (Bs, TC)).astype(np.int32)
+    for i in range(Bs):
+        gcap[i, ln[i]:] = 0
+    gmask = hostglue.masks_from_ids(gcap)
+    r = (rng.random(Bs) * 2).astype(np.float32); b = (rng.random(Bs) * 2).astype(np.float32)
+    labels = (rng.random((Bs, A)) < 0.03).astype(np.float32)
+    vid = np.arange(Bs, dtype=np.int32); sid = np.zeros(Bs, np.int32)
+    p = {n: mdl.store.p[n].cpu().numpy() for n in mdl.store.names}
+    s1 = mdl.dropout_seed + 104729 * mdl.global_step
+    drop1 = oracle.dropout_masks(s1, vid, sid, keep, H, TV, TC)
+    drop2 = oracle.dropout_masks(s1 + 7, vid, sid, keep, H, TV, TC)                 # the second pass draws its own masks
+    pt = T.to_torch(p, torch.float64, True)
+    vt = torch.as_tensor(video).double()
+    lg1 = T.teacher_forced(pt, vt, cap, drop1, keep)
+    lg2 = T.teacher_forced(pt, vt, gcap, drop2, keep)
+    xe = T.xe_loss({k: v for k, v in pt.items()}, lg2, gcap, gmask, q1=True)        # decays every non-LSTM-bias variable, attr_W / attr_b included
+    ref = (1 - lam) * T.pg_loss(lg1, cap, mask, r, b) + lam * xe + alpha * T.attr_bce(pt, vt, labels, normalise=True)
+    ref.backward()
+    st = mdl.mixed_update(dv, s, mask, r, b, gcap, gmask, lr=0.0, lambda_loss=lam, true_labels=labels)
+    wd = sum(0.5 * float((mdl.store.p[n].double() ** 2).sum()) for n in mdl.store.names if n not in M.UNDECAYED)
+    loss = float(st.loss) + float(st.attr_loss) + lam * mdl.decay_value * wd
+    _compare(mdl, st, loss, float(ref.detach()), {k: v.grad.numpy() for k, v in pt.items()})
