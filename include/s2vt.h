@@ -340,6 +340,24 @@ int s2vt_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, s2vt_st
 int s2vt_dropout_bwd(const float* dout, int32_t ld, float* dh, int32_t M, int32_t H, float keep, uint64_t seed,
                      uint32_t drop_code, const int32_t* video_id, const int32_t* sample_id, s2vt_stream stream);
 
+/* ---- a whole BasicLSTMCell recurrence in one call: the unroll of tf_s2vt.py:113-153 for a cell whose step input is
+ * known before the loop.  Step t = 0 .. T-1:  z = cinit_t (+) H_hist[t] @ W[kw0 : kw0 + H, :]  (cinit_t = cinit +
+ * t * cinit_tstride, rows ldcinit apart, for t < cinit_steps; absent otherwise), BasicLSTMCell pointwise with C_hist[t],
+ * results to C_hist[t+1], H_hist[t+1] ([T+1, M, H], slot 0 = the initial state), the activated gates to gates[t]
+ * ([T, M, 4H] or NULL; may alias cinit) and the DropoutWrapper output to out[t] ([T, M, H] or NULL; Philox code
+ * drop_code0 + t).  persistent = 1: ONE persistent launch with the recurrent weights resident in LDS and the state
+ * exchanged through L2 (needs M <= 64, H % 4 == 0, H / 4 <= the CU count; S2VT_E_BADARG otherwise); 0: T launches of
+ * the fused cell kernel; -1: persistent when the shape fits.  Both forms give the same bits.  scratch:
+ * s2vt_lstm_recurrence_scratch_bytes(H) bytes, 256-byte aligned (persistent form only). */
+size_t s2vt_lstm_recurrence_scratch_bytes(int32_t H);
+int s2vt_lstm_recurrence_fwd(const float* W, int32_t kw0, const float* b, const float* cinit, int64_t cinit_tstride, int32_t ldcinit,
+                             int32_t cinit_steps, float* C_hist, float* H_hist, float* gates, float* out, int32_t M, int32_t H,
+                             int32_t T, float keep, uint64_t seed, const int32_t* video_id, const int32_t* sample_id,
+                             uint32_t drop_code0, int32_t persistent, void* scratch, size_t scratch_bytes, s2vt_stream stream);
+/* Grid-wide waits of the persistent recurrence that gave up (bounded spins), over all launches of this process; 0 =
+ * healthy.  Read after synchronising the stream. */
+int s2vt_chain_timeouts(void);
+
 /* In-place SUM all-reduce of the flat gradient bucket over an existing RCCL communicator (ncclComm_t as
  * void*), on `stream` -- the exchange step of SURVEY.md section 8(e) for C/C++ hosts (Python hosts use
  * torch.distributed).  The library never loads RCCL itself (a communicator belongs to the instance that made it):

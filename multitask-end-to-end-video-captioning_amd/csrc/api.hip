@@ -225,8 +225,39 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
     for (int i = 0; i < 2; ++i) { t.c2[i] = c.take<float>((size_t)R * H); t.h2[i] = c.take<float>((size_t)R * H); }
     t.packed = c.take<unsigned long long>((size_t)Tc * R);
     t.vid = c.take<int32_t>(R); t.sid = c.take<int32_t>(R); t.bos = c.take<int32_t>(R);
+    t.chain_sync = c.take<unsigned>(kChainSyncBytes / 4);
+    t.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
     if (w) *w = t;
     return c.off;
+}
+
+hipError_t lstm_recurrence(const float* W, int kw0, const float* bias, const float* cinit, size_t cinit_tstride, int ldcinit,
+                           int cinit_steps, float* C, float* Hh, size_t state_tstride, float* gates, size_t gates_tstride,
+                           float* out, size_t out_tstride, int M, int H, int T, float keep, const NoiseIds& ids,
+                           uint32_t drop_code0, float* chain_abuf, unsigned* chain_sync, hipStream_t st)
+{
+    if (chain_abuf && chain_sync && chain_eligible(M, H)) {
+        ChainArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.W = W; a.ldw = 4 * H; a.kw0 = kw0; a.bias = bias;
+        a.cinit = cinit; a.cinit_tstride = cinit_tstride; a.ldcinit = ldcinit; a.cinit_steps = cinit_steps;
+        a.h0 = Hh; a.c0 = C; a.C = C; a.Hh = Hh; a.state_tstride = state_tstride;
+        a.gates = gates; a.gates_tstride = gates_tstride; a.out = out; a.out_tstride = out_tstride;
+        a.M = M; a.H = H; a.T = T; a.keep = keep;
+        a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32); a.drop_code0 = drop_code0;
+        a.video_id = ids.video_id; a.sample_id = ids.sample_id;
+        a.abuf = chain_abuf; a.sync = chain_sync;
+        return launch_lstm_chain(a, st);
+    }
+    for (int t = 0; t < T; ++t) {
+        ASeg s1 = make_seg(Hh + (size_t)t * state_tstride, H, H, kw0);
+        hipError_t e = lstm_call(&s1, 1, W, bias, C + (size_t)t * state_tstride, 0, C + (size_t)(t + 1) * state_tstride,
+                                 Hh + (size_t)(t + 1) * state_tstride, out ? out + (size_t)t * out_tstride : nullptr,
+                                 gates ? gates + (size_t)t * gates_tstride : nullptr, M, H, keep, ids, drop_code0 + (uint32_t)t, -1, st,
+                                 (cinit && t < cinit_steps) ? cinit + (size_t)t * cinit_tstride : nullptr, ldcinit, 0);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // Encoding stage (tf_s2vt.py:97-122) plus everything of the decoding stage that does not depend on a
@@ -256,12 +287,9 @@ int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, 
         ASeg sx = make_seg(w.emb, E, E, 0);
         HIP_TRY(store_call(&sx, 1, p->lstm1_W, 4 * H, nullptr, w.Xp1, 4 * H, B * Tv, 4 * H, 0, -1, st));
     }
-    for (int t = 0; t < T; ++t) {
-        ASeg s1 = make_seg(w.h1 + t * BH, H, H, E);
-        HIP_TRY(lstm_call(&s1, 1, p->lstm1_W, p->lstm1_b, w.c1 + t * BH, 0, w.c1 + (t + 1) * BH, w.h1 + (t + 1) * BH, nullptr,
-                          w.G1 + (size_t)t * 4 * BH, B, H, 1.0f, none, 0, -1, st, t < Tv ? w.Xp1 + (size_t)t * 4 * H : nullptr,
-                          Tv * 4 * H, 0));
-    }
+    // (one persistent launch for the whole trajectory when B <= 64: chain.hip)
+    HIP_TRY(lstm_recurrence(p->lstm1_W, E, p->lstm1_b, w.Xp1, (size_t)4 * H, Tv * 4 * H, Tv, w.c1, w.h1, BH, w.G1, (size_t)4 * BH,
+                            nullptr, 0, B, H, T, 1.0f, none, 0, w.chain_abuf, w.chain_sync, st));
     // ---- the out1 rows of W2 for every step at once (M = T*B)
     {
         ASeg so = make_seg(w.h1 + BH, H, H, 0);

@@ -122,7 +122,16 @@ struct SampleWs {
     float *emb, *Xp1, *c1, *h1, *G1, *P2, *c2e[2], *h2e[2], *c2[2], *h2[2];
     unsigned long long* packed;
     int32_t *vid, *sid, *bos;
+    float* chain_abuf;       // persistent-recurrence scratch (chain.hip): fragment images of h + arrival counters
+    unsigned* chain_sync;
 };
+
+// One LSTM recurrence of T steps on M rows: ONE persistent launch when the shape fits (chain_eligible), else T
+// per-step launches of the fused cell kernel.  Histories: step t reads slot t of C / Hh and writes slot t + 1.
+hipError_t lstm_recurrence(const float* W, int kw0, const float* bias, const float* cinit, size_t cinit_tstride, int ldcinit,
+                           int cinit_steps, float* C, float* Hh, size_t state_tstride, float* gates, size_t gates_tstride,
+                           float* out, size_t out_tstride, int M, int H, int T, float keep, const NoiseIds& ids,
+                           uint32_t drop_code0, float* chain_abuf, unsigned* chain_sync, hipStream_t st);
 size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w);
 int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, int B, const SampleWs& w, s2vt_stream stream);
 int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int with_greedy, uint64_t seed, int video_base,

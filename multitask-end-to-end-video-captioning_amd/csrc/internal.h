@@ -60,6 +60,28 @@ hipError_t launch_grad_finalize(float* g, const float* theta, int64_t n, const f
 hipError_t launch_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip,
                           float lr_t, float b1, float b2, float eps, hipStream_t st);
 
+// ---- a whole LSTM recurrence (T steps, M <= 64 rows) in one persistent launch (chain.hip)
+struct ChainArgs {
+    const float* W; int ldw; int kw0;                 // full cell matrix [*, 4H] (ldw floats per row); the recurrent rows start at kw0
+    const float* bias;                                 // [4H]
+    const float* cinit; size_t cinit_tstride; int ldcinit; int cinit_steps;   // carried partial of step t < cinit_steps: cinit + t*tstride, rows ldcinit apart; NULL = none
+    const float* h0; const float* c0;                  // initial state [M, H] or NULL = zeros
+    float* C; float* Hh; size_t state_tstride;         // state histories: step t writes slot t + 1 (C + (t+1)*state_tstride)
+    float* gates; size_t gates_tstride;                // optional activated gates [T][M][4H] (si | tj | sf | so)
+    float* out; size_t out_tstride;                    // optional DropoutWrapper output [T][M][H]
+    int M, H, T;
+    float keep; uint32_t seed_lo, seed_hi, drop_code0; // dropout of `out`: code = drop_code0 + t
+    const int32_t* video_id; const int32_t* sample_id;
+    float* abuf;                                       // chain_scratch_floats(H) floats, 16-byte aligned
+    unsigned* sync;                                    // kChainSyncBytes bytes: arrival counters + timeout word
+    unsigned* status;                                  // (set by the launcher) host-mapped count of timed-out waits
+};
+constexpr size_t kChainSyncBytes = 9 * 128;            // 8 counter shards + the status line, a block of its own (multiple of 16)
+bool chain_eligible(int M, int H);                     // shape fits the persistent form on this device (and S2VT_CHAIN != 0)
+size_t chain_scratch_floats(int H);
+hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st);
+unsigned chain_timeouts();                             // grid-wide waits that gave up, all launches of this process (0 = healthy)
+
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.
 struct NnBwdArgs {

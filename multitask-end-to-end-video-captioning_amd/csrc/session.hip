@@ -248,6 +248,42 @@ int s2vt_dropout_bwd(const float* dout, int32_t ld, float* dh, int32_t M, int32_
     return S2VT_OK;
 }
 
+size_t s2vt_lstm_recurrence_scratch_bytes(int32_t H)
+{
+    if (H <= 0) return 0;
+    return ((chain_scratch_floats(H) * 4 + 255) & ~size_t(255)) + ((kChainSyncBytes + 255) & ~size_t(255));
+}
+
+int s2vt_lstm_recurrence_fwd(const float* W, int32_t kw0, const float* b, const float* cinit, int64_t cinit_tstride, int32_t ldcinit,
+                             int32_t cinit_steps, float* C_hist, float* H_hist, float* gates, float* out, int32_t M, int32_t H,
+                             int32_t T, float keep, uint64_t seed, const int32_t* video_id, const int32_t* sample_id,
+                             uint32_t drop_code0, int32_t persistent, void* scratch, size_t scratch_bytes, s2vt_stream stream)
+{
+    if (!W || !b || !C_hist || !H_hist || M <= 0 || H <= 0 || T < 0 || kw0 < 0 || persistent < -1 || persistent > 1) return S2VT_E_BADARG;
+    if (cinit && (cinit_steps < 0 || ldcinit < 4 * H)) return S2VT_E_BADARG;
+    if (!(keep > 0.0f) || (keep < 1.0f && (!out || !video_id || !sample_id))) return S2VT_E_BADARG;
+    float* abuf = nullptr;
+    unsigned* sync = nullptr;
+    if (persistent != 0) {
+        if (persistent == 1 && !chain_eligible(M, H)) return S2VT_E_BADARG;
+        if (chain_eligible(M, H)) {
+            if (!scratch) return S2VT_E_BADARG;
+            if (reinterpret_cast<uintptr_t>(scratch) & 255u) return S2VT_E_ALIGN;
+            Carver c(scratch, scratch_bytes);
+            sync = c.take<unsigned>(kChainSyncBytes / 4);
+            abuf = c.take<float>(chain_scratch_floats(H));
+            if (!c.ok()) return S2VT_E_WORKSPACE;
+        }
+    }
+    NoiseIds ids{video_id, sample_id, seed};
+    const size_t MH = (size_t)M * H;
+    HIP_TRY(lstm_recurrence(W, kw0, b, cinit, (size_t)cinit_tstride, ldcinit, cinit ? cinit_steps : 0, C_hist, H_hist, MH, gates, 4 * MH, out,
+                            MH, M, H, T, keep, ids, drop_code0, abuf, sync, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_chain_timeouts(void) { return (int)chain_timeouts(); }
+
 // ncclAllReduce of the RCCL instance that OWNS the caller's communicator.  A communicator must never be handed to a
 // second copy of the library, so nothing is ever loaded here: (1) an entry point registered by the host
 // (s2vt_set_rccl_allreduce -- needed when the host loaded its RCCL with RTLD_LOCAL, as torch does), else (2) a symbol

@@ -30,6 +30,8 @@ struct TrainWs {
     float *G1, *C1, *H1, *O1, *G2, *C2, *H2, *O2;
     float *dO2, *dZ1, *dZ2, *dX2, *dX1, *dH1, *slab, *dc;
     int32_t* decidx;     // inverse of encidx: row of dX1 (time-major) for row j*Tv + t of d_video
+    float* chain_abuf;   // persistent-recurrence scratch (chain.hip)
+    unsigned* chain_sync;
 };
 
 // Split-K plan of the recurrent data-gradient product dz[M,4H] @ Whh^T[4H,H] (order-free): enough K slabs
@@ -70,6 +72,8 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * b * E); w.dH1 = c.take<float>(T * b * H);
     w.slab = c.take<float>((size_t)kMaxSlabs * n * H); w.dc = c.take<float>(n * H);
     w.decidx = c.take<int32_t>(Tv * b);
+    w.chain_sync = c.take<unsigned>(kChainSyncBytes / 4);
+    w.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
     if (out) *out = w;
     return c.off;
 }
@@ -204,13 +208,9 @@ int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, cons
             ASeg sx = make_seg(w.emb, E, E, 0);
             HIP_TRY(store_call(&sx, 1, p->lstm1_W, 4 * H, nullptr, w.Xp1, 4 * H, B * Tv, 4 * H, 0, -1, st));
         }
-        for (int t = 0; t < T; ++t) {
-            // tf_s2vt.py:119 (encode) / :140 (decode, zero padding input: only the recurrent rows remain)
-            ASeg s1 = make_seg(w.H1 + t * BH, H, H, E);
-            HIP_TRY(lstm_call(&s1, 1, p->lstm1_W, p->lstm1_b, w.C1 + t * BH, 0, w.C1 + (t + 1) * BH, w.H1 + (t + 1) * BH,
-                              nullptr, w.G1 + (size_t)t * 4 * BH, B, H, 1.0f, none, 0, -1, st,
-                              t < Tv ? w.Xp1 + (size_t)t * 4 * H : nullptr, Tv * 4 * H, 0));
-        }
+        // tf_s2vt.py:119 (encode) / :140 (decode, zero padding input: only the recurrent rows remain)
+        HIP_TRY(lstm_recurrence(p->lstm1_W, E, p->lstm1_b, w.Xp1, (size_t)4 * H, Tv * 4 * H, Tv, w.C1, w.H1, BH, w.G1, (size_t)4 * BH,
+                                nullptr, 0, B, H, T, 1.0f, none, 0, w.chain_abuf, w.chain_sync, st));
     }
     // DropoutWrapper(LSTM1) output for the N sample rows (tf_s2vt.py:75; code = 256 + t)
     HIP_TRY(launch_expand_dropout(w.H1 + BH, w.O1, T, B, N, H, keep, seed, 256u, video_id, sample_id, st));
@@ -222,12 +222,9 @@ int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, cons
         ASeg sd[2] = {make_seg(w.O1 + (size_t)Tv * NH, H, H, 0), make_seg(p->Wemb, E, E, H, 0, w.prev)};   // decode (:143)
         HIP_TRY(store_call(sd, 2, p->lstm2_W, 4 * H, nullptr, w.G2 + (size_t)Tv * 4 * NH, 4 * H, Tc * N, 4 * H, 0, -1, st));
     }
-    for (int t = 0; t < T; ++t) {
-        ASeg s2 = make_seg(w.H2 + t * NH, H, H, H + E);
-        float* g2 = w.G2 + (size_t)t * 4 * NH;
-        HIP_TRY(lstm_call(&s2, 1, p->lstm2_W, p->lstm2_b, w.C2 + t * NH, 0, w.C2 + (t + 1) * NH, w.H2 + (t + 1) * NH,
-                          w.O2 + t * NH, g2, N, H, keep, ids, 512u + (uint32_t)t, -1, st, g2, 4 * H, 0));
-    }
+    // the recurrence continues each chain from its partial in G2[t] and overwrites it with the activated gates
+    HIP_TRY(lstm_recurrence(p->lstm2_W, H + E, p->lstm2_b, w.G2, (size_t)4 * NH, 4 * H, T, w.C2, w.H2, NH, w.G2, (size_t)4 * NH,
+                            w.O2, NH, N, H, T, keep, ids, 512u, w.chain_abuf, w.chain_sync, st));
     // vocab logits for all Tc steps at once (tf_s2vt.py:153): rows t*N + n
     ASeg so = make_seg(w.O2 + (size_t)Tv * NH, H, H, 0);
     HIP_TRY(store_call(&so, 1, p->embed_word_W, V, p->embed_word_b, logits, V, Tc * N, V, 0, -1, st));

@@ -112,6 +112,37 @@ def lstm_cell_fwd(x0, x1, h_prev, c_prev, W, b, M, state_rowmod=0, keep=1.0, see
     return c, h, out, gates
 
 
+def lstm_recurrence_fwd(W, kw0, b, h0, c0, T, cinit=None, cinit_steps=0, keep=1.0, seed=0, video_id=None, sample_id=None,
+                        drop_code0=0, want_gates=True, want_out=False, persistent=-1, gates_in_cinit=False):
+    """T steps of one BasicLSTMCell on the recurrent rows W[kw0:kw0+H] (+ the carried partials cinit [steps, M, 4H]).
+    Returns (C_hist [T+1,M,H], H_hist [T+1,M,H], gates [T,M,4H] | None, out [T,M,H] | None).
+    persistent: 1 = the one-launch persistent form, 0 = per-step launches, -1 = auto.  gates_in_cinit: write the gates over cinit."""
+    _chk_f32(W, b, h0, c0, cinit)
+    M, H = h0.shape
+    dev = W.device
+    Ch = torch.empty((T + 1, M, H), dtype=torch.float32, device=dev); Hh = torch.empty_like(Ch)
+    Ch[0].copy_(c0); Hh[0].copy_(h0)
+    if gates_in_cinit:
+        assert cinit is not None and cinit.shape[0] == T
+        gates = cinit
+    else:
+        gates = torch.empty((T, M, 4 * H), dtype=torch.float32, device=dev) if want_gates else None
+    out = torch.empty((T, M, H), dtype=torch.float32, device=dev) if want_out else None
+    nb = lib().s2vt_lstm_recurrence_scratch_bytes(H)
+    ws = workspace(nb, dev, "chain")
+    check(lib().s2vt_lstm_recurrence_fwd(_ptr(W), kw0, _ptr(b), _ptr(cinit), 0 if cinit is None else cinit.stride(0),
+                                         0 if cinit is None else cinit.stride(1), cinit_steps, _ptr(Ch), _ptr(Hh), _ptr(gates), _ptr(out),
+                                         M, H, T, float(keep), seed, _ptr(video_id), _ptr(sample_id), drop_code0, persistent, _ptr(ws),
+                                         ws.numel(), _stream()), "s2vt_lstm_recurrence_fwd")
+    return Ch, Hh, gates, out
+
+
+def chain_timeouts() -> int:
+    """Timed-out grid-wide waits of the persistent recurrence so far (0 = healthy); synchronises the device."""
+    torch.cuda.synchronize()
+    return int(lib().s2vt_chain_timeouts())
+
+
 def vocab_pick(out2, W, b, video_id, sample_id, step, seed, want_logits=False, tile_cfg=-1):
     _chk_f32(out2, W, b)
     M, H = out2.shape

@@ -1,0 +1,94 @@
+"""The persistent LSTM recurrence (csrc/chain.hip: T steps in one launch, recurrent weights resident in LDS, state
+exchanged through L2 behind a grid-wide hand-off) against (1) T per-step launches of the fused cell kernel -- every state,
+gate and dropped output BIT-identical -- and (2) the CPU oracle's BasicLSTMCell steps (tf_s2vt.py:113-153 restated).
+Also under load on a second stream (hand-offs must not depend on timing) and repeated back to back (stale-state check:
+every polled word and the fragment images are re-zeroed per call)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _case(M, E, H, T, csteps, seed):
+    rng = np.random.default_rng(seed)
+    W = rng.uniform(-.3, .3, (E + H, 4 * H)).astype(np.float32); b = rng.uniform(-.5, .5, 4 * H).astype(np.float32)
+    h0 = rng.uniform(-1, 1, (M, H)).astype(np.float32); c0 = rng.standard_normal((M, H)).astype(np.float32)
+    cinit = rng.standard_normal((max(csteps, 1), M, 4 * H)).astype(np.float32)
+    vid = rng.integers(0, 1000, M).astype(np.int32); sid = rng.integers(0, 5, M).astype(np.int32)
+    return W, b, h0, c0, cinit, vid, sid
+
+
+SHAPES = [  # M, E, H, T, steps with a carried partial
+    (4, 12, 20, 6, 3), (64, 32, 64, 9, 9), (33, 8, 64, 5, 0), (1, 4, 128, 4, 2),
+    (64, 500, 1000, 25, 5),        # LSTM1 of the bench: B = 64, 5 frame steps with the hoisted input partial, 20 decode steps
+    (32, 500, 1000, 25, 25),       # the multitask per-GPU batch, a partial at every step (LSTM2 form)
+    (17, 500, 1000, 3, 1),
+]
+
+
+@pytest.mark.parametrize("M,E,H,T,csteps", SHAPES)
+@pytest.mark.parametrize("keep", [1.0, 0.9])
+def test_persistent_recurrence_equals_per_step_launches(gpu, oracle, M, E, H, T, csteps, keep):
+    import torch
+    W, b, h0, c0, cinit, vid, sid = _case(M, E, H, T, csteps, seed=M + H)
+    args = dict(T=T, cinit=_dev(cinit) if csteps else None, cinit_steps=csteps, keep=keep, seed=77, video_id=_dev(vid),
+                sample_id=_dev(sid), drop_code0=512, want_gates=True, want_out=True)
+    ref = gpu.lstm_recurrence_fwd(_dev(W), E, _dev(b), _dev(h0), _dev(c0), persistent=0, **args)
+    for rep in range(2):                                                   # back to back: nothing stale from the previous call
+        got = gpu.lstm_recurrence_fwd(_dev(W), E, _dev(b), _dev(h0), _dev(c0), persistent=1, **args)
+        assert gpu.chain_timeouts() == 0
+        for name, r, g in zip(("C", "H", "gates", "out"), ref, got):
+            assert torch.equal(r, g), (name, rep)
+    # the oracle's own steps (small shapes: seconds on CPU)
+    if H <= 128:
+        c, h = c0, h0
+        for t in range(T):
+            mask = None if keep >= 1 else oracle.dropout_mask(77, vid, sid, 512 + t, keep, H)
+            z = cinit[t].copy() if t < csteps else np.zeros((M, 4 * H), np.float32)       # the carried partial starts the chain
+            oracle.gemm_chain(np.ascontiguousarray(h), np.ascontiguousarray(W[E:]), z)
+            oracle.bias_add(z, b)
+            rc, rh, rout, rg = oracle.lstm_pointwise(z, c, mask, keep, want_gates=True)
+            assert np.array_equal(got[0][t + 1].cpu().numpy(), rc) and np.array_equal(got[1][t + 1].cpu().numpy(), rh), t
+            assert np.array_equal(got[2][t].cpu().numpy(), rg) and np.array_equal(got[3][t].cpu().numpy(), rout), t
+            c, h = rc, rh
+
+
+def test_persistent_recurrence_gates_over_the_partial_and_under_load(gpu):
+    """build_model's LSTM2 form: the activated gates overwrite the hoisted partial they continue from (G2 in train.hip);
+    run while a second stream keeps the chip busy with unrelated kernels, several times -- same bits every time."""
+    import torch
+    M, E, H, T = 64, 500, 1000, 25
+    W, b, h0, c0, cinit, vid, sid = _case(M, E, H, T, T, seed=5)
+    dW, db, dh0, dc0 = _dev(W), _dev(b), _dev(h0), _dev(c0)
+    ref = gpu.lstm_recurrence_fwd(dW, E, db, dh0, dc0, T, cinit=_dev(cinit), cinit_steps=T, keep=0.9, seed=3, video_id=_dev(vid),
+                                  sample_id=_dev(sid), drop_code0=512, want_out=True, persistent=0, gates_in_cinit=True)
+    side = torch.cuda.Stream()
+    x = torch.randn(4096, 4096, device="cuda")
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(3 + rep):
+                x = torch.tanh(x @ x * 1e-3)                                  # uneven load beside the chain
+        got = gpu.lstm_recurrence_fwd(dW, E, db, dh0, dc0, T, cinit=_dev(cinit), cinit_steps=T, keep=0.9, seed=3, video_id=_dev(vid),
+                                      sample_id=_dev(sid), drop_code0=512, want_out=True, persistent=1, gates_in_cinit=True)
+        torch.cuda.synchronize()
+        assert gpu.chain_timeouts() == 0
+        for r, g_ in zip(ref, got):
+            assert torch.equal(r, g_), rep
+
+
+def test_persistent_form_refuses_shapes_it_cannot_hold(gpu):
+    import torch
+    W = torch.zeros(8 + 6, 24, device="cuda"); b = torch.zeros(24, device="cuda")
+    h0 = torch.zeros(3, 6, device="cuda")
+    with pytest.raises(RuntimeError, match="bad argument"):
+        gpu.lstm_recurrence_fwd(W, 8, b, h0, h0, 2, persistent=1)            # H = 6 is not a multiple of 4
+    C, Hh, _, _ = gpu.lstm_recurrence_fwd(W, 8, b, h0, h0, 2, persistent=-1)  # auto: falls back to per-step launches
+    assert C.shape == (3, 3, 6)
+    W = torch.zeros(4 + 8, 32, device="cuda"); b = torch.zeros(32, device="cuda"); h0 = torch.zeros(65, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="bad argument"):
+        gpu.lstm_recurrence_fwd(W, 4, b, h0, h0, 2, persistent=1)            # M = 65 rows
