@@ -27,7 +27,10 @@ def prof_key(kname):
     if m:
         WM, WN, TM, TN = [int(x) for x in m.groups()[:4]]
         return f"3:tn{WM * TM * 16}x{WN * TN * 16}({WM}x{WN})"
-    return "x:" + kname.split("(")[0][-48:]
+    m = re.search(r"lstm_chain_kernel<(\d+)>", kname)
+    if m:
+        return f"5:chain(ng{m.group(1)})"
+    return "x:" + re.sub(r"^void ", "", kname).split("(")[0][-48:]
 
 
 agg = {c: collections.defaultdict(list) for c in ("FETCH_SIZE", "WRITE_SIZE")}
