@@ -346,7 +346,7 @@ int s2vt_dropout_bwd(const float* dout, int32_t ld, float* dh, int32_t M, int32_
  * results to C_hist[t+1], H_hist[t+1] ([T+1, M, H], slot 0 = the initial state), the activated gates to gates[t]
  * ([T, M, 4H] or NULL; may alias cinit) and the DropoutWrapper output to out[t] ([T, M, H] or NULL; Philox code
  * drop_code0 + t).  persistent = 1: ONE persistent launch with the recurrent weights resident in LDS and the state
- * exchanged through L2 (needs M <= 64, H % 4 == 0, H / 4 <= the CU count; S2VT_E_BADARG otherwise); 0: T launches of
+ * exchanged through L2 (needs M <= 384, H % 4 == 0, H <= 1024, H / 4 <= the CU count; S2VT_E_BADARG otherwise); 0: T launches of
  * the fused cell kernel; -1: persistent when the shape fits.  Both forms give the same bits.  scratch:
  * s2vt_lstm_recurrence_scratch_bytes(H) bytes, 256-byte aligned (persistent form only). */
 size_t s2vt_lstm_recurrence_scratch_bytes(int32_t H);

@@ -539,16 +539,19 @@ constexpr TnCfg tn_entry()
 const TnCfg kTn[] = {tn_entry<2, 2, 4, 4>() /*128x128*/, tn_entry<2, 2, 2, 4>() /*64x128*/, tn_entry<2, 2, 2, 2>() /*64x64*/,
                      tn_entry<2, 2, 3, 3>() /*96x96*/, tn_entry<2, 2, 2, 3>() /*64x96*/, tn_entry<2, 2, 3, 4>() /*96x128*/};
 std::once_flag g_tn_once;
+hipError_t g_tn_attr_err = hipSuccess;
 }  // namespace
 
 hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
 {
     std::call_once(g_tn_once, [] {
-        for (const TnCfg& c : kTn) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(c.vec), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(c.scalar), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
-        }
+        for (const TnCfg& c : kTn)
+            for (TnFn fn : {c.vec, c.scalar}) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
+                if (e != hipSuccess && g_tn_attr_err == hipSuccess) g_tn_attr_err = e;
+            }
     });
+    if (g_tn_attr_err != hipSuccess) return g_tn_attr_err;
     if (a.Mred <= 0 || a.Kout <= 0 || a.N <= 0) return hipSuccess;
     auto tiles = [&](const TnCfg& c) { return (long)((a.Kout + c.BMo - 1) / c.BMo) * ((a.N + c.BNo - 1) / c.BNo); };
     int ci = 0;

@@ -35,23 +35,32 @@ namespace {
 
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-__device__ __forceinline__ void bload16_sc1(f32x4& d, uint32_t voff, i32x4 rsrc, uint32_t soff)
+// A-fragment load: 16 bytes per lane, sc1 (served by L2, never by this CU's L1 -- the hand-off's load form).  A builtin,
+// not asm: hipcc then knows when the data lands, keeps its own vmcnt count and may place the registers anywhere (with
+// asm-issued loads it copied ring registers to AGPRs right behind the load, before the data had arrived); the loads are
+// kept where they are written by sched_barrier fences.
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 bload16_sc1(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
 {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16);      // aux 16 = sc1
+    return __builtin_bit_cast(f32x4, v);
 }
 
 constexpr int kShards = 8;             // counter shards, one 128-byte line each; word kShards * 32 = timeout flag
 constexpr unsigned kSpinLimit = 1u << 21;
 
-template <int NG>
+template <int NG, int TMW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_chain_kernel(const ChainArgs g)
 {
     constexpr int ZS = 20;                                     // z tile row stride (floats): 16-byte aligned rows, conflict-light
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                          // [NG][64 lanes][4]: B fragments of this workgroup's 16 gate columns
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* zb = smem + NG * 256 + wave * (16 * ZS);
+    const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* zb = smem + NG * 256 + pwave * (16 * ZS);
+    // which quarter of the rows this wave takes rotates with the workgroup: neighbouring CUs then walk DIFFERENT lines of
+    // the shared state image at any moment instead of all hammering the same L2 channel (speed only)
+    const int wave = (pwave + (int)blockIdx.x) & 3;
     const int l15 = lane & 15, lq = lane >> 4;
     const int H = g.H, M = g.M, T = g.T;
     const int u0 = blockIdx.x * 4;
@@ -68,18 +77,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int uu = 0; uu < 4; ++uu) Wl[((j * 64 + kq * 16 + uu * 4 + gt) << 2) + e] = v[uu];
     }
 
-    // ---- the (row, unit) this lane finishes at every step
-    const int rt = lane >> 2, uu = lane & 3;                   // row within the wave's 16-row tile, unit within the 4
-    const int row = wave * 16 + rt, u = u0 + uu;
-    const bool rok = row < M;
+    // ---- the (row, unit) pairs this lane finishes at every step: one per row tile of its wave (tiles wave*TMW .. +TMW-1)
+    const int rt = lane >> 2, uu = lane & 3;                   // row within a 16-row tile, unit within the 4
+    const int u = u0 + uu;
+    const int row0 = wave * TMW * 16 + rt;                     // row of tile 0; tile i is 16 i further
     const float bi = g.bias[u], bj = g.bias[H + u], bf = g.bias[2 * H + u], bo = g.bias[3 * H + u];
-    float c_reg = (rok && g.c0) ? g.c0[(size_t)row * H + u] : 0.0f;
-    uint32_t vid = 0, sid = 0;
-    if (g.keep < 1.0f && rok) { vid = (uint32_t)g.video_id[row]; sid = (uint32_t)g.sample_id[row]; }
-    // where this lane's h value sits in the A-fragment image: k = u -> group u / 16, lane (u % 4) * 16 + rt, component (u % 16) / 4
-    const size_t a_own = ((size_t)(wave * NG + (u >> 4)) * 64 + (size_t)((u & 3) * 16 + rt)) * 4 + ((u & 15) >> 2);
+    float c_reg[TMW];
+    uint32_t vid[TMW], sid[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        const int row = row0 + 16 * i;
+        const bool rok = row < M;
+        c_reg[i] = (rok && g.c0) ? g.c0[(size_t)row * H + u] : 0.0f;
+        vid[i] = (g.keep < 1.0f && rok) ? (uint32_t)g.video_id[row] : 0u;
+        sid[i] = (g.keep < 1.0f && rok) ? (uint32_t)g.sample_id[row] : 0u;
+    }
+    // where this lane's h value of tile 0 sits in the A-fragment image (tile i: + i * NG * 256 floats):
+    // k = u -> group u / 16, lane (u % 4) * 16 + rt, component (u % 16) / 4
+    const size_t a_own = ((size_t)(wave * TMW * NG + (u >> 4)) * 64 + (size_t)((u & 3) * 16 + rt)) * 4 + ((u & 15) >> 2);
     float* const abuf0 = g.abuf;
-    float* const abuf1 = g.abuf + (size_t)4 * NG * 256;
+    float* const abuf1 = g.abuf + (size_t)4 * TMW * NG * 256;
 
     gu32* const sync = (gu32*)g.sync;
     auto arrive = [&]() __attribute__((always_inline)) {
@@ -89,7 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     bool dead = false;                                         // a wait timed out: stop waiting, finish the launch
     auto wait_all = [&](unsigned arrival) __attribute__((always_inline)) {     // every workgroup has made arrival number `arrival`
-        if (wave == 0 && !dead) {
+        if (pwave == 0 && !dead) {
             const unsigned mine = lane < kShards ? (unsigned)((nwg + kShards - 1 - lane) / kShards) * (arrival + 1u) : 0u;
             unsigned spins = 0;
             for (;;) {
@@ -110,95 +127,121 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
     // ---- arrival 0: h_0 in fragment order (the image is zero-filled by the launcher: rows >= M and k >= H stay zero)
-    if (rok) {
-        const float h0 = g.h0 ? g.h0[(size_t)row * H + u] : 0.0f;
-        __hip_atomic_store((gu32*)(abuf0 + a_own), __float_as_uint(h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        const int row = row0 + 16 * i;
+        if (row < M) {
+            const float h0 = g.h0 ? g.h0[(size_t)row * H + u] : 0.0f;
+            __hip_atomic_store((gu32*)(abuf0 + a_own + (size_t)i * NG * 256), __float_as_uint(h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    // the carried partial of step 0 (accumulator layout: lane (column l15, row group lq) holds rows lq*4 + r)
+    // the carried partial of step 0 (accumulator layout: lane (column l15, row group lq) holds rows lq*4 + r of a tile)
     const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);          // W / cinit column of slice column l15
-    float ci[4] = {0.f, 0.f, 0.f, 0.f};
+    float ci[TMW][4];
     auto load_cinit = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = wave * 16 + lq * 4 + r;
-            ci[r] = (g.cinit && t < g.cinit_steps && m < M) ? g.cinit[(size_t)t * g.cinit_tstride + (size_t)m * g.ldcinit + ccol] : 0.0f;
-        }
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (wave * TMW + i) * 16 + lq * 4 + r;
+                ci[i][r] = (g.cinit && t < g.cinit_steps && m < M) ? g.cinit[(size_t)t * g.cinit_tstride + (size_t)m * g.ldcinit + ccol] : 0.0f;
+            }
     };
     load_cinit(0);
     arrive();
 
     for (int t = 0; t < T; ++t) {
-        f32x4 acc = {ci[0], ci[1], ci[2], ci[3]};
-        asm volatile("" : "+v"(acc));                          // the partial is in registers before the ring below is issued
+        f32x4 acc[TMW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            acc[i] = f32x4{ci[i][0], ci[i][1], ci[i][2], ci[i][3]};
+            asm volatile("" : "+v"(acc[i]));                   // the partial is in registers before the ring below is issued
+        }
         wait_all((unsigned)t);
-        // ---- all A fragments of this step in flight at once (asm-issued: hipcc neither sinks nor counts them)
+        // ---- A fragments straight into registers.  Ring of RING groups (x TMW row tiles): group j + RING is issued into
+        // group j's registers as soon as its MFMAs have read them.
         const float* acur = (t & 1) ? abuf1 : abuf0;
-        const i32x4 rsA = make_rsrc(acur + (size_t)wave * NG * 256);
-        const uint32_t voff = (uint32_t)lane * 16u;
-        // Ring of RING groups: group j + RING is issued into group j's registers as soon as its MFMAs have read them, so RING
-        // groups (32 KB per wave) stay in flight through the first NG - RING groups and the counted wait is a constant.
-        // (The whole step at once -- 256 registers -- made hipcc move ring registers to AGPRs right behind the asm load,
-        // i.e. before the data had landed.)
-        constexpr int RING = NG < 32 ? NG : 32;
-        f32x4 a[RING];
-        static_for<0, RING>([&](auto j_) { constexpr int j = decltype(j_)::value; bload16_sc1(a[j], voff, rsA, (uint32_t)j * 1024u); });
+        const __amdgpu_buffer_rsrc_t rsA =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)wave * TMW * NG * 256), 0, TMW * NG * 1024, 0x00020000);
+        const int voff = lane * 16;
+        constexpr int RING0 = TMW == 1 ? 32 : 40 / TMW;        // <= 160 ring registers
+        constexpr int RING = NG < RING0 ? NG : RING0;
+        f32x4 a[RING][TMW];
+        static_for<0, RING>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j][i] = bload16_sc1(rsA, voff, (i * NG + j) * 1024); });
+        });
+        __builtin_amdgcn_sched_barrier(0);
         const f32x4* bl = reinterpret_cast<const f32x4*>(Wl) + lane;
         constexpr int PB = NG < 4 ? NG : 4;                    // B fragments read PB groups ahead
         f32x4 b[PB];
         static_for<0, PB>([&](auto j_) { constexpr int j = decltype(j_)::value; b[j] = bl[j * 64]; });
         static_for<0, NG>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            // younger loads still wanted in flight when group j is needed: RING - 1 while refills keep pace, then the tail
-            wait_vmcnt<(j + RING <= NG ? RING - 1 : NG - 1 - j)>();
-            pin(a[j % RING]);
             const f32x4 bj4 = b[j % PB];
             if constexpr (j + PB < NG) b[j % PB] = bl[(j + PB) * 64];
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][0], bj4[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][1], bj4[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][2], bj4[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][3], bj4[3], acc, 0, 0, 0);
+            static_for<0, 4>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                static_for<0, TMW>([&](auto i_) {
+                    constexpr int i = decltype(i_)::value;
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][i][e], bj4[e], acc[i], 0, 0, 0);
+                });
+            });
             if constexpr (j + RING < NG) {
-                __builtin_amdgcn_sched_barrier(0);             // the refill stays BEHIND the MFMAs that read these registers
-                bload16_sc1(a[j % RING], voff, rsA, (uint32_t)(j + RING) * 1024u);
+                __builtin_amdgcn_sched_barrier(0);             // the refill stays behind the MFMAs that read these registers, and in place
+                static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j % RING][i] = bload16_sc1(rsA, voff, (i * NG + j + RING) * 1024); });
+                __builtin_amdgcn_sched_barrier(0);
             }
         });
-        // ---- gates of a unit meet through the wave's LDS tile: z[row][uu*4 + gate]
+        // ---- per row tile: the gates of a unit meet through the wave's LDS tile z[row][uu*4 + gate]; BasicLSTMCell
+        // pointwise (gate order i, j, f, o; forget_bias 1.0 added at run time) -- the EPI_LSTM expressions
+        float hv[TMW], siv[TMW], tjv[TMW], sfv[TMW], sov[TMW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[r];
-        __builtin_amdgcn_wave_barrier();
-        const f32x4 z = *reinterpret_cast<const f32x4*>(zb + rt * ZS + uu * 4);
-        __builtin_amdgcn_wave_barrier();
-        // BasicLSTMCell pointwise (gate order i, j, f, o; forget_bias 1.0 added at run time) -- the EPI_LSTM expressions
-        const float zi = z[0] + bi, zj = z[1] + bj, zf = z[2] + bf, zo = z[3] + bo;
-        const float si = dm_sigmoidf(zi);
-        const float tj = dm_tanhf(zj);
-        const float sf = dm_sigmoidf(zf + 1.0f);
-        const float so = dm_sigmoidf(zo);
-        const float t1 = c_reg * sf;
-        const float t2 = si * tj;
-        const float c = t1 + t2;
-        const float h = dm_tanhf(c) * so;
-        c_reg = c;
+        for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 z = *reinterpret_cast<const f32x4*>(zb + rt * ZS + uu * 4);
+            __builtin_amdgcn_wave_barrier();
+            const float zi = z[0] + bi, zj = z[1] + bj, zf = z[2] + bf, zo = z[3] + bo;
+            const float si = dm_sigmoidf(zi);
+            const float tj = dm_tanhf(zj);
+            const float sf = dm_sigmoidf(zf + 1.0f);
+            const float so = dm_sigmoidf(zo);
+            const float t1 = c_reg[i] * sf;
+            const float t2 = si * tj;
+            const float c = t1 + t2;
+            hv[i] = dm_tanhf(c) * so;
+            c_reg[i] = c;
+            siv[i] = si; tjv[i] = tj; sfv[i] = sf; sov[i] = so;
+        }
         // The hand-off first: h_t write-through, drained and signalled BEFORE the history stores, which nobody in this
         // launch reads -- they complete under the other workgroups' arrival (and only have to by the end of the kernel).
         if (t + 1 < T) {
-            if (rok)
-                __hip_atomic_store((gu32*)(((t & 1) ? abuf0 : abuf1) + a_own), __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+                if (row0 + 16 * i < M)
+                    __hip_atomic_store((gu32*)(((t & 1) ? abuf0 : abuf1) + a_own + (size_t)i * NG * 256), __float_as_uint(hv[i]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             arrive();
         }
-        if (rok) {
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int row = row0 + 16 * i;
+            if (row >= M) continue;
             const size_t o = (size_t)row * H + u;
-            g.C[(size_t)(t + 1) * g.state_tstride + o] = c;
-            g.Hh[(size_t)(t + 1) * g.state_tstride + o] = h;
+            g.C[(size_t)(t + 1) * g.state_tstride + o] = c_reg[i];
+            g.Hh[(size_t)(t + 1) * g.state_tstride + o] = hv[i];
             if (g.out) {
-                float ov = h;
-                if (g.keep < 1.0f) ov = (h / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid, sid, g.drop_code0 + (uint32_t)t, (uint32_t)u, g.keep);
+                float ov = hv[i];
+                if (g.keep < 1.0f)
+                    ov = (hv[i] / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)u, g.keep);
                 g.out[(size_t)t * g.out_tstride + o] = ov;
             }
             if (g.gates) {
                 float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)row * 4 * H + u;
-                gp[0] = si; gp[H] = tj; gp[2 * H] = sf; gp[3 * H] = so;
+                gp[0] = siv[i]; gp[H] = tjv[i]; gp[2 * H] = sfv[i]; gp[3 * H] = sov[i];
             }
         }
         if (t + 1 < T) load_cinit(t + 1);
@@ -206,8 +249,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 typedef void (*ChainFn)(const ChainArgs);
-struct ChainCfg { int ng; ChainFn fn; };
-const ChainCfg kChain[] = {{8, lstm_chain_kernel<8>}, {64, lstm_chain_kernel<64>}};
+struct ChainCfg { int ng, tmw; ChainFn fn; const char* name; };
+constexpr int kMaxTmw = 6;                                     // 6 row tiles per wave x 4 waves x 16 rows = 384 rows
+const ChainCfg kChain[] = {
+    {8, 1, lstm_chain_kernel<8, 1>, "chain(ng8,m64)"},      {8, 2, lstm_chain_kernel<8, 2>, "chain(ng8,m128)"},
+    {8, 3, lstm_chain_kernel<8, 3>, "chain(ng8,m192)"},     {8, 4, lstm_chain_kernel<8, 4>, "chain(ng8,m256)"},
+    {8, 5, lstm_chain_kernel<8, 5>, "chain(ng8,m320)"},     {8, 6, lstm_chain_kernel<8, 6>, "chain(ng8,m384)"},
+    {64, 1, lstm_chain_kernel<64, 1>, "chain(ng64,m64)"},   {64, 2, lstm_chain_kernel<64, 2>, "chain(ng64,m128)"},
+    {64, 3, lstm_chain_kernel<64, 3>, "chain(ng64,m192)"},  {64, 4, lstm_chain_kernel<64, 4>, "chain(ng64,m256)"},
+    {64, 5, lstm_chain_kernel<64, 5>, "chain(ng64,m320)"},  {64, 6, lstm_chain_kernel<64, 6>, "chain(ng64,m384)"},
+};
+int chain_cfg(int M, int H)                                    // index into kChain, or -1
+{
+    const int ng = (H + 15) / 16 <= 8 ? 8 : 64, tmw = (M + 63) / 64;
+    for (int i = 0; i < (int)(sizeof(kChain) / sizeof(kChain[0])); ++i)
+        if (kChain[i].ng == ng && kChain[i].tmw == tmw) return i;
+    return -1;
+}
 
 std::once_flag g_chain_once;
 int g_num_cus = 0;
@@ -219,7 +277,13 @@ unsigned* g_status_dev = nullptr;
 size_t chain_scratch_floats(int H)
 {
     const int ng = (H + 15) / 16 <= 8 ? 8 : 64;
-    return (size_t)2 * 4 * ng * 256;                          // two fragment images of h (ping-pong)
+    return (size_t)2 * 4 * kMaxTmw * ng * 256;                // two fragment images of h (ping-pong), up to 384 rows
+}
+
+static int chain_max_rows()
+{
+    static const int v = [] { const char* e = getenv("S2VT_CHAIN_MAXM"); return e ? atoi(e) : 64 * kMaxTmw; }();   // dev knob
+    return v;
 }
 
 bool chain_eligible(int M, int H)
@@ -242,7 +306,7 @@ bool chain_eligible(int M, int H)
         }
         if (!ok || !g_status_dev) g_num_cus = 0;               // an LDS request refused / no status word: the per-step path serves
     });
-    return !off && M >= 1 && M <= 64 && H >= 4 && (H & 3) == 0 && H <= 1024 && H / 4 <= g_num_cus;
+    return !off && M >= 1 && chain_cfg(M, H) >= 0 && M <= chain_max_rows() && H >= 4 && (H & 3) == 0 && H <= 1024 && H / 4 <= g_num_cus;
 }
 
 hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
@@ -250,18 +314,19 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
     if (!chain_eligible(a.M, a.H)) return hipErrorInvalidValue;
     if (a.T <= 0) return hipSuccess;
     if ((reinterpret_cast<uintptr_t>(a.W) & 15) || (a.ldw & 3) || (reinterpret_cast<uintptr_t>(a.abuf) & 15)) return hipErrorInvalidValue;
-    const ChainCfg& c = (a.H + 15) / 16 <= 8 ? kChain[0] : kChain[1];
+    const int ci = chain_cfg(a.M, a.H);
+    const ChainCfg& c = kChain[ci];
     ChainArgs a2 = a;
     a2.status = g_status_dev;
     // every polled word and the fragment images start from zero on EVERY call (a memset node ahead of the launch)
     hipError_t e = hipMemsetAsync(a.sync, 0, kChainSyncBytes, st);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.abuf, 0, chain_scratch_floats(a.H) * 4, st);
+    e = hipMemsetAsync(a.abuf, 0, (size_t)2 * 4 * c.tmw * c.ng * 256 * 4, st);
     if (e != hipSuccess) return e;
     const int lds = (c.ng * 256 + 4 * 16 * 20) * 4;
     const dim3 grid((unsigned)(a.H / 4));
     const double flops = 2.0 * a.M * (double)a.H * 4.0 * a.H * a.T;
-    if (!prof_wants(5, c.ng == 8 ? 0 : 1)) {
+    if (!prof_wants(5, ci)) {
         hipLaunchKernelGGL(c.fn, grid, dim3(256), lds, st, a2);
         return hipGetLastError();
     }
@@ -271,7 +336,7 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
     (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(c.fn, grid, dim3(256), lds, st, a2);
     (void)hipEventRecord(e1, st);
-    prof_record(5, c.ng == 8 ? 0 : 1, c.ng == 8 ? "chain(ng8)" : "chain(ng64)", flops, e0, e1);
+    prof_record(5, ci, c.name, flops, e0, e1);
     return hipGetLastError();
 }
 

@@ -157,6 +157,7 @@ int choose_lstm(int M)
 }
 
 std::once_flag g_attr_once;
+hipError_t g_attr_err = hipSuccess;        // first refusal of a dynamic-LDS request: reported by every launch instead of an opaque launch failure
 
 // ---- launch profiler state
 struct Pending { int cls, cfg; const char* name; double flops; hipEvent_t e0, e1; };
@@ -164,6 +165,7 @@ std::mutex g_prof_mu;
 bool g_prof_on = false;
 int g_prof_cls = -1, g_prof_cfg = -1;      // >= 0: only launches of this (class, tile cfg) are bracketed by events
 std::vector<Pending> g_pending;
+constexpr size_t kMaxPending = 1u << 16;    // launches between two prof_collect() calls that are kept (~100 bench steps)
 std::vector<hipEvent_t> g_event_pool;
 
 void set_lds_attrs()
@@ -172,10 +174,11 @@ void set_lds_attrs()
         int n;
         const CfgEntry* t = table(epi, &n);
         for (int i = 0; i < n; ++i) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t[i].vec), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      t[i].lds_bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(t[i].scalar),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, t[i].lds_bytes);
+            for (KernelFn fn : {t[i].vec, t[i].scalar}) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         t[i].lds_bytes);
+                if (e != hipSuccess && g_attr_err == hipSuccess) g_attr_err = e;
+            }
         }
     }
 }
@@ -215,6 +218,11 @@ hipError_t prof_events(hipEvent_t* e0, hipEvent_t* e1)
 void prof_record(int cls, int cfg, const char* name, double flops, hipEvent_t e0, hipEvent_t e1)
 {
     std::lock_guard<std::mutex> l(g_prof_mu);
+    if (g_pending.size() >= kMaxPending) {             // nobody collects: stop recording rather than grow without bound
+        g_event_pool.push_back(e0);
+        g_event_pool.push_back(e1);
+        return;
+    }
     g_pending.push_back(Pending{cls, cfg, name, flops, e0, e1});
 }
 
@@ -259,6 +267,7 @@ const char* gemm_cfg_name(int epi, int cfg)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
 {
     std::call_once(g_attr_once, set_lds_attrs);
+    if (g_attr_err != hipSuccess) return g_attr_err;
     int n;
     const CfgEntry* t = table(epi, &n);
     // vocab pick: 64x96 tiles put ~3 independent workgroups on every CU at M = (K+1)*B = 384 (750 tiles); measured

@@ -29,6 +29,7 @@ class Config:
     model_path: str = "./models"
     model_name: str = "s2vt_model"
     max_steps_per_epoch: int = 0       # 0 = the whole epoch (tests bound it)
+    step_log: str = ""                 # path of a JSONL step log ("" = none)
 
 
 class Corpus:
@@ -38,6 +39,25 @@ class Corpus:
             vocabulary = data.read_vocabulary(vocabulary_file)
         self.vocabulary = vocabulary
         self.index = data.CaptionIndex(self.captions)
+
+
+class StepLog:
+    """One JSON object per line per training step / epoch (the reference prints and appends to loss.txt, tf_s2vt.py:463-499):
+    machine-readable, flushed per record, safe to tail.  path=None disables it."""
+
+    def __init__(self, path=None):
+        self._f = open(path, "a") if path else None
+
+    def write(self, **record):
+        if self._f:
+            import json
+            self._f.write(json.dumps(record) + "\n")
+            self._f.flush()
+
+    def close(self):
+        if self._f:
+            self._f.close()
+            self._f = None
 
 
 def learning_rate(cfg: Config, global_step: int) -> float:

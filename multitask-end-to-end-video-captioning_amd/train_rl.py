@@ -21,7 +21,7 @@ import time
 import numpy as np
 
 from . import hostglue, reward
-from .train_common import Config, Corpus, epoch_batches, greedy_eval, learning_rate, optimistic_restore, save_checkpoint
+from .train_common import Config, Corpus, StepLog, epoch_batches, greedy_eval, learning_rate, optimistic_restore, save_checkpoint
 
 
 def rl_config(**kw):
@@ -47,6 +47,7 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
     rng = random.Random(cfg.seed)
     caps = train_corpus.captions
     history = []
+    steplog = StepLog(cfg.step_log)
     if test_corpus is not None:
         log(f"before train: ciderD {greedy_eval(model, test_corpus, ixtoword, test_scorer, cfg.batch_size)[1]}")
     for epoch in range(cfg.n_epochs):
@@ -74,12 +75,15 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
             losses.append(float(st.loss)); adv.append(float(r.mean() - b.mean()))
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} loss: {losses[-1]:.5f} "
                 f"r: {r.mean():.4f} b: {b.mean():.4f} Elapsed time: {time.time() - t0:.3f}")
+            steplog.write(kind="step", epoch=epoch, step=model.global_step, lr=learning_rate(cfg, model.global_step), loss=losses[-1], reward=float(r.mean()), baseline=float(b.mean()), seconds=time.time() - t0)
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None, "r_minus_b": float(np.mean(adv)) if adv else None}
         if test_corpus is not None:
             _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, test_scorer, cfg.batch_size)
         entry["checkpoint"] = save_checkpoint(model, cfg, epoch)
         history.append(entry)
+        steplog.write(kind="epoch", **entry)
         log(f"Epoch {epoch} is done: {entry}")
+    steplog.close()
     return model, history
 
 

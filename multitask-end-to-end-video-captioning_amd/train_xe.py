@@ -14,7 +14,7 @@ import time
 import numpy as np
 
 from . import hostglue, reward
-from .train_common import Config, Corpus, epoch_batches, greedy_eval, learning_rate, save_checkpoint
+from .train_common import Config, Corpus, StepLog, epoch_batches, greedy_eval, learning_rate, save_checkpoint
 
 
 def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, log=print):
@@ -29,6 +29,7 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
     rng = random.Random(cfg.seed)
     caps = train_corpus.captions
     history = []
+    steplog = StepLog(cfg.step_log)
     for epoch in range(cfg.n_epochs):
         losses = []
         for it, idx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
@@ -42,12 +43,15 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
             losses.append(float(st.loss))
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
                 f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")
+            steplog.write(kind="step", epoch=epoch, step=model.global_step, lr=learning_rate(cfg, model.global_step), loss=losses[-1], seconds=time.time() - t0)
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None}
         if test_corpus is not None:
             _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, scorer, cfg.batch_size)
         entry["checkpoint"] = save_checkpoint(model, cfg, epoch)
         history.append(entry)
+        steplog.write(kind="epoch", **entry)
         log(f"Epoch {epoch} is done: {entry}")
+    steplog.close()
     return model, history
 
 

@@ -1,5 +1,5 @@
 """The persistent LSTM recurrence (csrc/chain.hip: T steps in one launch, recurrent weights resident in LDS, state
-exchanged through L2 behind a grid-wide hand-off) against (1) T per-step launches of the fused cell kernel -- every state,
+exchanged through L2 behind a grid-wide hand-off; M <= 384 rows) against (1) T per-step launches of the fused cell kernel -- every state,
 gate and dropped output BIT-identical -- and (2) the CPU oracle's BasicLSTMCell steps (tf_s2vt.py:113-153 restated).
 Also under load on a second stream (hand-offs must not depend on timing) and repeated back to back (stale-state check:
 every polled word and the fragment images are re-zeroed per call)."""
@@ -28,6 +28,9 @@ SHAPES = [  # M, E, H, T, steps with a carried partial
     (64, 500, 1000, 25, 5),        # LSTM1 of the bench: B = 64, 5 frame steps with the hoisted input partial, 20 decode steps
     (32, 500, 1000, 25, 25),       # the multitask per-GPU batch, a partial at every step (LSTM2 form)
     (17, 500, 1000, 3, 1),
+    (100, 8, 64, 4, 4), (130, 12, 128, 3, 0),   # two / three row tiles per wave
+    (320, 500, 1000, 25, 25),                     # LSTM2 of build_loss at K * B = 320 rows: five row tiles per wave
+    (384, 500, 1000, 4, 2), (200, 500, 1000, 3, 3),
 ]
 
 
@@ -58,11 +61,12 @@ def test_persistent_recurrence_equals_per_step_launches(gpu, oracle, M, E, H, T,
             c, h = rc, rh
 
 
-def test_persistent_recurrence_gates_over_the_partial_and_under_load(gpu):
+@pytest.mark.parametrize("M_", [64, 320])
+def test_persistent_recurrence_gates_over_the_partial_and_under_load(gpu, M_):
     """build_model's LSTM2 form: the activated gates overwrite the hoisted partial they continue from (G2 in train.hip);
     run while a second stream keeps the chip busy with unrelated kernels, several times -- same bits every time."""
     import torch
-    M, E, H, T = 64, 500, 1000, 25
+    M, E, H, T = M_, 500, 1000, 25
     W, b, h0, c0, cinit, vid, sid = _case(M, E, H, T, T, seed=5)
     dW, db, dh0, dc0 = _dev(W), _dev(b), _dev(h0), _dev(c0)
     ref = gpu.lstm_recurrence_fwd(dW, E, db, dh0, dc0, T, cinit=_dev(cinit), cinit_steps=T, keep=0.9, seed=3, video_id=_dev(vid),
@@ -89,6 +93,6 @@ def test_persistent_form_refuses_shapes_it_cannot_hold(gpu):
         gpu.lstm_recurrence_fwd(W, 8, b, h0, h0, 2, persistent=1)            # H = 6 is not a multiple of 4
     C, Hh, _, _ = gpu.lstm_recurrence_fwd(W, 8, b, h0, h0, 2, persistent=-1)  # auto: falls back to per-step launches
     assert C.shape == (3, 3, 6)
-    W = torch.zeros(4 + 8, 32, device="cuda"); b = torch.zeros(32, device="cuda"); h0 = torch.zeros(65, 8, device="cuda")
+    W = torch.zeros(4 + 8, 32, device="cuda"); b = torch.zeros(32, device="cuda"); h0 = torch.zeros(385, 8, device="cuda")
     with pytest.raises(RuntimeError, match="bad argument"):
-        gpu.lstm_recurrence_fwd(W, 4, b, h0, h0, 2, persistent=1)            # M = 65 rows
+        gpu.lstm_recurrence_fwd(W, 4, b, h0, h0, 2, persistent=1)            # M = 385 rows: more than 6 row tiles per wave

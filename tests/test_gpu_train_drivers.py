@@ -36,10 +36,14 @@ def test_xe_then_rl_drivers(tmp_path):
     corpus = tc.Corpus(sents, feats, vocabulary=vocab)
     assert len(corpus.features) == 12 and corpus.features.features.shape == (12, 3, 24)
     cfg = tc.Config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=6, batch_size=8,
-                    start_learning_rate=2e-2, model_path=str(tmp_path / "m"), model_name="xe")
+                    start_learning_rate=2e-2, model_path=str(tmp_path / "m"), model_name="xe", step_log=str(tmp_path / "xe.jsonl"))
     quiet = lambda *_: None
     model, hist = train_xe.train(cfg, corpus, corpus, log=quiet)
     assert hist[-1]["loss"] < 0.7 * hist[0]["loss"]                      # it learns
+    import json
+    recs = [json.loads(l) for l in open(tmp_path / "xe.jsonl")]          # machine-readable step log: one object per step / epoch
+    assert sum(r["kind"] == "epoch" for r in recs) == 6 and all("loss" in r for r in recs)
+    assert [r["step"] for r in recs if r["kind"] == "step"] == list(range(1, model.global_step + 1))
     assert os.path.exists(hist[-1]["checkpoint"]) and hist[-1]["ciderD"] is not None
     rl = train_rl.rl_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=1,
                             batch_size=8, multisample=3, start_learning_rate=1e-3, model_path=str(tmp_path / "m"), model_name="rl")
