@@ -200,6 +200,11 @@ int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, cons
  * data-parallel all-reduce by s2vt_grad_finalize.  lp_target (optional) = log-prob of target. */
 int s2vt_softmax_nll_fwd_bwd(float* logits, int32_t ld, int32_t R, int32_t V, const int32_t* target, const float* coef,
                              float smoothing, float* nll, float* lp_target, s2vt_stream stream);
+/* The same with one label-smoothing value PER ROW (smoothing_rows [R]): rows of two objectives -- the reward-scaled NLL of
+ * sampled captions (s = 0) and the smoothed XE of ground-truth captions (s = 0.05), reinforce_multitask_e2e_attribute_s2vt.py:850
+ * -- share one teacher-forced pass. */
+int s2vt_softmax_nll_fwd_bwd_rows(float* logits, int32_t ld, int32_t R, int32_t V, const int32_t* target, const float* coef,
+                                  const float* smoothing_rows, float* nll, float* lp_target, s2vt_stream stream);
 
 /* ---- back-propagation through the unroll (what tf.gradients builds, :650) ---------------------
  * dlogits [Tc*N, V] time-major (output of s2vt_softmax_nll_fwd_bwd); the workspace must still hold

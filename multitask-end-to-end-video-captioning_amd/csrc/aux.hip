@@ -70,8 +70,10 @@ hipError_t launch_prep_caption(const int32_t* cap, int32_t* prev, int32_t* tgt, 
 // One workgroup per row; the row is re-read from L2 (48 KB at V=12k), HBM sees one read + one write.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_nll_kernel(float* logits, int ld, int V, const int32_t* target,
-                                                          const float* coef, float smoothing, float* nll, float* lp_t)
+                                                          const float* coef, float smoothing_all, const float* smooth_rows,
+                                                          float* nll, float* lp_t)
 {
+    const float smoothing = smooth_rows ? smooth_rows[blockIdx.x] : smoothing_all;      // per-row label smoothing (rows of two objectives in one pass)
     __shared__ float sh[8];
     const int row = blockIdx.x;
     float* l = logits + (size_t)row * ld;
@@ -134,8 +136,10 @@ __global__ __launch_bounds__(256) void softmax_nll_kernel(float* logits, int ld,
 // pass -- HBM and L2 see one read and one write of the row, and each element costs one exp instead of two.
 template <int NV4>
 __global__ __launch_bounds__(256) void softmax_nll_reg_kernel(float* logits, int ld, int V, const int32_t* target,
-                                                              const float* coef, float smoothing, float* nll, float* lp_t)
+                                                              const float* coef, float smoothing_all, const float* smooth_rows,
+                                                              float* nll, float* lp_t)
 {
+    const float smoothing = smooth_rows ? smooth_rows[blockIdx.x] : smoothing_all;
     __shared__ float sh[8];
     const int row = blockIdx.x;
     float* l = logits + (size_t)row * ld;
@@ -199,16 +203,16 @@ __global__ __launch_bounds__(256) void softmax_nll_reg_kernel(float* logits, int
 }
 
 hipError_t launch_softmax_nll(float* logits, int ld, int R, int V, const int32_t* target, const float* coef,
-                              float smoothing, float* nll, float* lp_t, hipStream_t st)
+                              float smoothing, float* nll, float* lp_t, hipStream_t st, const float* smooth_rows)
 {
     if (R <= 0) return hipSuccess;
     const bool vec = (ld & 3) == 0 && (V & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
     if (vec && V <= 1024 * 4)
-        hipLaunchKernelGGL(softmax_nll_reg_kernel<4>, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, nll, lp_t);
+        hipLaunchKernelGGL(softmax_nll_reg_kernel<4>, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, smooth_rows, nll, lp_t);
     else if (vec && V <= 1024 * 12)
-        hipLaunchKernelGGL(softmax_nll_reg_kernel<12>, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, nll, lp_t);
+        hipLaunchKernelGGL(softmax_nll_reg_kernel<12>, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, smooth_rows, nll, lp_t);
     else
-        hipLaunchKernelGGL(softmax_nll_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, nll, lp_t);
+        hipLaunchKernelGGL(softmax_nll_kernel, dim3(R), dim3(256), 0, st, logits, ld, V, target, coef, smoothing, smooth_rows, nll, lp_t);
     return hipGetLastError();
 }
 

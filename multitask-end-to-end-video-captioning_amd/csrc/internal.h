@@ -37,7 +37,7 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st);
 
 hipError_t launch_prep_caption(const int32_t* cap, int32_t* prev, int32_t* tgt, int N, int Tc, hipStream_t st);
 hipError_t launch_softmax_nll(float* logits, int ld, int R, int V, const int32_t* target, const float* coef,
-                              float smoothing, float* nll, float* lp_t, hipStream_t st);
+                              float smoothing, float* nll, float* lp_t, hipStream_t st, const float* smooth_rows = nullptr);
 hipError_t launch_softmax_unshifted_argmax(const float* logits, int ld, int R, int V, int32_t* ids, float* probs, hipStream_t st);
 hipError_t launch_lstm_bwd_pointwise(const float* gates, const float* c_new, const float* c_prev, const float* dh_rec,
                                      int nslab, size_t slab_stride, const float* dout_ext, int ld_ext, const float* dc_in,

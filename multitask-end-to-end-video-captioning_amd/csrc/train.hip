@@ -247,6 +247,14 @@ int s2vt_softmax_unshifted_argmax(const float* logits, int32_t ld, int32_t R, in
     return S2VT_OK;
 }
 
+int s2vt_softmax_nll_fwd_bwd_rows(float* logits, int32_t ld, int32_t R, int32_t V, const int32_t* target, const float* coef,
+                                  const float* smoothing_rows, float* nll, float* lp_target, s2vt_stream stream)
+{
+    if (!logits || !target || !coef || !smoothing_rows || R < 0 || V <= 0 || ld < V) return S2VT_E_BADARG;
+    HIP_TRY(launch_softmax_nll(logits, ld, R, V, target, coef, 0.0f, nll, lp_target, S(stream), smoothing_rows));
+    return S2VT_OK;
+}
+
 int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
                   int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                   const int32_t* sample_id, void* workspace, size_t workspace_bytes, s2vt_stream stream)

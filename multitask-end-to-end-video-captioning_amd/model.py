@@ -312,7 +312,7 @@ class Video_Caption_Generator:
         B = video.shape[0]
         N = caption.shape[0]
         vid, sid = self._row_ids(B, rep, video_base)
-        seed = self.dropout_seed + 104729 * self.global_step + 7 * getattr(self, "global_step_dropout_offset", 0)
+        seed = self.dropout_seed + 104729 * self.global_step
         state = None
         if reuse_sampler_state:
             ls = getattr(self, "_sampler_state", None)
@@ -489,9 +489,11 @@ class Video_Caption_Generator:
             sum_loss = -(1 - lambda) * PG / sum(mask_pg)  +  lambda * model_loss
         with PG the reward-scaled log-likelihood of the SAMPLED captions (build_loss) and model_loss the
         cross-entropy loss of build_model on the GROUND-TRUTH captions of the same videos (label smoothing, Q1,
-        weight decay), clip 5, Adam.  Two teacher-forced passes accumulate into one gradient bucket, each with its
-        coefficient already divided by its GLOBAL mask sum (one tiny all-reduce first), so the bucket needs no
-        further normalisation.  With true_labels [B, label_dim] (and a model built with label_dim > 0) the attribute head's
+        weight decay), clip 5, Adam.  The reference evaluates two graphs on the same videos; here the rep*B sampled rows and
+        the B ground-truth rows are ONE teacher-forced pass of (rep+1)*B sample-major rows (the ground truth is "sample"
+        number rep: its own dropout masks, label smoothing per row, each block's coefficient already divided by its GLOBAL
+        mask sum), so the unrolls, the vocabulary products and the backward run once -- at B = 32, K = 1 that is 64 rows
+        for the price of 32.  With true_labels [B, label_dim] (and a model built with label_dim > 0) the attribute head's
         term of reinforce_multitask_e2e_attribute_loss.py:957 is added: + alpha * sum(bce) / (label_dim * B_global) --
         the per-GPU shape of BASELINE configs[3] (attribute FC + XE mix + REINFORCE, K = 1)."""
         video = self._dev(video, torch.float32)
@@ -502,29 +504,28 @@ class Video_Caption_Generator:
         adv = self._dev(rewards, torch.float32) - self._dev(baseline, torch.float32)
         B = video.shape[0]
         rep = cap.shape[0] // B
+        assert gcap.shape[0] == B, "one ground-truth caption per video of the batch (reinforce_multitask_e2e_attribute_s2vt.py:977)"
         keep = self.dropout_rate if keep is None else keep
         lam = float(lambda_loss)
         sums = torch.stack([mask.sum(), gmask.sum()])
-        dp.allreduce_small(sums)                                           # global sum(mask) of both passes
-        # ---- pass 1: policy gradient on the sampled captions
-        coef_pg = (mask * (adv * (1.0 - lam))[:, None] / sums[0]).t().contiguous().view(-1)
-        nll, _ = self._forward_loss(video, cap, coef_pg, 0.0, rep, video_base, keep)
-        loss_pg = torch.dot(coef_pg, nll)
-        self.backward(accumulate=False, overlap=False)
-        # ---- pass 2: cross entropy on the ground truth (tf_s2vt.py:150-166 semantics, as xe_update)
-        Ng = gcap.shape[0]
-        if q1:
+        dp.allreduce_small(sums)                                           # global sum(mask) of both objectives
+        coef_pg = mask * (adv * (1.0 - lam))[:, None] / sums[0]            # [rep*B, Tc] policy gradient on the sampled captions
+        if q1:                                                             # cross entropy on the ground truth (tf_s2vt.py:150-166, as xe_update)
             colsum = gmask.sum(0)
             dp.allreduce_small(colsum)
-            coef_xe = (colsum[:, None] / float(Ng * self.world_size)).expand(-1, Ng) * self.loss_weight
+            coef_xe = (colsum[None, :] / float(B * self.world_size)).expand(B, -1) * self.loss_weight
         else:
-            coef_xe = gmask.t() * self.loss_weight
-        coef_xe = (coef_xe * (lam / sums[1])).contiguous().view(-1)
-        self.global_step_dropout_offset = 1                                # a different dropout stream than pass 1
-        nll2, _ = self._forward_loss(video, gcap, coef_xe, smoothing, 1, video_base, keep)
-        self.global_step_dropout_offset = 0
-        loss_xe = torch.dot(coef_xe, nll2)
-        self.backward(accumulate=True, overlap=False)
+            coef_xe = gmask * self.loss_weight
+        coef_xe = coef_xe * (lam / sums[1])                                # [B, Tc]
+        coef = torch.cat([coef_pg, coef_xe], 0).t().contiguous().view(-1)  # time-major over the (rep+1)*B rows
+        smooth = torch.zeros((rep + 1) * B, dtype=torch.float32, device=self.device)
+        smooth[rep * B:] = float(smoothing)
+        smooth_tm = smooth.repeat(self.n_caption_lstm_step).contiguous()
+        nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, rep + 1, video_base, keep)
+        N = (rep + 1) * B
+        per_row = (coef * nll).view(-1, N)
+        loss_pg, loss_xe = per_row[:, :rep * B].sum(), per_row[:, rep * B:].sum()
+        self.backward(accumulate=False, overlap=False)
         attr_scale = attr_loss = None
         if true_labels is not None and self.label_dim > 0:
             y = self._dev(true_labels, torch.float32)

@@ -226,12 +226,19 @@ def teacher_forced_fwd(dims: Dims, params: Params, video, caption, N: int, keep=
 
 
 def softmax_nll_fwd_bwd(logits, target, coef, smoothing=0.0):
-    """In place: logits <- coef * (softmax - q).  Returns (nll [R], lp_target [R])."""
+    """In place: logits <- coef * (softmax - q).  Returns (nll [R], lp_target [R]).  smoothing: a float, or a CUDA fp32
+    tensor [R] with one label-smoothing value per row."""
     _chk_f32(logits, coef)
     R, V = logits.shape
     assert target.dtype == torch.int32 and target.is_cuda and target.numel() == R and coef.numel() == R
     nll = torch.empty(R, dtype=torch.float32, device=logits.device)
     lp = torch.empty_like(nll)
+    if isinstance(smoothing, torch.Tensor):
+        _chk_f32(smoothing)
+        assert smoothing.numel() == R and smoothing.is_contiguous()
+        check(lib().s2vt_softmax_nll_fwd_bwd_rows(_ptr(logits), logits.stride(0), R, V, _ptr(target), _ptr(coef), _ptr(smoothing),
+                                                  _ptr(nll), _ptr(lp), _stream()), "s2vt_softmax_nll_fwd_bwd_rows")
+        return nll, lp
     check(lib().s2vt_softmax_nll_fwd_bwd(_ptr(logits), logits.stride(0), R, V, _ptr(target), _ptr(coef), float(smoothing),
                                          _ptr(nll), _ptr(lp), _stream()), "s2vt_softmax_nll_fwd_bwd")
     return nll, lp

@@ -212,7 +212,7 @@ def test_config3_multitask_b32_full_dims_vs_float64_autograd(gpu, oracle):
     p = {n: mdl.store.p[n].cpu().numpy() for n in mdl.store.names}
     s1 = mdl.dropout_seed + 104729 * mdl.global_step
     drop1 = oracle.dropout_masks(s1, vid, sid, keep, H, TV, TC)
-    drop2 = oracle.dropout_masks(s1 + 7, vid, sid, keep, H, TV, TC)                 # the second pass draws its own masks
+    drop2 = oracle.dropout_masks(s1, vid, np.ones(Bs, np.int32), keep, H, TV, TC)    # the ground-truth rows are "sample" 1 of the same pass
     pt = T.to_torch(p, torch.float64, True)
     vt = torch.as_tensor(video).double()
     lg1 = T.teacher_forced(pt, vt, cap, drop1, keep)

@@ -172,8 +172,8 @@ def test_sampler_state_reuse_is_equivalent(gpu, oracle):
 
 
 def test_mixed_pg_xe_objective_vs_float64_autograd(gpu, oracle):
-    """reinforce_multitask_e2e_attribute_s2vt.py:850: -(1-lambda)*PG/sum(mask) + lambda*model_loss, two teacher-forced
-    passes (sampled captions, ground truth) into one bucket, vs float64 autograd with the same dropout masks."""
+    """reinforce_multitask_e2e_attribute_s2vt.py:850: -(1-lambda)*PG/sum(mask) + lambda*model_loss, the sampled
+    rows and the ground-truth rows in one teacher-forced pass, vs float64 autograd with the same dropout masks."""
     import torch
     import s2vt_amd
     from s2vt_amd import model as M
@@ -191,7 +191,8 @@ def test_mixed_pg_xe_objective_vs_float64_autograd(gpu, oracle):
     mdl.store.load(p)
     s1 = mdl.dropout_seed + 104729 * mdl.global_step
     drop1 = oracle.dropout_masks(s1, vid, sid, keep, d.lstm_dim, d.n_video_lstm_step, d.n_caption_lstm_step)
-    drop2 = oracle.dropout_masks(s1 + 7, vid[:B], sid[:B], keep, d.lstm_dim, d.n_video_lstm_step, d.n_caption_lstm_step)
+    # the ground-truth rows ride in the same pass as "sample" number rep of each video: their own dropout masks
+    drop2 = oracle.dropout_masks(s1, vid[:B], np.full(B, rep, np.int32), keep, d.lstm_dim, d.n_video_lstm_step, d.n_caption_lstm_step)
     pt = T.to_torch(p, torch.float64, True)
     lg1 = T.teacher_forced(pt, torch.as_tensor(np.tile(video, (rep, 1, 1))).double(), cap, drop1, keep)
     lg2 = T.teacher_forced(pt, torch.as_tensor(video).double(), gcap, drop2, keep)
