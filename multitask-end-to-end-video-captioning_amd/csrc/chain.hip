@@ -49,6 +49,45 @@ __device__ __forceinline__ f32x4 bload16_sc1(__amdgpu_buffer_rsrc_t rsrc, int vo
 constexpr int kShards = 8;             // counter shards, one 128-byte line each; word kShards * 32 = timeout flag
 constexpr unsigned kSpinLimit = 1u << 21;
 
+// The grid-wide hand-off of the persistent kernels (MI355X_MICROARCH.md "Valid forms", row 1): every storing wave drains its
+// write-through stores / atomics, the workgroup's barrier, ONE lane adds to its shard of the arrival counter; one wave per
+// workgroup polls every shard with sc1 loads (bounded: a timeout raises the status words and stops further waiting), the
+// other waves continue behind the workgroup barrier.  Arrival numbers count from 0 within the launch; the counters are
+// zeroed by a memset node ahead of every launch.
+struct GridSync {
+    gu32* sync;
+    unsigned* status;
+    int nwg;
+    bool dead;
+    __device__ __forceinline__ void arrive(int tid)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(sync + (blockIdx.x & (kShards - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void wait_all(unsigned arrival, int pwave, int lane)
+    {
+        if (pwave == 0 && !dead) {
+            const unsigned mine = lane < kShards ? (unsigned)((nwg + kShards - 1 - lane) / kShards) * (arrival + 1u) : 0u;
+            unsigned spins = 0;
+            for (;;) {
+                const unsigned v = lane < kShards ? __hip_atomic_load(sync + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                if (__all(lane >= kShards || v >= mine)) break;
+                if (++spins > kSpinLimit) {                    // never hang: flag it and go on (results are then garbage, status says so)
+                    if (lane == 0) {
+                        __hip_atomic_store(sync + kShards * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (status) __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible
+                    }
+                    dead = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+    }
+};
+
 template <int NG, int TMW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_chain_kernel(const ChainArgs g)
 {
@@ -98,33 +137,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* const abuf0 = g.abuf;
     float* const abuf1 = g.abuf + (size_t)4 * TMW * NG * 256;
 
-    gu32* const sync = (gu32*)g.sync;
-    auto arrive = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores ...
-        __syncthreads();                                       // ... before the ONE lane that signals for all of them
-        if (tid == 0) __hip_atomic_fetch_add(sync + (blockIdx.x & (kShards - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    bool dead = false;                                         // a wait timed out: stop waiting, finish the launch
-    auto wait_all = [&](unsigned arrival) __attribute__((always_inline)) {     // every workgroup has made arrival number `arrival`
-        if (pwave == 0 && !dead) {
-            const unsigned mine = lane < kShards ? (unsigned)((nwg + kShards - 1 - lane) / kShards) * (arrival + 1u) : 0u;
-            unsigned spins = 0;
-            for (;;) {
-                const unsigned v = lane < kShards ? __hip_atomic_load(sync + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                if (__all(lane >= kShards || v >= mine)) break;
-                if (++spins > kSpinLimit) {                    // never hang: flag it and go on (results are then garbage, status says so)
-                    if (lane == 0) {
-                        __hip_atomic_store(sync + kShards * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (g.status) __hip_atomic_fetch_add(g.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible
-                    }
-                    dead = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __syncthreads();
-    };
+    GridSync gs{(gu32*)g.sync, g.status, nwg, false};
+    auto arrive = [&]() __attribute__((always_inline)) { gs.arrive(tid); };
+    auto wait_all = [&](unsigned arrival) __attribute__((always_inline)) { gs.wait_all(arrival, pwave, lane); };
 
     // ---- arrival 0: h_0 in fragment order (the image is zero-filled by the launcher: rows >= M and k >= H stay zero)
 #pragma unroll
