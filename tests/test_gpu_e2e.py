@@ -172,3 +172,53 @@ def test_feature_dropout_is_slim_dropout(gpu, oracle):
     # ... and independent draws (the sampler graph's and the loss graph's dropout ops) get independent masks from one CNN pass
     (d0, _), (d1, _) = tr.extract(frames, dropout=True, draws=(0, 1))
     assert torch.equal(d0, dropped) and not torch.equal(d1, dropped) and 0.85 < float((d1 != 0).float().mean()) < 0.95
+
+
+def test_e2e_real_inception_resnet_v2_step(gpu):
+    """BASELINE configs[4] with the REAL network (irv2.InceptionResnetV2, 244 conv units, MIOpen convolutions) in front of
+    the HIP captioner at the reference's dimensions (299 x 299 frames, d = 1536, E = 500, H = 1000, Tc = 20; batch 2 x 5
+    frames, a 2,000-word vocabulary to keep it light).  No TF checkpoint exists to compare activations with (the layer
+    table, paddings and BN formula are pinned on the CPU side, tests/test_irv2_cpu.py), so this checks the SEAM on the real
+    network: the features the captioner sees are the network's pooled output with slim.dropout applied, the gradient that
+    reaches the CNN is the directional derivative of the captioner's loss w.r.t. those features (a finite-difference probe
+    along the gradient itself), one global norm spans both halves, and steps with lr > 0 reduce the loss."""
+    import torch
+    from s2vt_amd import e2e, hostglue, irv2, model as M
+    torch.manual_seed(0)
+    B, TV, TC, D, E, H, V = 2, 5, 20, 1536, 500, 1000, 2000
+    cnn = irv2.InceptionResnetV2()
+    mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, dropout_rate=1.0, seed=3)      # no LSTM dropout: the probe below re-runs the loss
+    tr = e2e.EndToEnd(mdl, cnn, feature_keep=1.0)
+    rng = np.random.default_rng(0)
+    frames = torch.as_tensor(rng.uniform(-1, 1, (B, TV, 3, 299, 299)).astype(np.float32))
+    cap = rng.integers(2, V, (B, TC)).astype(np.int32); cap[0, 7:] = 0; cap[1, 12:] = 0
+    mask = hostglue.masks_from_ids(cap)
+    feats, _ = tr.extract(frames, dropout=False)
+    assert feats.shape == (B, TV, D) and float(feats.min()) >= 0.0 and bool(torch.isfinite(feats).all())
+    with torch.no_grad():
+        direct = cnn(frames.cuda().reshape(B * TV, 3, 299, 299)).reshape(B, TV, D)
+    assert torch.allclose(feats, direct, rtol=1e-4, atol=1e-6)          # (MIOpen may pick a different algorithm per call: not bitwise)
+    # lr = 0 step: gradients only
+    st = tr.xe_step(frames, cap, mask, lr=0.0)
+    g_cnn = tr.grad.clone()
+    assert bool(torch.isfinite(g_cnn).all()) and float(g_cnn.abs().max()) > 0
+    cap_sq = sum(float((mdl.store.g[n].double() ** 2).sum()) for n in mdl.store.names)
+    cnn_sq = float((g_cnn.double() ** 2).sum())
+    assert abs(float(st.grad_sumsq) - (cap_sq + cnn_sq)) <= 1e-3 * (cap_sq + cnn_sq)       # ONE clip norm over both halves
+    # the gradient handed across the seam: d loss / d features, probed by a finite difference along itself
+    mdl.global_step = 0
+    dv = mdl.video_grad() / float(mask.sum())                                              # (unnormalised in the workspace)
+
+    def xe_loss_of(f):
+        mdl.global_step = 0
+        c = torch.as_tensor(cap).cuda(); m = torch.as_tensor(mask).cuda()
+        coef = ((m.sum(0)[:, None] / float(B)).expand(-1, B)).contiguous().view(-1)
+        nll, _ = mdl._forward_loss(f.contiguous(), c, coef, 0.05, 1, 0, 1.0)
+        return float(torch.dot(coef, nll).double() / m.sum().double())
+    eps = 1e-2 / float(dv.norm())
+    num = (xe_loss_of(feats + eps * dv) - xe_loss_of(feats - eps * dv)) / (2 * eps)
+    assert abs(num - float((dv.double() ** 2).sum())) <= 5e-2 * float((dv.double() ** 2).sum())
+    # and it learns through the real network
+    mdl.global_step = 0
+    losses = [float(tr.xe_step(frames, cap, mask, lr=1e-3).loss) for _ in range(4)]
+    assert losses[-1] < losses[0] and np.isfinite(losses).all()
