@@ -277,7 +277,8 @@ def main():
                "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "how": "HIP events per step on the launching stream"},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl["desc"], "global_batch": B * world, "samples_per_video": K, "parallelism": f"dp{world}",
-                          "dp_overlap": bool(mdl.dp_overlap), "loss": float(st.loss)},
+                          "dp_overlap": bool(mdl.dp_overlap), "loss": float(st.loss),
+                          "persistent_recurrence_timeouts": ops.chain_timeouts()},      # grid-wide waits that gave up: must be 0
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline and args.workload == "rl":
             out["cpu_baseline"] = cpu_baseline()
