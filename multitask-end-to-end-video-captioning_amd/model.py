@@ -68,8 +68,9 @@ class ParamStore:
         self.v = torch.zeros(off, dtype=torch.float32, device=device)
         self.p = {n: self._view(self.theta, n) for n in self.names}
         self.g = {n: self._view(self.grad, n) for n in self.names}
-        self.params = ops.make_params(self.p)
-        self.grads = ops.make_params(self.g)
+        on_gpu = torch.device(device).type == "cuda"      # (a CPU store serves checkpoint conversion / tests: no kernel can take it)
+        self.params = ops.make_params(self.p) if on_gpu else None
+        self.grads = ops.make_params(self.g) if on_gpu else None
 
     def _view(self, flat, n):
         k = int(np.prod(self.shapes[n]))

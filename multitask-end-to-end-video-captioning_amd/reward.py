@@ -18,7 +18,7 @@ _LIB = None
 def host_lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libs2vt_host.so")
+        path = os.environ.get("S2VT_HOST_LIB") or os.path.join(_HERE, "libs2vt_host.so")   # S2VT_HOST_LIB: the sanitizer build (tests)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: build it with __graft_entry__.build()")
         L = C.CDLL(path)

@@ -1,0 +1,94 @@
+"""Host-side logic that needs no GPU: the sess.run shim's evaluation order, checkpoints under the TF variable names with the
+Adam slots tf.train.Saver keeps, the JSONL step log, the data-parallel switches."""
+import json
+
+import numpy as np
+import torch
+
+
+def test_session_run_evaluates_updates_first_and_shares_their_loss():
+    import s2vt_amd
+    from s2vt_amd.model import Output, Placeholder, Session
+    x = Placeholder("x", (None,), np.float32)
+    state = {"w": 1.0, "evals": []}
+
+    def forward(v):
+        state["evals"].append("fwd")
+        return {"loss": state["w"] * float(np.sum(v)), "probs": np.asarray(v) * state["w"]}
+
+    loss = Output("loss", forward, [x])
+    probs = Output("probs", forward, [x])
+
+    def update(v):                                   # a train_op: computes the loss it differentiates, then changes the variable
+        state["evals"].append("upd")
+        l = state["w"] * float(np.sum(v))
+        state["w"] *= 0.5
+        return {"train_op": None, "loss": l}
+
+    train_op = Output("train_op", update, [x], provides={loss: "loss"})
+    sess = Session(None)
+    feed = {x: np.array([1.0, 2.0], np.float32)}
+    # sess.run([train_op, tf_loss]): ONE evaluation, and the loss is the pre-update one (TF: train_op depends on the loss node)
+    out = sess.run([train_op, loss], feed)
+    assert out == [None, 3.0] and state["evals"] == ["upd"] and state["w"] == 0.5
+    # order in the fetch list does not matter
+    out = sess.run([loss, train_op], feed)
+    assert out == [1.5, None] and state["evals"] == ["upd", "upd"]
+    # two fetches of one graph call share it; a fetch the update does not provide is evaluated after it
+    state["evals"].clear()
+    l, p = sess.run([loss, probs], feed)
+    assert state["evals"] == ["fwd"] and l == 0.25 * 3.0 and np.allclose(p, [0.25, 0.5])
+    assert sess.run(loss, feed) == 0.75                                  # a single fetch returns the bare value
+    try:
+        sess.run(loss, {})
+        assert False
+    except KeyError as e:
+        assert "x" in str(e)                                             # a missing feed names the placeholder
+
+
+def test_checkpoint_keeps_tf_names_adam_slots_and_step():
+    import s2vt_amd
+    from s2vt_amd import model as M
+    shapes = M.param_shapes(8, 11, 4, 4, label_dim=3)
+    a = M.ParamStore(shapes, torch.device("cpu"))
+    M.init_reference(a, seed=1)
+    a.m.uniform_(-1, 1); a.v.uniform_(0, 1)
+    sd = a.state_dict(global_step=7)
+    assert "s2vt/LSTM1/basic_lstm_cell/weights" in sd and "s2vt/LSTM2/basic_lstm_cell/biases/Adam_1" in sd and "Wemb/Adam" in sd
+    assert int(sd["global_step"]) == 7 and abs(float(sd["beta1_power"]) - 0.9 ** 8) < 1e-7
+    b = M.ParamStore(shapes, torch.device("cpu"))
+    loaded = b.load_state_dict(sd)
+    assert b.restored_step == 7 and len(loaded) == 3 * len(a.names) + 1
+    for n in a.names:
+        assert torch.equal(a.p[n], b.p[n]) and torch.equal(a._view(a.m, n), b._view(b.m, n)) and torch.equal(a._view(a.v, n), b._view(b.v, n))
+    # optimistic_restore: a variable of another shape is skipped, unknown names are ignored, variables-only dumps load too
+    sd2 = {k: v for k, v in a.state_dict().items()}
+    sd2["Wemb"] = np.zeros((5, 5), np.float32); sd2["something/else"] = np.zeros(3, np.float32)
+    c = M.ParamStore(shapes, torch.device("cpu"))
+    names = c.load_state_dict(sd2)
+    assert "Wemb" not in names and "something/else" not in names and "encode_image_W" in names and c.restored_step is None
+
+
+def test_step_log_is_one_json_object_per_line(tmp_path):
+    import s2vt_amd
+    from s2vt_amd.train_common import StepLog
+    log = StepLog(str(tmp_path / "s.jsonl"))
+    log.write(kind="step", step=1, loss=0.5)
+    log.write(kind="epoch", epoch=0, loss=0.4, ciderD=None)
+    log.close()
+    recs = [json.loads(l) for l in open(tmp_path / "s.jsonl")]
+    assert recs == [{"kind": "step", "step": 1, "loss": 0.5}, {"kind": "epoch", "epoch": 0, "loss": 0.4, "ciderD": None}]
+    StepLog(None).write(kind="step")                                     # disabled: a no-op
+
+
+def test_data_parallel_switches_without_a_process_group(monkeypatch):
+    import s2vt_amd
+    from s2vt_amd import dist as dp
+    assert dp.world_size() == 1 and not dp.active()
+    monkeypatch.setenv("S2VT_DP_FORCE", "1")
+    assert not dp.active()                                               # forcing needs an initialised process group
+    t = torch.arange(4.0)
+    g = torch.zeros(8)
+    out = dp.allreduce_bucket(g, 4, 3.0)                                 # no group: the bucket is untouched, sum(mask) rides in the tail
+    assert float(out) == 3.0 and dp.allreduce_async(t) is None and torch.equal(dp.allreduce_small(t), torch.arange(4.0))
+    assert dp.shard_range(64, 3, 8) == (24, 32)
