@@ -221,7 +221,7 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
     t.c1 = c.take<float>((T + 1) * B * H); t.h1 = c.take<float>((T + 1) * B * H);     // LSTM1 state history, slot 0 = zeros
     t.G1 = c.take<float>(T * B * 4 * H);                                                // LSTM1 activated gates (reused by the update pass)
     t.P2 = c.take<float>(T * B * 4 * H);                                                // h1[t+1] @ W2[0:H] for every step
-    for (int i = 0; i < 2; ++i) { t.c2e[i] = c.take<float>((size_t)B * H); t.h2e[i] = c.take<float>((size_t)B * H); }
+    t.c2e = c.take<float>((Tv + 1) * (size_t)B * H); t.h2e = c.take<float>((Tv + 1) * (size_t)B * H);
     for (int i = 0; i < 2; ++i) { t.c2[i] = c.take<float>((size_t)R * H); t.h2[i] = c.take<float>((size_t)R * H); }
     t.packed = c.take<unsigned long long>((size_t)Tc * R);
     t.vid = c.take<int32_t>(R); t.sid = c.take<int32_t>(R); t.bos = c.take<int32_t>(R);
@@ -262,7 +262,7 @@ hipError_t lstm_recurrence(const float* W, int kw0, const float* bias, const flo
 
 // Encoding stage (tf_s2vt.py:97-122) plus everything of the decoding stage that does not depend on a
 // sampled word: frame embedding, the whole LSTM1 trajectory, its products with the out1 rows of W2, LSTM2 over
-// the Tv frames.  Leaves the encoder state in w.c2e/h2e[Tv & 1].
+// the Tv frames.  Leaves the encoder state in slot Tv of w.c2e / w.h2e.
 int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, int B, const SampleWs& w, s2vt_stream stream)
 {
     const int H = d->lstm_dim, E = d->word_dim, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
@@ -272,8 +272,8 @@ int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, 
     // zero initial states (tf_s2vt.py:105-107)
     HIP_TRY(hipMemsetAsync(w.c1, 0, BH * 4, st));
     HIP_TRY(hipMemsetAsync(w.h1, 0, BH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.c2e[0], 0, BH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.h2e[0], 0, BH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.c2e, 0, BH * 4, st));
+    HIP_TRY(hipMemsetAsync(w.h2e, 0, BH * 4, st));
     int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
     if (rc != S2VT_OK) return rc;
 
@@ -295,15 +295,9 @@ int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, 
         ASeg so = make_seg(w.h1 + BH, H, H, 0);
         HIP_TRY(store_call(&so, 1, p->lstm2_W, 4 * H, nullptr, w.P2, 4 * H, T * B, 4 * H, 0, -1, st));
     }
-    // ---- LSTM2 encoding stage (tf_s2vt.py:122: word slot = zero padding), M = B
-    int cur = 0;
-    for (int t = 0; t < Tv; ++t) {
-        const int nxt = cur ^ 1;
-        ASeg s2 = make_seg(w.h2e[cur], H, H, H + E);
-        HIP_TRY(lstm_call(&s2, 1, p->lstm2_W, p->lstm2_b, w.c2e[cur], 0, w.c2e[nxt], w.h2e[nxt], nullptr, nullptr, B, H, 1.0f,
-                          none, 0, -1, st, w.P2 + (size_t)t * 4 * BH, 4 * H, 0));
-        cur = nxt;
-    }
+    // ---- LSTM2 encoding stage (tf_s2vt.py:122: word slot = zero padding), M = B: the chain continues from the out1 partial
+    HIP_TRY(lstm_recurrence(p->lstm2_W, H + E, p->lstm2_b, w.P2, (size_t)4 * BH, 4 * H, Tv, w.c2e, w.h2e, BH, nullptr, 0, nullptr, 0, B, H, Tv,
+                            1.0f, none, 0, w.chain_abuf, w.chain_sync, st));
     return S2VT_OK;
 }
 
@@ -323,12 +317,12 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
     HIP_TRY(hipGetLastError());
     NoiseIds none{nullptr, nullptr, 0};
     NoiseIds ids{w.vid, w.sid, seed};
-    const int cur = Tv & 1;                  // where sample_encode left the encoder state
+    const size_t enc = (size_t)Tv * B * H;   // where sample_encode left the encoder state: slot Tv of the history
     int cur2 = 0;
     for (int t = 0; t < Tc; ++t) {
         const int nxt2 = cur2 ^ 1;
-        const float* h2p = t == 0 ? w.h2e[cur] : w.h2[cur2];
-        const float* c2p = t == 0 ? w.c2e[cur] : w.c2[cur2];
+        const float* h2p = t == 0 ? w.h2e + enc : w.h2[cur2];
+        const float* c2p = t == 0 ? w.c2e + enc : w.c2[cur2];
         const int smod = t == 0 ? B : 0;
         ASeg s2[2] = {t == 0 ? make_seg(p->Wemb, E, E, H, 0, w.bos)
                              : make_seg(p->Wemb, E, E, H, 0, nullptr, w.packed + (size_t)(t - 1) * R),

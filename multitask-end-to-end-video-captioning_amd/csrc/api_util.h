@@ -119,7 +119,7 @@ inline hipError_t store_call(const ASeg* segs, int nseg, const float* W, int ldw
 
 // ---- sampler halves (api.hip), shared with the session API (session.hip)
 struct SampleWs {
-    float *emb, *Xp1, *c1, *h1, *G1, *P2, *c2e[2], *h2e[2], *c2[2], *h2[2];
+    float *emb, *Xp1, *c1, *h1, *G1, *P2, *c2e, *h2e, *c2[2], *h2[2];   // c2e / h2e: LSTM2 state history of the encoding stage [Tv+1][B][H]
     unsigned long long* packed;
     int32_t *vid, *sid, *bos;
     float* chain_abuf;       // persistent-recurrence scratch (chain.hip): fragment images of h + arrival counters

@@ -1,4 +1,4 @@
-// chain.hip -- a whole BasicLSTMCell recurrence (T steps, M <= 64 rows) in ONE launch: the unroll of tf_s2vt.py:113-153
+// chain.hip -- a whole BasicLSTMCell recurrence (T steps, M <= 384 rows) in ONE launch: the unroll of tf_s2vt.py:113-153
 // for a cell whose only step-dependent input is a partial that is known before the loop (LSTM1 over a video: frame
 // rows hoisted, then the zero padding; LSTM2 in build_model once [out1 ; embed(word)] @ W2 has been hoisted).
 //
