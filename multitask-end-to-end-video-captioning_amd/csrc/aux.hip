@@ -580,6 +580,7 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     splits = (a.Mred + k.mper - 1) / k.mper;
     k.atomic = splits > 1 ? 1 : 0;
     k.accumulate = a.accumulate;
+    k.colsum = nullptr;
     if (k.atomic && !a.accumulate) {
         hipError_t e = hipMemset2DAsync(a.C, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, a.Kout, st);
         if (e != hipSuccess) return e;
@@ -589,6 +590,13 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
                      // the vector path addresses a chunk (32 rows) of each operand by 32-bit byte offsets from a base it
                      // re-computes per chunk; a gathered A must fit a 2 GiB window (its extent is the caller's table)
                      (size_t)32 * a.lda * 4 < (1ull << 31) && (size_t)32 * a.ldb * 4 < (1ull << 31);
+    if (a.colsum) {
+        if (vec) k.colsum = a.colsum;                                   // fused: the B tiles pass through registers anyway
+        else {
+            hipError_t e = launch_colsum(a.B, a.ldb, a.Mred, a.N, a.colsum, st);
+            if (e != hipSuccess) return e;
+        }
+    }
     if (!prof_wants(3, ci)) {
         hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
         return hipGetLastError();

@@ -22,6 +22,8 @@ struct TnKArgs {
     int mper;          // reduction rows per split (multiple of 32)
     int atomic;        // 1: atomicAdd into C (C pre-zeroed or accumulating); 0: plain store
     int accumulate;    // with atomic == 0: C += acc
+    float* colsum;     // optional [N]: += sum_m B[m, n] (the bias gradient that goes with this weight gradient: the B tiles are
+                       // in registers anyway); added by the workgroups of the first row panel, fp32 atomics; vector path only
 };
 
 template <int WM, int WN, int TM, int TN, bool VEC>
@@ -194,6 +196,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
             }
         };
         auto splice = [](int p) constexpr { return ((2 * p + 1) * HALF) / (2 * LPC); };
+        // column sums of B beside the MFMAs (free VALU slots): the waves of the first wave-row of the first row panel
+        const float csm = (g.colsum && k0 == 0 && wm == 0) ? 1.0f : 0.0f;
+        float cs[TN];
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) cs[jj] = 0.f;
 
         static_for<0, LPC>([&](auto p_) { issue_piece(p_, ra[0], rb[0]); });
         walk_next();
@@ -228,6 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
                         }
                         if constexpr (n == HALF) wait_vmcnt<WAITN>();
                         acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][i], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+                        if constexpr (i == 0) cs[jj] += bv[ks & 1][jj] * csm;
                         static_for<0, LPC>([&](auto p_) {
                             constexpr int p = decltype(p_)::value;
                             if constexpr (splice(p) == n) issue_piece(p_, ra[j], rb[j]);
@@ -248,6 +256,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
             for (int i = 0; i < A4; ++i) pin(ra[j][i]);
 #pragma unroll
             for (int i = 0; i < B4; ++i) pin(rb[j][i]);
+        }
+        if (csm != 0.0f) {                                               // lane (l15, lq) holds rows m == lq (mod 4) of column l15
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                float v = cs[jj];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int n = n0 + (wn * TN + jj) * 16 + l15;
+                if (lq == 0 && n < g.N) atomicAdd(g.colsum + n, v);
+            }
         }
       }
     } else

@@ -32,7 +32,10 @@ struct TnArgs {
     float* C; int ldc;                                 // [Kout, N]
     int Mred, Kout, N;
     int accumulate;                                    // 1: C += result (fp32 atomics when split)
+    float* colsum;                                     // optional [N]: += column sums of B (bias gradient), see launch_gemm_tn
 };
+// colsum: when given, the column sums of B are ADDED to it -- inside the contraction on the vector path, by a colsum launch
+// otherwise (so callers never launch one themselves).
 hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st);
 
 hipError_t launch_prep_caption(const int32_t* cap, int32_t* prev, int32_t* tgt, int N, int Tc, hipStream_t st);

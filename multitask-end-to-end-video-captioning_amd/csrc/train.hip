@@ -293,8 +293,8 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         hipStream_t sv = phase == 0 ? sd : st;              // (phase 1: its gradients must be final on the caller's stream)
         if (sv != st) HIP_TRY(fork_to(st, sv, ss.ev[0]));
         TnArgs a{w.O2 + (size_t)Tv * NH, nullptr, H, dlogits, V, grads->embed_word_W, V, Tc * N, H, V, 1};
+        a.colsum = grads->embed_word_b;                     // the bias gradient rides in the same pass over dlogits
         HIP_TRY(launch_gemm_tn(a, sv));
-        HIP_TRY(launch_colsum(dlogits, V, Tc * N, V, grads->embed_word_b, sv));
         HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2, H, Tc * N, H, V, 1, 0, st));
     }
     const SlabPlan sp2 = slab_plan(N, H), sp1 = slab_plan(B, H);
@@ -319,8 +319,8 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                  4 * H, 1};
         HIP_TRY(launch_gemm_tn(b, sd));
         TnArgs e{w.H2, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, T * N, H, 4 * H, 1};
+        e.colsum = grads->lstm2_b;
         HIP_TRY(launch_gemm_tn(e, sd));
-        HIP_TRY(launch_colsum(w.dZ2, 4 * H, T * N, 4 * H, grads->lstm2_b, sd));
     }
     }
     if (!do_rest) return S2VT_OK;
@@ -344,14 +344,14 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         TnArgs f{w.emb, w.encidx, E, w.dZ1, 4 * H, grads->lstm1_W, 4 * H, Tv * B, E, 4 * H, 1};
         HIP_TRY(launch_gemm_tn(f, st));
         TnArgs g{w.H1, nullptr, H, w.dZ1, 4 * H, grads->lstm1_W + (size_t)E * 4 * H, 4 * H, T * B, H, 4 * H, 1};
+        g.colsum = grads->lstm1_b;
         HIP_TRY(launch_gemm_tn(g, st));
-        HIP_TRY(launch_colsum(w.dZ1, 4 * H, T * B, 4 * H, grads->lstm1_b, st));
         // embedding rows (gradient of tf.nn.embedding_lookup): scatter-add of the embed slice of dX2
         HIP_TRY(launch_scatter_add_rows(w.dX2 + (size_t)Tv * N * (H + E) + H, H + E, w.prev, Tc * N, E, grads->Wemb, E, st));
         // frame embedding
         TnArgs h{video, w.encidx, D, w.dX1, E, grads->encode_image_W, E, Tv * B, D, E, 1};
+        h.colsum = grads->encode_image_b;
         HIP_TRY(launch_gemm_tn(h, st));
-        HIP_TRY(launch_colsum(w.dX1, E, Tv * B, E, grads->encode_image_b, st));
     }
     if (sd != st) HIP_TRY(fork_to(sd, st, ss.ev[2]));        // join: the caller's stream waits for the side stream's gradients
     return S2VT_OK;
