@@ -209,6 +209,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
         static_for<0, LPC>([&](auto p_) { issue_piece(p_, ra[1], rb[1]); });
         walk_next();
         __syncthreads();
+        // two copies of the main loop: only the waves that own a bias column sum (first row panel, first k slab) carry its adds
+        auto main_loop = [&](auto cs_) __attribute__((always_inline)) {
+        constexpr bool CS = decltype(cs_)::value;
         int c = 0;
         bool more = true;
         while (more) {
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
                         }
                         if constexpr (n == HALF) wait_vmcnt<WAITN>();
                         acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][i], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
-                        if constexpr (i == 0) cs[jj] += bv[ks & 1][jj] * csm;
+                        if constexpr (CS && i == 0) cs[jj] += bv[ks & 1][jj];
                         static_for<0, LPC>([&](auto p_) {
                             constexpr int p = decltype(p_)::value;
                             if constexpr (splice(p) == n) issue_piece(p_, ra[j], rb[j]);
@@ -249,6 +252,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
                 }
             }
         }
+        };
+        if (csm != 0.0f) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
         wait_vmcnt<0>();
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
