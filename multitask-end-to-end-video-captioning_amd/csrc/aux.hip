@@ -579,6 +579,11 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     k.mper = ((a.Mred + splits - 1) / splits + 31) / 32 * 32;
     splits = (a.Mred + k.mper - 1) / k.mper;
     k.atomic = splits > 1 ? 1 : 0;
+    k.splits = splits;
+    static const int xmap = [] { const char* e = getenv("S2VT_TN_XMAP"); return e ? atoi(e) : 1; }();         // dev knob
+    k.xmap = xmap;
+    const long nrow = (a.Kout + c.BMo - 1) / c.BMo, ncol = (a.N + c.BNo - 1) / c.BNo;
+    const dim3 grid = xmap ? dim3((unsigned)(8 * nrow * ((ncol * splits + 7) / 8))) : dim3((unsigned)nt, (unsigned)splits);
     k.accumulate = a.accumulate;
     k.colsum = nullptr;
     if (k.atomic && !a.accumulate) {
@@ -598,7 +603,7 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
         }
     }
     if (!prof_wants(3, ci)) {
-        hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
+        hipLaunchKernelGGL(vec ? c.vec : c.scalar, grid, dim3(c.NT), c.lds, st, k);
         return hipGetLastError();
     }
     hipEvent_t e0, e1;
@@ -606,7 +611,7 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     if (pe != hipSuccess) return pe;
     static const char* names[] = {"tn128x128(2x2)", "tn64x128(2x2)", "tn64x64(2x2)", "tn96x96(2x2)", "tn64x96(2x2)", "tn96x128(2x2)"};
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(vec ? c.vec : c.scalar, dim3((unsigned)nt, (unsigned)splits), dim3(c.NT), c.lds, st, k);
+    hipLaunchKernelGGL(vec ? c.vec : c.scalar, grid, dim3(c.NT), c.lds, st, k);
     (void)hipEventRecord(e1, st);
     prof_record(3, ci, names[ci], 2.0 * a.Mred * (double)a.Kout * a.N, e0, e1);
     return hipGetLastError();

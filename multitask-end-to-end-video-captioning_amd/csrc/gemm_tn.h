@@ -20,6 +20,8 @@ struct TnKArgs {
     float* C; int ldc;
     int Mred, Kout, N;
     int mper;          // reduction rows per split (multiple of 32)
+    int splits;        // reduction slabs
+    int xmap;          // 1: one-dimensional grid, XCD-aware workgroup -> (row panel, column panel, slab) order
     int atomic;        // 1: atomicAdd into C (C pre-zeroed or accumulating); 0: plain store
     int accumulate;    // with atomic == 0: C += acc
     float* colsum;     // optional [N]: += sum_m B[m, n] (the bias gradient that goes with this weight gradient: the B tiles are
@@ -42,8 +44,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l15 = lane & 15, lq = lane >> 4;
     const int ntn = (g.N + BNo - 1) / BNo;
-    const int k0 = (blockIdx.x / ntn) * BMo, n0 = (blockIdx.x % ntn) * BNo;
-    const int mbeg = blockIdx.y * g.mper;
+    int k0, n0, mbeg;
+    if (g.xmap) {
+        // XCD-aware order (workgroup i runs on XCD i % 8): the row panels of one (column panel, reduction slab) pair sit in
+        // consecutive slots of ONE XCD, so that slab of B crosses the fabric once and the XCD's L2 serves the other panels;
+        // the pairs an XCD works on at the same time belong to the same slab and share the A slices the same way.
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int nrow = (g.Kout + BMo - 1) / BMo;
+        const int pr = (slot / nrow) * 8 + xcd;
+        if (pr >= ntn * g.splits) return;
+        k0 = (slot % nrow) * BMo; n0 = (pr % ntn) * BNo; mbeg = (pr / ntn) * g.mper;
+    } else {
+        k0 = (blockIdx.x / ntn) * BMo; n0 = (blockIdx.x % ntn) * BNo; mbeg = blockIdx.y * g.mper;
+    }
     const int mend = (mbeg + g.mper < g.Mred) ? mbeg + g.mper : g.Mred;
     const int nchunks = mend > mbeg ? (mend - mbeg + BR - 1) / BR : 0;
 
