@@ -542,6 +542,7 @@ constexpr TnCfg tn_entry()
 }
 const TnCfg kTn[] = {tn_entry<2, 2, 4, 4>() /*128x128*/, tn_entry<2, 2, 2, 4>() /*64x128*/, tn_entry<2, 2, 2, 2>() /*64x64*/,
                      tn_entry<2, 2, 3, 3>() /*96x96*/, tn_entry<2, 2, 2, 3>() /*64x96*/, tn_entry<2, 2, 3, 4>() /*96x128*/};
+constexpr int kTnDmaLds = 2 * 32 * (128 + 128) * 4;
 std::once_flag g_tn_once;
 hipError_t g_tn_attr_err = hipSuccess;
 }  // namespace
@@ -549,6 +550,10 @@ hipError_t g_tn_attr_err = hipSuccess;
 hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
 {
     std::call_once(g_tn_once, [] {
+        for (TnFn fn : {gemm_tn_dma_kernel<false>, gemm_tn_dma_kernel<true>}) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kTnDmaLds);
+            if (e != hipSuccess && g_tn_attr_err == hipSuccess) g_tn_attr_err = e;
+        }
         for (const TnCfg& c : kTn)
             for (TnFn fn : {c.vec, c.scalar}) {
                 const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
@@ -602,8 +607,13 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
             if (e != hipSuccess) return e;
         }
     }
+    // the 128x128 vector path stages by LDS-DMA (rows must be 16-byte aligned, which `vec` already says)
+    static const int use_dma = [] { const char* e = getenv("S2VT_TN_DMA"); return e ? atoi(e) : 1; }();       // dev knob
+    const bool dma = vec && ci == 0 && use_dma;
+    const TnFn fn = dma ? (a.rowidx ? gemm_tn_dma_kernel<true> : gemm_tn_dma_kernel<false>) : (vec ? c.vec : c.scalar);
+    const int lds = dma ? kTnDmaLds : c.lds;
     if (!prof_wants(3, ci)) {
-        hipLaunchKernelGGL(vec ? c.vec : c.scalar, grid, dim3(c.NT), c.lds, st, k);
+        hipLaunchKernelGGL(fn, grid, dim3(c.NT), lds, st, k);
         return hipGetLastError();
     }
     hipEvent_t e0, e1;
@@ -611,7 +621,7 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     if (pe != hipSuccess) return pe;
     static const char* names[] = {"tn128x128(2x2)", "tn64x128(2x2)", "tn64x64(2x2)", "tn96x96(2x2)", "tn64x96(2x2)", "tn96x128(2x2)"};
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(vec ? c.vec : c.scalar, grid, dim3(c.NT), c.lds, st, k);
+    hipLaunchKernelGGL(fn, grid, dim3(c.NT), lds, st, k);
     (void)hipEventRecord(e1, st);
     prof_record(3, ci, names[ci], 2.0 * a.Mred * (double)a.Kout * a.N, e0, e1);
     return hipGetLastError();

@@ -330,4 +330,148 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
     }
 }
 
+// ---- the 128x128 tile with LDS-DMA staging -----------------------------------------------------------------------------
+// Same contraction, same 32-row chunks, but the chunk goes global -> LDS by `buffer_load_dwordx4 ... lds` (no staging
+// registers, no ds_write pass, no address VALU in the loop: the register-staged kernel above parks its 64-register ring in
+// AGPRs and pays ~110 v_accvgpr moves per chunk for it).  An LDS-DMA wave-instruction writes 1 KiB lane-linearly, i.e. two
+// unpadded 128-float rows; with unpadded rows the b32 fragment reads would conflict, so the fragments are read as ONE
+// ds_read_b128 per operand per k-step instead: lane (l15, lq) takes floats [4*l15, 4*l15+4) of row m = 4*ks + lq, and
+// accumulator (i, j) of the wave therefore holds output rows 4*rho + i (rho = the MFMA tile row) and columns 4*l15 + j --
+// a permutation of which MFMA computes which output, free because the outputs are independent; the reduction order per
+// output is what it was.  Two LDS buffers, one barrier per chunk: chunk c+1 is in flight while chunk c is multiplied.
+template <bool GATHER>
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
+{
+    constexpr int BR = 32, BMo = 128, BNo = 128, TM = 4, TN = 4;
+    constexpr int KS = BR / 4, NM = KS * 16;
+    constexpr int PCS = BR / 8;                        // DMA pieces per operand per wave: 4 waves x 2 rows each
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                   // [2][BR][BMo]
+    float* Bs = smem + 2 * BR * BMo;    // [2][BR][BNo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+    const int ntn = (g.N + BNo - 1) / BNo;
+    int k0, n0, mbeg;
+    if (g.xmap) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int nrow = (g.Kout + BMo - 1) / BMo;
+        const int pr = (slot / nrow) * 8 + xcd;
+        if (pr >= ntn * g.splits) return;
+        k0 = (slot % nrow) * BMo; n0 = (pr % ntn) * BNo; mbeg = (pr / ntn) * g.mper;
+    } else {
+        k0 = (blockIdx.x / ntn) * BMo; n0 = (blockIdx.x % ntn) * BNo; mbeg = blockIdx.y * g.mper;
+    }
+    const int mend = (mbeg + g.mper < g.Mred) ? mbeg + g.mper : g.Mred;
+    const int nchunks = mend > mbeg ? (mend - mbeg + BR - 1) / BR : 0;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // piece p of this wave: rows 8p + 2*wave + (lane >> 5) of the chunk, floats 4*(lane & 31) .. +3 of the tile row
+    const int prow = 2 * wave + (lane >> 5), pcol = (lane & 31) * 4;
+    const bool aok = k0 + pcol < g.Kout, bok = n0 + pcol < g.N;
+    const uint32_t acol = (uint32_t)(k0 + pcol) * 4u, bcol = (uint32_t)(n0 + pcol) * 4u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue_piece = [&](int c, int buf, auto p_) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_)::value;
+        const int m0 = mbeg + c * BR;                 // a chunk past the slab: every lane out of range, zeros into the idle buffer
+        if constexpr (P < PCS) {
+            const int row = P * 8 + prow;
+            const bool in = aok && m0 + row < mend;
+            uint32_t vo;
+            __amdgpu_buffer_rsrc_t rs;
+            if constexpr (GATHER) {
+                rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)kOob, 0x00020000);
+                vo = (uint32_t)(in ? g.rowidx[m0 + row] : 0) * (uint32_t)g.lda * 4u + acol;
+            } else {
+                rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)m0 * g.lda), 0, (int)kOob, 0x00020000);
+                vo = (uint32_t)row * (uint32_t)g.lda * 4u + acol;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(As + (buf * BR + P * 8 + 2 * wave) * BMo), 16, in ? vo : kOob, 0, 0, 0);
+        } else {
+            constexpr int Q = P - PCS;
+            const int row = Q * 8 + prow;
+            const bool in = bok && m0 + row < mend;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B + (size_t)m0 * g.ldb), 0, (int)kOob, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(Bs + (buf * BR + Q * 8 + 2 * wave) * BNo), 16,
+                                                     in ? (uint32_t)row * (uint32_t)g.ldb * 4u + bcol : kOob, 0, 0, 0);
+        }
+    };
+    auto splice = [](int p) constexpr { return ((2 * p + 1) * (NM / 2)) / (2 * 2 * PCS); };   // pieces spread over the first half
+    const float csm = (g.colsum && k0 == 0 && wm == 0) ? 1.0f : 0.0f;
+    float cs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cs[j] = 0.f;
+
+    if (nchunks > 0) {
+        static_for<0, 2 * PCS>([&](auto p_) { issue_piece(0, 0, p_); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto main_loop = [&](auto cs_) __attribute__((always_inline)) {
+            constexpr bool CS = decltype(cs_)::value;
+            for (int c = 0; c < nchunks; ++c) {
+                const int buf = c & 1;
+                const f32x4* a = reinterpret_cast<const f32x4*>(As + (buf * BR + lq) * BMo + wm * 64 + l15 * 4);
+                const f32x4* b = reinterpret_cast<const f32x4*>(Bs + (buf * BR + lq) * BNo + wn * 64 + l15 * 4);
+                f32x4 av[2], bv[2];
+                av[0] = a[0];
+                bv[0] = b[0];
+                static_for<0, NM>([&](auto n_) {
+                    constexpr int n = decltype(n_)::value, ks = n / 16, r = n % 16, i = r / TN, j = r % TN;
+                    if constexpr (r == 0 && ks + 1 < KS) {
+                        av[(ks + 1) & 1] = a[(ks + 1) * BMo];            // (ks+1)*4 rows further: 4*BMo floats = BMo f32x4
+                        bv[(ks + 1) & 1] = b[(ks + 1) * BNo];
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
+                    if constexpr (CS && i == 0) cs[j] += bv[ks & 1][j];
+                    static_for<0, 2 * PCS>([&](auto p_) {
+                        constexpr int p = decltype(p_)::value;
+                        if constexpr (splice(p) == n) issue_piece(c + 1, buf ^ 1, p_);   // no branch in the MFMA stream
+                    });
+                });
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        };
+        if (csm != 0.0f) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
+        if (csm != 0.0f) {                                               // lane (l15, lq) holds rows m == lq (mod 4) of columns 4*l15 + j
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = cs[j];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int n = n0 + wn * 64 + l15 * 4 + j;
+                if (lq == 0 && n < g.N) atomicAdd(g.colsum + n, v);
+            }
+        }
+    }
+
+    // epilogue through LDS (free after the last barrier; each wave owns 16 KB): the accumulators hold 4 consecutive columns
+    // per lane, the atomics / stores want 64 consecutive columns per wave-instruction
+    float* tr = smem + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4*>(tr + ((lq * 4 + r) * 4 + i) * 64 + l15 * 4) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+    const int n = n0 + wn * 64 + lane;
+    if (n < g.N) {
+        const int kb = k0 + wm * 64;
+        const int rows = g.Kout - kb < 64 ? g.Kout - kb : 64;
+        float* p = g.C + (size_t)kb * g.ldc + n;
+#pragma unroll 8
+        for (int row = 0; row < rows; ++row) {
+            const float v = tr[row * 64 + lane];
+            if (g.atomic) atomicAdd(p, v);
+            else if (g.accumulate) *p = *p + v;
+            else *p = v;
+            p += g.ldc;
+        }
+    }
+}
+
 }  // namespace s2vt
