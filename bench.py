@@ -219,7 +219,7 @@ def main():
     if dom_w:
         ops.prof_filter(dom_w["kernel_class"], dom_w["tile_cfg"])
     else:
-        ops.prof_filter(3, 0)          # --warmup 0: no table to pick from; the weight-gradient contraction (tn128x128) is the known dominant kernel
+        ops.prof_filter(3, 6)          # --warmup 0: no table to pick from; the weight-gradient contraction (tn128x128, LDS-DMA form) is the known dominant kernel
     # per-step durations: one event per step boundary on the launching stream (negligible next to ~600 launches)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:

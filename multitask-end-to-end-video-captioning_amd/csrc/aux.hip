@@ -542,7 +542,15 @@ constexpr TnCfg tn_entry()
 }
 const TnCfg kTn[] = {tn_entry<2, 2, 4, 4>() /*128x128*/, tn_entry<2, 2, 2, 4>() /*64x128*/, tn_entry<2, 2, 2, 2>() /*64x64*/,
                      tn_entry<2, 2, 3, 3>() /*96x96*/, tn_entry<2, 2, 2, 3>() /*64x96*/, tn_entry<2, 2, 3, 4>() /*96x128*/};
-constexpr int kTnDmaLds = 2 * 32 * (128 + 128) * 4;
+struct TnDma { TnFn plain, gather; int lds, br, wgs_per_cu; };
+template <int BR, int NB>
+constexpr TnDma tn_dma_entry()
+{
+    constexpr int lds = NB * BR * 256 * 4, by_lds = 160 * 1024 / lds;
+    return TnDma{gemm_tn_dma_kernel<false, BR, NB>, gemm_tn_dma_kernel<true, BR, NB>, lds, BR, by_lds < 3 ? by_lds : 3};   // 136 VGPRs: three waves per SIMD
+}
+// LDS-DMA forms of the 128x128 tile: {rows per chunk, LDS buffers}; [0] is the one used (the rest: S2VT_TN_DMA=2.. dev knob)
+const TnDma kTnDma[] = {tn_dma_entry<16, 2>(), tn_dma_entry<32, 2>(), tn_dma_entry<16, 3>(), tn_dma_entry<16, 4>()};
 std::once_flag g_tn_once;
 hipError_t g_tn_attr_err = hipSuccess;
 }  // namespace
@@ -550,10 +558,11 @@ hipError_t g_tn_attr_err = hipSuccess;
 hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
 {
     std::call_once(g_tn_once, [] {
-        for (TnFn fn : {gemm_tn_dma_kernel<false>, gemm_tn_dma_kernel<true>}) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kTnDmaLds);
-            if (e != hipSuccess && g_tn_attr_err == hipSuccess) g_tn_attr_err = e;
-        }
+        for (const TnDma& d : kTnDma)
+            for (TnFn fn : {d.plain, d.gather}) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, d.lds);
+                if (e != hipSuccess && g_tn_attr_err == hipSuccess) g_tn_attr_err = e;
+            }
         for (const TnCfg& c : kTn)
             for (TnFn fn : {c.vec, c.scalar}) {
                 const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, c.lds);
@@ -563,20 +572,49 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     if (g_tn_attr_err != hipSuccess) return g_tn_attr_err;
     if (a.Mred <= 0 || a.Kout <= 0 || a.N <= 0) return hipSuccess;
     auto tiles = [&](const TnCfg& c) { return (long)((a.Kout + c.BMo - 1) / c.BMo) * ((a.N + c.BNo - 1) / c.BNo); };
+    const bool vec = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0 && (a.lda & 3) == 0 &&
+                     (a.ldb & 3) == 0 && (a.Kout & 3) == 0 && (a.N & 3) == 0 &&
+                     // the vector path addresses a chunk (32 rows) of each operand by 32-bit byte offsets from a base it
+                     // re-computes per chunk; a gathered A must fit a 2 GiB window (its extent is the caller's table)
+                     (size_t)32 * a.lda * 4 < (1ull << 31) && (size_t)32 * a.ldb * 4 < (1ull << 31);
+    // the 128x128 vector path stages by LDS-DMA (rows must be 16-byte aligned, which `vec` already says)
+    static const int use_dma = [] { const char* e = getenv("S2VT_TN_DMA"); return e ? atoi(e) : 1; }();       // dev knob
+    const bool dma_on = vec && use_dma >= 1 && use_dma <= (int)(sizeof(kTnDma) / sizeof(kTnDma[0]));
+    const int maxs = (a.Mred + 255) / 256;
     int ci = 0;
-    if (tiles(kTn[0]) < 200) ci = 1;
+    // fewer than 200 tiles of 128x128: the smaller tiles -- unless the LDS-DMA tile can fill the chip with reduction slabs
+    const bool dma_fills = dma_on && tiles(kTn[0]) * (maxs < 64 ? maxs : 64) >= 512 && a.Kout >= 96 && a.N >= 96;
+    if (tiles(kTn[0]) < 200 && !dma_fills) ci = 1;
     if (ci == 1 && tiles(kTn[1]) < 200) ci = 2;
     static const int force = [] { const char* e = getenv("S2VT_TN_CFG"); return e ? atoi(e) : -1; }();       // dev knob
     if (force >= 0 && ci == 0) ci = force;
     const TnCfg& c = kTn[ci];
     const long nt = tiles(c);
+    const bool dma = dma_on && ci == 0;
+    const TnDma& dm = kTnDma[dma ? use_dma - 1 : 0];
+    const TnFn fn = dma ? (a.rowidx ? dm.gather : dm.plain) : (vec ? c.vec : c.scalar);
+    const int lds = dma ? dm.lds : c.lds;
     int splits = 1;
-    static const int tn_target = [] { const char* e = getenv("S2VT_TN_WGS"); return e ? atoi(e) : 1024; }();   // workgroups wanted: >= ~4 per CU keeps the MFMA pipes fed (measured 62 -> 88 TFLOP/s); env = dev knob
-    if (nt < tn_target) {
-        splits = (int)((tn_target + nt - 1) / nt);
-        const int maxs = (a.Mred + 255) / 256;
-        if (splits > maxs) splits = maxs;
-        if (splits < 1) splits = 1;
+    static const int tn_target = [] { const char* e = getenv("S2VT_TN_WGS"); return e ? atoi(e) : 0; }();      // dev knob: workgroups wanted (the rule of the register-staged tiles)
+    if (dma && tn_target == 0) {
+        // reduction slabs by cost: rounds of co-resident workgroups x (chunks per workgroup + its fixed prologue / epilogue,
+        // priced in chunks).  752 tiles of the vocabulary gradient are one round of 768 slots -- no split, no atomics.
+        static const int ovh = [] { const char* e = getenv("S2VT_TN_OVH"); return e ? atoi(e) : 12; }();       // dev knob
+        const long slots = 256L * dm.wgs_per_cu;
+        long best = -1;
+        for (int sp = 1; sp <= (maxs < 64 ? maxs : 64); ++sp) {
+            const long rounds = (nt * sp + slots - 1) / slots;
+            const long chunks = ((a.Mred + sp - 1) / sp + dm.br - 1) / dm.br;
+            const long cost = rounds * (chunks + ovh) * 64 + sp;                  // ties: fewer slabs
+            if (best < 0 || cost < best) { best = cost; splits = sp; }
+        }
+    } else {
+        const int target = tn_target ? tn_target : 1024;                          // >= ~4 per CU keeps the MFMA pipes fed (measured 62 -> 88 TFLOP/s)
+        if (nt < target) {
+            splits = (int)((target + nt - 1) / nt);
+            if (splits > maxs) splits = maxs;
+            if (splits < 1) splits = 1;
+        }
     }
     TnKArgs k;
     k.A = a.A; k.rowidx = a.rowidx; k.lda = a.lda; k.B = a.B; k.ldb = a.ldb; k.C = a.C; k.ldc = a.ldc;
@@ -595,11 +633,6 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
         hipError_t e = hipMemset2DAsync(a.C, (size_t)a.ldc * 4, 0, (size_t)a.N * 4, a.Kout, st);
         if (e != hipSuccess) return e;
     }
-    const bool vec = ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0 && (a.lda & 3) == 0 &&
-                     (a.ldb & 3) == 0 && (a.Kout & 3) == 0 && (a.N & 3) == 0 &&
-                     // the vector path addresses a chunk (32 rows) of each operand by 32-bit byte offsets from a base it
-                     // re-computes per chunk; a gathered A must fit a 2 GiB window (its extent is the caller's table)
-                     (size_t)32 * a.lda * 4 < (1ull << 31) && (size_t)32 * a.ldb * 4 < (1ull << 31);
     if (a.colsum) {
         if (vec) k.colsum = a.colsum;                                   // fused: the B tiles pass through registers anyway
         else {
@@ -607,23 +640,19 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
             if (e != hipSuccess) return e;
         }
     }
-    // the 128x128 vector path stages by LDS-DMA (rows must be 16-byte aligned, which `vec` already says)
-    static const int use_dma = [] { const char* e = getenv("S2VT_TN_DMA"); return e ? atoi(e) : 1; }();       // dev knob
-    const bool dma = vec && ci == 0 && use_dma;
-    const TnFn fn = dma ? (a.rowidx ? gemm_tn_dma_kernel<true> : gemm_tn_dma_kernel<false>) : (vec ? c.vec : c.scalar);
-    const int lds = dma ? kTnDmaLds : c.lds;
-    if (!prof_wants(3, ci)) {
+    const int pcfg = dma ? 6 : ci;                                       // profiler row of the LDS-DMA tile
+    if (!prof_wants(3, pcfg)) {
         hipLaunchKernelGGL(fn, grid, dim3(c.NT), lds, st, k);
         return hipGetLastError();
     }
     hipEvent_t e0, e1;
     hipError_t pe = prof_events(&e0, &e1);
     if (pe != hipSuccess) return pe;
-    static const char* names[] = {"tn128x128(2x2)", "tn64x128(2x2)", "tn64x64(2x2)", "tn96x96(2x2)", "tn64x96(2x2)", "tn96x128(2x2)"};
+    static const char* names[] = {"tn128x128(2x2)", "tn64x128(2x2)", "tn64x64(2x2)", "tn96x96(2x2)", "tn64x96(2x2)", "tn96x128(2x2)", "tn128x128(dma)"};
     (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(fn, grid, dim3(c.NT), lds, st, k);
     (void)hipEventRecord(e1, st);
-    prof_record(3, ci, names[ci], 2.0 * a.Mred * (double)a.Kout * a.N, e0, e1);
+    prof_record(3, pcfg, names[pcfg], 2.0 * a.Mred * (double)a.Kout * a.N, e0, e1);
     return hipGetLastError();
 }
 

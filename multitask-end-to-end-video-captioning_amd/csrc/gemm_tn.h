@@ -339,15 +339,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
 // accumulator (i, j) of the wave therefore holds output rows 4*rho + i (rho = the MFMA tile row) and columns 4*l15 + j --
 // a permutation of which MFMA computes which output, free because the outputs are independent; the reduction order per
 // output is what it was.  Two LDS buffers, one barrier per chunk: chunk c+1 is in flight while chunk c is multiplied.
-template <bool GATHER>
+template <bool GATHER, int BR, int NB>
 __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
 {
-    constexpr int BR = 32, BMo = 128, BNo = 128, TM = 4, TN = 4;
+    constexpr int BMo = 128, BNo = 128, TM = 4, TN = 4;
     constexpr int KS = BR / 4, NM = KS * 16;
     constexpr int PCS = BR / 8;                        // DMA pieces per operand per wave: 4 waves x 2 rows each
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                   // [2][BR][BMo]
-    float* Bs = smem + 2 * BR * BMo;    // [2][BR][BNo]
+    float* As = smem;                    // [NB][BR][BMo]
+    float* Bs = smem + NB * BR * BMo;    // [NB][BR][BNo]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
     const int ntn = (g.N + BNo - 1) / BNo;
@@ -375,7 +375,16 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
     const bool aok = k0 + pcol < g.Kout, bok = n0 + pcol < g.N;
     const uint32_t acol = (uint32_t)(k0 + pcol) * 4u, bcol = (uint32_t)(n0 + pcol) * 4u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    auto issue_piece = [&](int c, int buf, auto p_) __attribute__((always_inline)) {
+    // gathered A: the row indices of a chunk are loaded one iteration before its pieces are issued (an index load waited for
+    // inside the MFMA stream would drain the DMA queue with it: vmcnt retires in order)
+    auto load_idx = [&](int c, int (&gi)[PCS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int P = 0; P < PCS; ++P) {
+            const int m = mbeg + c * BR + P * 8 + prow;
+            gi[P] = (GATHER && m < mend) ? g.rowidx[m] : 0;
+        }
+    };
+    auto issue_piece = [&](int c, int buf, auto p_, const int (&gi)[PCS]) __attribute__((always_inline)) {
         constexpr int P = decltype(p_)::value;
         const int m0 = mbeg + c * BR;                 // a chunk past the slab: every lane out of range, zeros into the idle buffer
         if constexpr (P < PCS) {
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
             __amdgpu_buffer_rsrc_t rs;
             if constexpr (GATHER) {
                 rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)kOob, 0x00020000);
-                vo = (uint32_t)(in ? g.rowidx[m0 + row] : 0) * (uint32_t)g.lda * 4u + acol;
+                vo = (uint32_t)gi[P] * (uint32_t)g.lda * 4u + acol;
             } else {
                 rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + (size_t)m0 * g.lda), 0, (int)kOob, 0x00020000);
                 vo = (uint32_t)row * (uint32_t)g.lda * 4u + acol;
@@ -407,16 +416,22 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
     for (int j = 0; j < TN; ++j) cs[j] = 0.f;
 
     if (nchunks > 0) {
-        static_for<0, 2 * PCS>([&](auto p_) { issue_piece(0, 0, p_); });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        int gcur[PCS], gnxt[PCS];
+        static_for<0, NB - 1>([&](auto c_) {
+            load_idx(decltype(c_)::value, gcur);
+            static_for<0, 2 * PCS>([&](auto p_) { issue_piece(decltype(c_)::value, decltype(c_)::value, p_, gcur); });
+        });
+        load_idx(NB - 1, gcur);
+        wait_vmcnt<(NB - 2) * 2 * PCS>();
+        __builtin_amdgcn_s_barrier();
         auto main_loop = [&](auto cs_) __attribute__((always_inline)) {
             constexpr bool CS = decltype(cs_)::value;
+            int buf = 0, nbuf = NB - 1;                                  // the buffer multiplied / the one chunk c+NB-1 goes to
             for (int c = 0; c < nchunks; ++c) {
-                const int buf = c & 1;
                 const f32x4* a = reinterpret_cast<const f32x4*>(As + (buf * BR + lq) * BMo + wm * 64 + l15 * 4);
                 const f32x4* b = reinterpret_cast<const f32x4*>(Bs + (buf * BR + lq) * BNo + wn * 64 + l15 * 4);
                 f32x4 av[2], bv[2];
+                load_idx(c + NB, gnxt);
                 av[0] = a[0];
                 bv[0] = b[0];
                 static_for<0, NM>([&](auto n_) {
@@ -429,15 +444,22 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
                     if constexpr (CS && i == 0) cs[j] += bv[ks & 1][j];
                     static_for<0, 2 * PCS>([&](auto p_) {
                         constexpr int p = decltype(p_)::value;
-                        if constexpr (splice(p) == n) issue_piece(c + 1, buf ^ 1, p_);   // no branch in the MFMA stream
+                        if constexpr (splice(p) == n) issue_piece(c + NB - 1, nbuf, p_, gcur);   // no branch in the MFMA stream
                     });
                 });
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                wait_vmcnt<(NB - 2) * 2 * PCS>();                         // chunk c+1 has landed; the later ones stay in flight
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                nbuf = buf;
+                buf = buf + 1 == NB ? 0 : buf + 1;
+#pragma unroll
+                for (int P = 0; P < PCS; ++P) gcur[P] = gnxt[P];
             }
         };
         if (csm != 0.0f) main_loop(std::true_type{});
         else main_loop(std::false_type{});
+        wait_vmcnt<0>();                                                 // the zero chunks issued past the slab, too
+        __builtin_amdgcn_s_barrier();
         if (csm != 0.0f) {                                               // lane (l15, lq) holds rows m == lq (mod 4) of columns 4*l15 + j
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -450,26 +472,35 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
         }
     }
 
-    // epilogue through LDS (free after the last barrier; each wave owns 16 KB): the accumulators hold 4 consecutive columns
-    // per lane, the atomics / stores want 64 consecutive columns per wave-instruction
-    float* tr = smem + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<f32x4*>(tr + ((lq * 4 + r) * 4 + i) * 64 + l15 * 4) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+    // epilogue through LDS (the staging buffers, free once every wave's last DMA has landed): the accumulators hold 4
+    // consecutive columns per lane, the atomics / stores want 64 consecutive columns per wave-instruction
+    constexpr int RGN = NB * BR * 256 / 4 < 4096 ? NB * BR * 256 / 4 : 4096;      // floats per wave
+    constexpr int IPP = RGN >= 4096 ? 4 : RGN >= 2048 ? 2 : 1;                    // accumulator rows i per pass (16 tile rows x 64 columns each)
+    static_assert(IPP >= 1 && TM % IPP == 0, "epilogue passes");
+    float* tr = smem + wave * RGN;
     const int n = n0 + wn * 64 + lane;
-    if (n < g.N) {
-        const int kb = k0 + wm * 64;
-        const int rows = g.Kout - kb < 64 ? g.Kout - kb : 64;
-        float* p = g.C + (size_t)kb * g.ldc + n;
+    const int kb = k0 + wm * 64;
+#pragma unroll
+    for (int h = 0; h < TM / IPP; ++h) {
+        if (h > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private region: program order is enough
+#pragma unroll
+        for (int ii = 0; ii < IPP; ++ii)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = h * IPP + ii;
+                *reinterpret_cast<f32x4*>(tr + ((lq * 4 + r) * IPP + ii) * 64 + l15 * 4) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            }
+        if (n < g.N) {
 #pragma unroll 8
-        for (int row = 0; row < rows; ++row) {
-            const float v = tr[row * 64 + lane];
-            if (g.atomic) atomicAdd(p, v);
-            else if (g.accumulate) *p = *p + v;
-            else *p = v;
-            p += g.ldc;
+            for (int lr = 0; lr < 16 * IPP; ++lr) {
+                const int k = kb + (lr / IPP) * 4 + h * IPP + lr % IPP;
+                if (k >= g.Kout) continue;
+                const float v = tr[lr * 64 + lane];
+                float* p = g.C + (size_t)k * g.ldc + n;
+                if (g.atomic) atomicAdd(p, v);
+                else if (g.accumulate) *p = *p + v;
+                else *p = v;
+            }
         }
     }
 }

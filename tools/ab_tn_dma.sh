@@ -1,15 +1,24 @@
-# A/B of the LDS-DMA weight-gradient tile (S2VT_TN_DMA=0/1): parity tests, then bench lines of the three workloads
+# A/B of the LDS-DMA forms of the weight-gradient tile (S2VT_TN_DMA=0: register staging, n>=1: kTnDma[n-1]) and of the
+# slab-count rule (S2VT_TN_OVH = fixed cost per workgroup in chunks; S2VT_TN_WGS = the old rule): parity tests, bench lines
 mkdir -p gpurun_out/dma; export TMPDIR=/tmp
-python -m pytest tests/test_gpu_timed_tiles.py tests/test_gpu_train.py tests/test_gpu_fwd.py -m gpu -x -q 2>&1 | tail -3
-for x in 0 1; do
+python -m pytest tests/test_gpu_timed_tiles.py tests/test_gpu_train.py -m gpu -x -q 2>&1 | tail -1
+run() {  # tag, env...
+  tag=$1; shift
   for w in rl xe multitask; do
-    S2VT_TN_DMA=$x python bench.py --workload $w --steps 80 --no-cpu-baseline > gpurun_out/dma/$w$x.json 2>/dev/null
+    env "$@" python bench.py --workload $w --steps 60 --no-cpu-baseline > gpurun_out/dma/$w.$tag.json 2>/dev/null
   done
-done
+}
+run reg S2VT_TN_DMA=0
+run dma_wgs1024 S2VT_TN_WGS=1024
+run dma_ovh4 S2VT_TN_OVH=4
+run dma_ovh12 S2VT_TN_OVH=12
+run dma_ovh30 S2VT_TN_OVH=30
+run dma32_ovh6 S2VT_TN_DMA=2 S2VT_TN_OVH=6
+run dma32_wgs1024 S2VT_TN_DMA=2 S2VT_TN_WGS=1024
 python - <<'PY'
-import json
-for x in (0,1):
+import json,glob
+for tag in ('reg','dma_wgs1024','dma_ovh4','dma_ovh12','dma_ovh30','dma32_ovh6','dma32_wgs1024'):
     for w in ('rl','xe','multitask'):
-        d=json.loads(open(f'gpurun_out/dma/{w}{x}.json').read().strip().splitlines()[-1])
-        print(x,w,d['ms_per_step'],[ (k['tile'],k['tflops']) for k in d['roofline']['all_kernels_warmup'] if k['class']==3])
+        d=json.loads(open(f'gpurun_out/dma/{w}.{tag}.json').read().strip().splitlines()[-1])
+        print(tag,w,d['ms_per_step'],[ (k['tile'],k['tflops']) for k in d['roofline']['all_kernels_warmup'] if k['class']==3][:1])
 PY

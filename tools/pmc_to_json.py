@@ -27,6 +27,8 @@ def prof_key(kname):
     if m:
         WM, WN, TM, TN = [int(x) for x in m.groups()[:4]]
         return f"3:tn{WM * TM * 16}x{WN * TN * 16}({WM}x{WN})"
+    if "gemm_tn_dma_kernel" in kname:
+        return "3:tn128x128(dma)"
     m = re.search(r"lstm_chain_kernel<(\d+)>", kname)
     if m:
         return f"5:chain(ng{m.group(1)})"
