@@ -42,13 +42,13 @@ __global__ void sampler_rows_kernel(int32_t* vid, int32_t* sid, int B, int K, in
     sid[i] = (i / B) < K ? i / B : -1;
 }
 
-// packed [T][R] -> ids [R][T]
-__global__ void unpack_ids_kernel(const unsigned long long* packed, int32_t* ids, int R, int T)
+// packed [T][R] (entries `stride` words apart) -> ids [R][T]
+__global__ void unpack_ids_kernel(const unsigned long long* packed, int32_t* ids, int R, int T, int stride)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * T) return;
     const int m = i / T, t = i % T;
-    ids[i] = (int32_t)(~(uint32_t)packed[(size_t)t * R + m]);
+    ids[i] = (int32_t)(~(uint32_t)packed[((size_t)t * R + m) * stride]);
 }
 
 }  // namespace
@@ -186,7 +186,7 @@ int s2vt_vocab_pick(const float* out2, int32_t ld, const float* W, const float* 
     NoiseIds ids{video_id, sample_id, seed};
     HIP_TRY(pick_call(out2, ld, W, b, M, H, V, ids, step, packed, logits_out, tile_cfg, S(stream)));
     if (tokens_out) {
-        hipLaunchKernelGGL(unpack_ids_kernel, dim3((M + 255) / 256), dim3(256), 0, S(stream), packed, tokens_out, M, 1);
+        hipLaunchKernelGGL(unpack_ids_kernel, dim3((M + 255) / 256), dim3(256), 0, S(stream), packed, tokens_out, M, 1, 1);
         HIP_TRY(hipGetLastError());
     }
     return S2VT_OK;
@@ -223,7 +223,7 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
     t.P2 = c.take<float>(T * B * 4 * H);                                                // h1[t+1] @ W2[0:H] for every step
     t.c2e = c.take<float>((Tv + 1) * (size_t)B * H); t.h2e = c.take<float>((Tv + 1) * (size_t)B * H);
     for (int i = 0; i < 2; ++i) { t.c2[i] = c.take<float>((size_t)R * H); t.h2[i] = c.take<float>((size_t)R * H); }
-    t.packed = c.take<unsigned long long>((size_t)Tc * R);
+    t.packed = c.take<unsigned long long>((size_t)Tc * R * kPickStride);
     t.vid = c.take<int32_t>(R); t.sid = c.take<int32_t>(R); t.bos = c.take<int32_t>(R);
     t.chain_sync = c.take<unsigned>(kChainSyncBytes / 4);
     t.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
@@ -311,7 +311,7 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
     const int R = (K + (with_greedy ? 1 : 0)) * B;
     hipStream_t st = S(stream);
     const size_t BH = (size_t)B * H;
-    HIP_TRY(hipMemsetAsync(w.packed, 0, (size_t)Tc * R * 8, st));
+    HIP_TRY(hipMemsetAsync(w.packed, 0, (size_t)Tc * R * kPickStride * 8, st));
     hipLaunchKernelGGL(sampler_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.vid, w.sid, B, K, R, video_base);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.bos, 1, R);   // <bos> = 1
     HIP_TRY(hipGetLastError());
@@ -325,15 +325,15 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
         const float* c2p = t == 0 ? w.c2e + enc : w.c2[cur2];
         const int smod = t == 0 ? B : 0;
         ASeg s2[2] = {t == 0 ? make_seg(p->Wemb, E, E, H, 0, w.bos)
-                             : make_seg(p->Wemb, E, E, H, 0, nullptr, w.packed + (size_t)(t - 1) * R),
+                             : make_seg(p->Wemb, E, E, H, 0, nullptr, w.packed + (size_t)(t - 1) * R * kPickStride, kPickStride),
                       make_seg(h2p, H, H, H + E, smod)};
         HIP_TRY(lstm_call(s2, 2, p->lstm2_W, p->lstm2_b, c2p, smod, w.c2[nxt2], w.h2[nxt2], nullptr, nullptr, R, H, 1.0f,
                           none, 0, -1, st, w.P2 + (size_t)(Tv + t) * 4 * BH, 4 * H, B));
-        HIP_TRY(pick_call(w.h2[nxt2], H, p->embed_word_W, p->embed_word_b, R, H, V, ids, t, w.packed + (size_t)t * R,
-                          nullptr, -1, st));
+        HIP_TRY(pick_call(w.h2[nxt2], H, p->embed_word_W, p->embed_word_b, R, H, V, ids, t, w.packed + (size_t)t * R * kPickStride,
+                          nullptr, -1, st, kPickStride));
         cur2 = nxt2;
     }
-    hipLaunchKernelGGL(unpack_ids_kernel, dim3((R * Tc + 255) / 256), dim3(256), 0, st, w.packed, ids_out, R, Tc);
+    hipLaunchKernelGGL(unpack_ids_kernel, dim3((R * Tc + 255) / 256), dim3(256), 0, st, w.packed, ids_out, R, Tc, kPickStride);
     HIP_TRY(hipGetLastError());
     return S2VT_OK;
 }

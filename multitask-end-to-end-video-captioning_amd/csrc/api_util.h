@@ -56,12 +56,14 @@ inline void seg_from_operand(ASeg& s, const s2vt_operand* o, int kw)
     s.rowmod = o->rowmod;
 }
 
+constexpr int kPickStride = 16;      // sampler workspace: one packed pick per 128-byte line (GemmArgs::pick_stride)
+
 inline ASeg make_seg(const float* ptr, int ld, int k, int kw, int rowmod = 0, const int* rowidx = nullptr,
-              const unsigned long long* rowkey = nullptr)
+              const unsigned long long* rowkey = nullptr, int rowkey_stride = 1)
 {
     ASeg s;
     std::memset(&s, 0, sizeof(s));
-    s.ptr = ptr; s.ld = ld; s.k = k; s.kw = kw; s.rowmod = rowmod; s.rowidx = rowidx; s.rowkey = rowkey;
+    s.ptr = ptr; s.ld = ld; s.k = k; s.kw = kw; s.rowmod = rowmod; s.rowidx = rowidx; s.rowkey = rowkey; s.rowkey_stride = rowkey_stride;
     return s;
 }
 
@@ -91,7 +93,7 @@ inline hipError_t lstm_call(const ASeg* segs, int nseg, const float* W, const fl
 }
 
 inline hipError_t pick_call(const float* A, int lda, const float* W, const float* b, int M, int H, int V, const NoiseIds& ids,
-                     int step, unsigned long long* packed, float* logits_out, int cfg, hipStream_t st)
+                     int step, unsigned long long* packed, float* logits_out, int cfg, hipStream_t st, int pick_stride = 1)
 {
     GemmArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -100,7 +102,7 @@ inline hipError_t pick_call(const float* A, int lda, const float* W, const float
     a.W = W; a.ldw = V; a.M = M; a.N = V; a.gstride = 0; a.bias = b;
     a.video_id = ids.video_id; a.sample_id = ids.sample_id;
     a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32);
-    a.step = step; a.pick = packed; a.logits_out = logits_out; a.ldc = V;
+    a.step = step; a.pick = packed; a.pick_stride = pick_stride; a.logits_out = logits_out; a.ldc = V;
     return launch_gemm(a, EPI_PICK, cfg, st);
 }
 

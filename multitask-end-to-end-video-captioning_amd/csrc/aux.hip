@@ -550,7 +550,7 @@ constexpr TnDma tn_dma_entry()
     return TnDma{gemm_tn_dma_kernel<false, BR, NB>, gemm_tn_dma_kernel<true, BR, NB>, lds, BR, by_lds < 3 ? by_lds : 3};   // 136 VGPRs: three waves per SIMD
 }
 // LDS-DMA forms of the 128x128 tile: {rows per chunk, LDS buffers}; [0] is the one used (the rest: S2VT_TN_DMA=2.. dev knob)
-const TnDma kTnDma[] = {tn_dma_entry<16, 2>(), tn_dma_entry<32, 2>(), tn_dma_entry<16, 3>(), tn_dma_entry<16, 4>()};
+const TnDma kTnDma[] = {tn_dma_entry<16, 2>(), tn_dma_entry<32, 2>()};
 std::once_flag g_tn_once;
 hipError_t g_tn_attr_err = hipSuccess;
 }  // namespace

@@ -76,8 +76,13 @@ const CfgEntry kPick[] = {
     make_entry<2, 4, 3, 3, 1, EPI_PICK>("96x192(2x4)"),
     make_entry<2, 2, 2, 3, 1, EPI_PICK>("64x96(2x2)"),
     make_entry<2, 2, 3, 2, 1, EPI_PICK>("96x64(2x2)"),
+    make_entry<2, 2, 1, 3, 1, EPI_PICK>("32x96(2x2)"),
 };
-constexpr int kPick64x96 = 4;
+// vocab pick, tile by M (tools/tune_pick_m.py on MI355X, H = 1000, |V| = 12000; us per launch 64x96 / 64x64 / 32x96):
+// M=64: 62/51/49, 128: 63/57/58, 192: 76/75/67, 256: 78/76/76, 320: 102/90/92, 384: 101/110/103.  Below M ~ 128 every
+// tile sits on a ~50 us floor (one workgroup per CU streaming its 192-256 KB slice of W and of the state, latency-bound).
+constexpr int kPick64x96 = 4, kPick64x64 = 0, kPick32x96 = 6;
+int choose_pick(int M) { return M <= 256 ? kPick32x96 : (M <= 352 ? kPick64x64 : kPick64x96); }
 
 const CfgEntry* table(int epi, int* n)
 {
@@ -272,7 +277,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     const CfgEntry* t = table(epi, &n);
     // vocab pick: 64x96 tiles put ~3 independent workgroups on every CU at M = (K+1)*B = 384 (750 tiles); measured
     // 109 us vs 131 us for one 96x192 8-wave workgroup per CU and 136 us for 64x128
-    if (cfg < 0 || cfg >= n) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : (epi == EPI_PICK && a.M >= 64 ? kPick64x96 : choose(t, n, a.M, a.N, a.splits));
+    if (cfg < 0 || cfg >= n) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : (epi == EPI_PICK && a.M >= 32 ? choose_pick(a.M) : choose(t, n, a.M, a.N, a.splits));
     const CfgEntry& e = t[cfg];
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     const int mt = ceil_div(a.M, e.BM), nt = ceil_div(a.N, e.CG);

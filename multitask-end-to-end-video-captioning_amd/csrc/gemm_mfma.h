@@ -41,6 +41,7 @@ struct ASeg {
     int k;               // segment length along K
     int kw;              // first row of W this segment multiplies
     int rowmod;          // >0: row(m) = m % rowmod (applied before rowidx)
+    int rowkey_stride;   // 64-bit words between the rowkey entries of consecutive rows (0 = 1, dense)
 };
 
 struct GemmArgs {
@@ -78,6 +79,9 @@ struct GemmArgs {
     uint32_t seed_lo, seed_hi;
     int step;
     unsigned long long* pick;   // [M] packed (orderable(key) << 32) | ~index, zeroed before the launch
+    int pick_stride;            // 64-bit words between consecutive rows' entries (0 = 1, dense).  The sampler spreads them one
+                                // per 128-byte line (kPickStride): every column tile of the launch does an atomicMax per row, and
+                                // 16 rows per line made ~4000 serialized atomics per line at M = 64 (15-18 us of a 48 us launch)
     float* logits_out;          // optional [M, ldc]
 };
 
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
     // Row offsets of this thread's A slots for every segment, resolved ONCE (gather / broadcast index
     // loads happen here, never inside the pipelined loop).  -1 marks a row beyond M / an absent segment.
     int aoff0[A4], aoff1[A4], aoff2[A4];
-    auto row_offsets = [&](int sl, int rowmod, const int* rowidx, const unsigned long long* rowkey, int ld, int (&ao)[A4]) __attribute__((always_inline)) {
+    auto row_offsets = [&](int sl, int rowmod, const int* rowidx, const unsigned long long* rowkey, int rks, int ld, int (&ao)[A4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A4; ++i) {
             const int idx = ltid + i * NTL;
@@ -372,15 +376,15 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                 if (rowmod <= 0 && !rowidx && !rowkey) m -= m0;          // plain segment: relative to the tile's first row (seg_base)
                 if (rowmod > 0) m %= rowmod;
                 if (rowidx) m = rowidx[m];
-                if (rowkey) m = (int)(~(uint32_t)rowkey[m]);
+                if (rowkey) m = (int)(~(uint32_t)rowkey[(size_t)m * (rks > 0 ? rks : 1)]);
                 off = m * ld + kbeg;
             }
             ao[i] = off;
         }
     };
-    row_offsets(slen0, g.seg[0].rowmod, g.seg[0].rowidx, g.seg[0].rowkey, g.seg[0].ld, aoff0);
-    row_offsets(slen1, g.seg[1].rowmod, g.seg[1].rowidx, g.seg[1].rowkey, g.seg[1].ld, aoff1);
-    row_offsets(slen2, g.seg[2].rowmod, g.seg[2].rowidx, g.seg[2].rowkey, g.seg[2].ld, aoff2);
+    row_offsets(slen0, g.seg[0].rowmod, g.seg[0].rowidx, g.seg[0].rowkey, g.seg[0].rowkey_stride, g.seg[0].ld, aoff0);
+    row_offsets(slen1, g.seg[1].rowmod, g.seg[1].rowidx, g.seg[1].rowkey, g.seg[1].rowkey_stride, g.seg[1].ld, aoff1);
+    row_offsets(slen2, g.seg[2].rowmod, g.seg[2].rowidx, g.seg[2].rowkey, g.seg[2].rowkey_stride, g.seg[2].ld, aoff2);
 
     // ---- LDS images.  A is stored as four PLANES, one per lq = k % 4: As[stage][lq][row][k / 4].  The MFMA lane
     // (l15, lq) consumes A[row l15][k = 4*ks + lq] at k-step ks, so its operands for FOUR consecutive k-steps are 16
@@ -977,7 +981,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     const unsigned long long o = __shfl_xor(key, off, 64);
                     key = o > key ? o : key;
                 }
-                if (l15 == 0 && m < g.M && key != 0ull) atomicMax(&g.pick[m], key);
+                if (l15 == 0 && m < g.M && key != 0ull) atomicMax(&g.pick[(size_t)m * (g.pick_stride > 0 ? g.pick_stride : 1)], key);
             }
             S2VT_STAMP_AT(11);                     // (dev build) lane reduction + atomics
         }

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/dma2; export TMPDIR=/tmp
-python -m pytest tests/test_gpu_timed_tiles.py tests/test_gpu_train.py tests/test_gpu_train_drivers.py -m gpu -x -q 2>&1 | tail -2
+python -m pytest tests/test_gpu_fwd.py tests/test_gpu_fullsize.py tests/test_gpu_replay_train.py tests/test_gpu_beam.py -m gpu -x -q 2>&1 | tail -2
 for w in rl xe multitask; do python bench.py --workload $w --steps 80 --no-cpu-baseline > gpurun_out/dma2/$w.json 2>/dev/null; done
 python - <<'PY'
 import json
