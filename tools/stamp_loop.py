@@ -60,3 +60,8 @@ sidg = -torch.ones(384, dtype=torch.int32, device=dev)
 report("PICK M=384 greedy rows only", lambda: ops.vocab_pick(o2, Wout, bout, vid, sidg, 0, 1))
 A = torch.randn(6400, 1000, device=dev)
 report("STORE logits 6400x1000x12000", lambda: ops.gemm([ops.operand(A)], Wout, None, M=6400), reps=2)
+for M in (64, 128):
+    vid = torch.zeros(M, dtype=torch.int32, device=dev); sid = torch.zeros(M, dtype=torch.int32, device=dev)
+    o2 = torch.randn(M, H, device=dev)
+    report(f"PICK M={M}", lambda: ops.vocab_pick(o2, Wout, bout, vid, sid, 0, 1))
+    report(f"PICK M={M} greedy rows only", lambda: ops.vocab_pick(o2, Wout, bout, vid, -torch.ones(M, dtype=torch.int32, device=dev), 0, 1))
