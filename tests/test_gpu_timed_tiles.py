@@ -48,6 +48,8 @@ TN_SHAPES = [
     (320, 1536, 500, True, "tn64x64(2x2)"),           # frame-embedding gradient: gathered rows (encidx)
     (777, 1000, 12000, True, "tn128x128(dma)"),       # gathered + ragged reduction length (777 = 48*16 + 9)
     (1290, 1000, 12000, False, "tn128x128(dma)"),     # reduction length not a multiple of the 16-row chunk (1290 = 80*16 + 10), one slab
+    (48, 64, 51200, False, "tn128x128(dma)"),         # half-empty row panel (Kout = 64), 400 column panels, three chunks
+    (5, 1000, 12000, True, "tn128x128(dma)"),         # a reduction shorter than one chunk, gathered
     (640, 1000, 1002, False, "tn64x64(2x2)"),         # N % 4 != 0: no 16-byte rows, the scalar-load form of the register-staged tile
 ]
 
