@@ -88,54 +88,74 @@ struct GridSync {
     }
 };
 
-template <int NG, int TMW>
+// NC = 16-column tiles of gate columns per workgroup (4 NC hidden units).  NC = 1: the rows are not split, a wave owns TMW
+// row tiles and streams their whole state image every step -- at M >= 128 that stream (M*H*4 bytes per CU per step through
+// the CU's L2 port, ~15 B/clk) takes longer than the MFMAs.  NC = 2: each workgroup owns 8 units and HALF the row tiles
+// (g.tpp per part, grid = 2 * H/8), so a CU streams half the image for the same number of MFMAs.
+template <int NG, int TMW, int NC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_chain_kernel(const ChainArgs g)
 {
     constexpr int ZS = 20;                                     // z tile row stride (floats): 16-byte aligned rows, conflict-light
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wl = smem;                                          // [NG][64 lanes][4]: B fragments of this workgroup's 16 gate columns
+    float* Wl = smem;                                          // [NG][NC][64 lanes][4]: B fragments of this workgroup's 16 NC gate columns
     const int tid = threadIdx.x, lane = tid & 63;
     const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* zb = smem + NG * 256 + pwave * (16 * ZS);
+    float* zb = smem + NG * NC * 256 + pwave * (16 * ZS);
     // which quarter of the rows this wave takes rotates with the workgroup: neighbouring CUs then walk DIFFERENT lines of
     // the shared state image at any moment instead of all hammering the same L2 channel (speed only)
     const int wave = (pwave + (int)blockIdx.x) & 3;
     const int l15 = lane & 15, lq = lane >> 4;
     const int H = g.H, M = g.M, T = g.T;
-    const int u0 = blockIdx.x * 4;
+    const int cg = (int)blockIdx.x % g.ncg, rp = (int)blockIdx.x / g.ncg;     // column group, row part
+    const int u0 = cg * 4 * NC;
     const int nwg = gridDim.x;
+    const int tb = rp * g.tpp + wave * TMW;                    // first row tile of this wave
+    bool tok[TMW];                                             // tile i is this wave's to compute (inside its part and inside M)
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) tok[i] = wave * TMW + i < g.tpp && (tb + i) * 16 < M;
 
-    // ---- this workgroup's slice of the recurrent rows -> LDS, once.  Column c = uu * 4 + gate of the slice is W column
-    // gate * H + u0 + uu; element (k, c) goes to group k / 16, lane (k % 4) * 16 + c, component (k % 16) / 4.
-    for (int idx = tid; idx < NG * 16 * 4; idx += 256) {
-        const int k = idx >> 2, gt = idx & 3;
+    // ---- this workgroup's slice of the recurrent rows -> LDS, once.  Column cc = uu * 4 + gate of column tile c is W column
+    // gate * H + u0 + 4c + uu; element (k, cc) goes to group k / 16, tile c, lane (k % 4) * 16 + cc, component (k % 16) / 4.
+    for (int idx = tid; idx < NG * 16 * 4 * NC; idx += 256) {
+        const int c = idx % NC, kg = idx / NC;
+        const int k = kg >> 2, gt = kg & 3;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < H) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)(g.kw0 + k) * g.ldw + (size_t)gt * H + u0);
+        if (k < H) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)(g.kw0 + k) * g.ldw + (size_t)gt * H + u0 + 4 * c);
         const int j = k >> 4, e = (k & 15) >> 2, kq = k & 3;
 #pragma unroll
-        for (int uu = 0; uu < 4; ++uu) Wl[((j * 64 + kq * 16 + uu * 4 + gt) << 2) + e] = v[uu];
+        for (int uu = 0; uu < 4; ++uu) Wl[(((j * NC + c) * 64 + kq * 16 + uu * 4 + gt) << 2) + e] = v[uu];
     }
 
-    // ---- the (row, unit) pairs this lane finishes at every step: one per row tile of its wave (tiles wave*TMW .. +TMW-1)
+    // ---- the (row, unit) pairs this lane finishes at every step: one per (column tile, row tile) of its wave
     const int rt = lane >> 2, uu = lane & 3;                   // row within a 16-row tile, unit within the 4
-    const int u = u0 + uu;
-    const int row0 = wave * TMW * 16 + rt;                     // row of tile 0; tile i is 16 i further
-    const float bi = g.bias[u], bj = g.bias[H + u], bf = g.bias[2 * H + u], bo = g.bias[3 * H + u];
-    float c_reg[TMW];
+    const int row0 = tb * 16 + rt;                             // row of tile 0; tile i is 16 i further
+    float bi[NC], bj[NC], bf[NC], bo[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int u = u0 + 4 * c + uu;
+        bi[c] = g.bias[u]; bj[c] = g.bias[H + u]; bf[c] = g.bias[2 * H + u]; bo[c] = g.bias[3 * H + u];
+    }
+    float c_reg[NC][TMW];
     uint32_t vid[TMW], sid[TMW];
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
         const int row = row0 + 16 * i;
-        const bool rok = row < M;
-        c_reg[i] = (rok && g.c0) ? g.c0[(size_t)row * H + u] : 0.0f;
+        const bool rok = tok[i] && row < M;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) c_reg[c][i] = (rok && g.c0) ? g.c0[(size_t)row * H + u0 + 4 * c + uu] : 0.0f;
         vid[i] = (g.keep < 1.0f && rok) ? (uint32_t)g.video_id[row] : 0u;
         sid[i] = (g.keep < 1.0f && rok) ? (uint32_t)g.sample_id[row] : 0u;
     }
-    // where this lane's h value of tile 0 sits in the A-fragment image (tile i: + i * NG * 256 floats):
+    // where this lane's h value of (column tile c, row tile 0) sits in the A-fragment image (tile i: + i * NG * 256 floats):
     // k = u -> group u / 16, lane (u % 4) * 16 + rt, component (u % 16) / 4
-    const size_t a_own = ((size_t)(wave * TMW * NG + (u >> 4)) * 64 + (size_t)((u & 3) * 16 + rt)) * 4 + ((u & 15) >> 2);
+    size_t a_own[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int u = u0 + 4 * c + uu;
+        a_own[c] = ((size_t)(tb * NG + (u >> 4)) * 64 + (size_t)((u & 3) * 16 + rt)) * 4 + ((u & 15) >> 2);
+    }
     float* const abuf0 = g.abuf;
-    float* const abuf1 = g.abuf + (size_t)4 * TMW * NG * 256;
+    float* const abuf1 = g.abuf + (size_t)g.img_tiles * NG * 256;
 
     GridSync gs{(gu32*)g.sync, g.status, nwg, false};
     auto arrive = [&]() __attribute__((always_inline)) { gs.arrive(tid); };
@@ -145,118 +165,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
         const int row = row0 + 16 * i;
-        if (row < M) {
-            const float h0 = g.h0 ? g.h0[(size_t)row * H + u] : 0.0f;
-            __hip_atomic_store((gu32*)(abuf0 + a_own + (size_t)i * NG * 256), __float_as_uint(h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tok[i] && row < M) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float h0 = g.h0 ? g.h0[(size_t)row * H + u0 + 4 * c + uu] : 0.0f;
+                __hip_atomic_store((gu32*)(abuf0 + a_own[c] + (size_t)i * NG * 256), __float_as_uint(h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     // the carried partial of step 0 (accumulator layout: lane (column l15, row group lq) holds rows lq*4 + r of a tile)
-    const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);          // W / cinit column of slice column l15
-    float ci[TMW][4];
+    float ci[NC][TMW][4];
     auto load_cinit = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TMW; ++i)
+        for (int c = 0; c < NC; ++c) {
+            const int ccol = (l15 & 3) * H + u0 + 4 * c + (l15 >> 2);      // W / cinit column of column l15 of tile c
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = (wave * TMW + i) * 16 + lq * 4 + r;
-                ci[i][r] = (g.cinit && t < g.cinit_steps && m < M) ? g.cinit[(size_t)t * g.cinit_tstride + (size_t)m * g.ldcinit + ccol] : 0.0f;
-            }
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = (tb + i) * 16 + lq * 4 + r;
+                    ci[c][i][r] = (g.cinit && t < g.cinit_steps && tok[i] && m < M) ? g.cinit[(size_t)t * g.cinit_tstride + (size_t)m * g.ldcinit + ccol] : 0.0f;
+                }
+        }
     };
     load_cinit(0);
     arrive();
+    // per-lane byte offset of the A-fragment loads of tile i; a tile that is not this wave's reads nothing (out of range: zeros)
+    int voff[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) voff[i] = tok[i] ? lane * 16 : (int)0x80000000u;
 
     for (int t = 0; t < T; ++t) {
-        f32x4 acc[TMW];
+        f32x4 acc[NC][TMW];
 #pragma unroll
-        for (int i = 0; i < TMW; ++i) {
-            acc[i] = f32x4{ci[i][0], ci[i][1], ci[i][2], ci[i][3]};
-            asm volatile("" : "+v"(acc[i]));                   // the partial is in registers before the ring below is issued
-        }
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                acc[c][i] = f32x4{ci[c][i][0], ci[c][i][1], ci[c][i][2], ci[c][i][3]};
+                asm volatile("" : "+v"(acc[c][i]));            // the partial is in registers before the ring below is issued
+            }
         wait_all((unsigned)t);
         // ---- A fragments straight into registers.  Ring of RING groups (x TMW row tiles): group j + RING is issued into
         // group j's registers as soon as its MFMAs have read them.
         const float* acur = (t & 1) ? abuf1 : abuf0;
         const __amdgpu_buffer_rsrc_t rsA =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)wave * TMW * NG * 256), 0, TMW * NG * 1024, 0x00020000);
-        const int voff = lane * 16;
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)tb * NG * 256), 0, TMW * NG * 1024, 0x00020000);
         constexpr int RING0 = TMW == 1 ? 32 : 40 / TMW;        // <= 160 ring registers
         constexpr int RING = NG < RING0 ? NG : RING0;
         f32x4 a[RING][TMW];
         static_for<0, RING>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j][i] = bload16_sc1(rsA, voff, (i * NG + j) * 1024); });
+            static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j][i] = bload16_sc1(rsA, voff[i], (i * NG + j) * 1024); });
         });
         __builtin_amdgcn_sched_barrier(0);
         const f32x4* bl = reinterpret_cast<const f32x4*>(Wl) + lane;
         constexpr int PB = NG < 4 ? NG : 4;                    // B fragments read PB groups ahead
-        f32x4 b[PB];
-        static_for<0, PB>([&](auto j_) { constexpr int j = decltype(j_)::value; b[j] = bl[j * 64]; });
+        f32x4 b[PB][NC];
+        static_for<0, PB>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) b[j][c] = bl[(j * NC + c) * 64];
+        });
         static_for<0, NG>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
-            const f32x4 bj4 = b[j % PB];
-            if constexpr (j + PB < NG) b[j % PB] = bl[(j + PB) * 64];
+            f32x4 bj4[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) bj4[c] = b[j % PB][c];
+            if constexpr (j + PB < NG) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) b[j % PB][c] = bl[((j + PB) * NC + c) * 64];
+            }
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, 4>([&](auto e_) {
                 constexpr int e = decltype(e_)::value;
-                static_for<0, TMW>([&](auto i_) {
-                    constexpr int i = decltype(i_)::value;
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][i][e], bj4[e], acc[i], 0, 0, 0);
+                static_for<0, NC>([&](auto c_) {
+                    constexpr int c = decltype(c_)::value;
+                    static_for<0, TMW>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        acc[c][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][i][e], bj4[c][e], acc[c][i], 0, 0, 0);
+                    });
                 });
             });
             if constexpr (j + RING < NG) {
                 __builtin_amdgcn_sched_barrier(0);             // the refill stays behind the MFMAs that read these registers, and in place
-                static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j % RING][i] = bload16_sc1(rsA, voff, (i * NG + j + RING) * 1024); });
+                static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j % RING][i] = bload16_sc1(rsA, voff[i], (i * NG + j + RING) * 1024); });
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
-        // ---- per row tile: the gates of a unit meet through the wave's LDS tile z[row][uu*4 + gate]; BasicLSTMCell
-        // pointwise (gate order i, j, f, o; forget_bias 1.0 added at run time) -- the EPI_LSTM expressions
-        float hv[TMW], siv[TMW], tjv[TMW], sfv[TMW], sov[TMW];
+        // ---- per (column tile, row tile): the gates of a unit meet through the wave's LDS tile z[row][uu*4 + gate];
+        // BasicLSTMCell pointwise (gate order i, j, f, o; forget_bias 1.0 added at run time) -- the EPI_LSTM expressions
+        float hv[NC][TMW], siv[NC][TMW], tjv[NC][TMW], sfv[NC][TMW], sov[NC][TMW];
 #pragma unroll
-        for (int i = 0; i < TMW; ++i) {
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
-            __builtin_amdgcn_wave_barrier();
-            const f32x4 z = *reinterpret_cast<const f32x4*>(zb + rt * ZS + uu * 4);
-            __builtin_amdgcn_wave_barrier();
-            const float zi = z[0] + bi, zj = z[1] + bj, zf = z[2] + bf, zo = z[3] + bo;
-            const float si = dm_sigmoidf(zi);
-            const float tj = dm_tanhf(zj);
-            const float sf = dm_sigmoidf(zf + 1.0f);
-            const float so = dm_sigmoidf(zo);
-            const float t1 = c_reg[i] * sf;
-            const float t2 = si * tj;
-            const float c = t1 + t2;
-            hv[i] = dm_tanhf(c) * so;
-            c_reg[i] = c;
-            siv[i] = si; tjv[i] = tj; sfv[i] = sf; sov[i] = so;
-        }
+            for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[c][i][r];
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 z = *reinterpret_cast<const f32x4*>(zb + rt * ZS + uu * 4);
+                __builtin_amdgcn_wave_barrier();
+                const float zi = z[0] + bi[c], zj = z[1] + bj[c], zf = z[2] + bf[c], zo = z[3] + bo[c];
+                const float si = dm_sigmoidf(zi);
+                const float tj = dm_tanhf(zj);
+                const float sf = dm_sigmoidf(zf + 1.0f);
+                const float so = dm_sigmoidf(zo);
+                const float t1 = c_reg[c][i] * sf;
+                const float t2 = si * tj;
+                const float cc = t1 + t2;
+                hv[c][i] = dm_tanhf(cc) * so;
+                c_reg[c][i] = cc;
+                siv[c][i] = si; tjv[c][i] = tj; sfv[c][i] = sf; sov[c][i] = so;
+            }
         // The hand-off first: h_t write-through, drained and signalled BEFORE the history stores, which nobody in this
         // launch reads -- they complete under the other workgroups' arrival (and only have to by the end of the kernel).
         if (t + 1 < T) {
 #pragma unroll
             for (int i = 0; i < TMW; ++i)
-                if (row0 + 16 * i < M)
-                    __hip_atomic_store((gu32*)(((t & 1) ? abuf0 : abuf1) + a_own + (size_t)i * NG * 256), __float_as_uint(hv[i]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                if (tok[i] && row0 + 16 * i < M) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        __hip_atomic_store((gu32*)(((t & 1) ? abuf0 : abuf1) + a_own[c] + (size_t)i * NG * 256), __float_as_uint(hv[c][i]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             arrive();
         }
 #pragma unroll
         for (int i = 0; i < TMW; ++i) {
             const int row = row0 + 16 * i;
-            if (row >= M) continue;
-            const size_t o = (size_t)row * H + u;
-            g.C[(size_t)(t + 1) * g.state_tstride + o] = c_reg[i];
-            g.Hh[(size_t)(t + 1) * g.state_tstride + o] = hv[i];
-            if (g.out) {
-                float ov = hv[i];
-                if (g.keep < 1.0f)
-                    ov = (hv[i] / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)u, g.keep);
-                g.out[(size_t)t * g.out_tstride + o] = ov;
-            }
-            if (g.gates) {
-                float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)row * 4 * H + u;
-                gp[0] = siv[i]; gp[H] = tjv[i]; gp[2 * H] = sfv[i]; gp[3 * H] = sov[i];
+            if (!tok[i] || row >= M) continue;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int u = u0 + 4 * c + uu;
+                const size_t o = (size_t)row * H + u;
+                g.C[(size_t)(t + 1) * g.state_tstride + o] = c_reg[c][i];
+                g.Hh[(size_t)(t + 1) * g.state_tstride + o] = hv[c][i];
+                if (g.out) {
+                    float ov = hv[c][i];
+                    if (g.keep < 1.0f)
+                        ov = (hv[c][i] / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)u, g.keep);
+                    g.out[(size_t)t * g.out_tstride + o] = ov;
+                }
+                if (g.gates) {
+                    float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)row * 4 * H + u;
+                    gp[0] = siv[c][i]; gp[H] = tjv[c][i]; gp[2 * H] = sfv[c][i]; gp[3 * H] = sov[c][i];
+                }
             }
         }
         if (t + 1 < T) load_cinit(t + 1);
@@ -264,26 +316,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 typedef void (*ChainFn)(const ChainArgs);
-struct ChainCfg { int ng, tmw; ChainFn fn; const char* name; };
+struct ChainCfg { int ng, tmw, nc; ChainFn fn; const char* name; };
 constexpr int kMaxTmw = 6;                                     // 6 row tiles per wave x 4 waves x 16 rows = 384 rows
 const ChainCfg kChain[] = {
-    {8, 1, lstm_chain_kernel<8, 1>, "chain(ng8,m64)"},      {8, 2, lstm_chain_kernel<8, 2>, "chain(ng8,m128)"},
-    {8, 3, lstm_chain_kernel<8, 3>, "chain(ng8,m192)"},     {8, 4, lstm_chain_kernel<8, 4>, "chain(ng8,m256)"},
-    {8, 5, lstm_chain_kernel<8, 5>, "chain(ng8,m320)"},     {8, 6, lstm_chain_kernel<8, 6>, "chain(ng8,m384)"},
-    {64, 1, lstm_chain_kernel<64, 1>, "chain(ng64,m64)"},   {64, 2, lstm_chain_kernel<64, 2>, "chain(ng64,m128)"},
-    {64, 3, lstm_chain_kernel<64, 3>, "chain(ng64,m192)"},  {64, 4, lstm_chain_kernel<64, 4>, "chain(ng64,m256)"},
-    {64, 5, lstm_chain_kernel<64, 5>, "chain(ng64,m320)"},  {64, 6, lstm_chain_kernel<64, 6>, "chain(ng64,m384)"},
+    {8, 1, 1, lstm_chain_kernel<8, 1, 1>, "chain(ng8,m64)"},      {8, 2, 1, lstm_chain_kernel<8, 2, 1>, "chain(ng8,m128)"},
+    {8, 3, 1, lstm_chain_kernel<8, 3, 1>, "chain(ng8,m192)"},     {8, 4, 1, lstm_chain_kernel<8, 4, 1>, "chain(ng8,m256)"},
+    {8, 5, 1, lstm_chain_kernel<8, 5, 1>, "chain(ng8,m320)"},     {8, 6, 1, lstm_chain_kernel<8, 6, 1>, "chain(ng8,m384)"},
+    {64, 1, 1, lstm_chain_kernel<64, 1, 1>, "chain(ng64,m64)"},   {64, 2, 1, lstm_chain_kernel<64, 2, 1>, "chain(ng64,m128)"},
+    {64, 3, 1, lstm_chain_kernel<64, 3, 1>, "chain(ng64,m192)"},  {64, 4, 1, lstm_chain_kernel<64, 4, 1>, "chain(ng64,m256)"},
+    {64, 5, 1, lstm_chain_kernel<64, 5, 1>, "chain(ng64,m320)"},  {64, 6, 1, lstm_chain_kernel<64, 6, 1>, "chain(ng64,m384)"},
+    // 8 units x half the row tiles per workgroup (M > 64): tmw = row tiles per wave of a part
+    {64, 1, 2, lstm_chain_kernel<64, 1, 2>, "chain2(ng64,m128)"}, {64, 2, 2, lstm_chain_kernel<64, 2, 2>, "chain2(ng64,m256)"},
+    {64, 3, 2, lstm_chain_kernel<64, 3, 2>, "chain2(ng64,m384)"},
 };
+int g_num_cus = 0;
+bool chain_two_parts(int M, int H)                             // the 8-unit / half-the-rows form serves this shape
+{
+    static const bool off = [] { const char* e = getenv("S2VT_CHAIN2"); return e && e[0] == '0'; }();          // dev knob
+    return !off && M > 64 && (H + 15) / 16 > 8 && (H & 7) == 0 && 2 * (H / 8) <= g_num_cus;
+}
 int chain_cfg(int M, int H)                                    // index into kChain, or -1
 {
-    const int ng = (H + 15) / 16 <= 8 ? 8 : 64, tmw = (M + 63) / 64;
+    const int tiles = (M + 15) / 16;
+    const bool two = chain_two_parts(M, H);
+    const int ng = (H + 15) / 16 <= 8 ? 8 : 64, tmw = two ? ((tiles + 1) / 2 + 3) / 4 : (M + 63) / 64, nc = two ? 2 : 1;
     for (int i = 0; i < (int)(sizeof(kChain) / sizeof(kChain[0])); ++i)
-        if (kChain[i].ng == ng && kChain[i].tmw == tmw) return i;
+        if (kChain[i].ng == ng && kChain[i].tmw == tmw && kChain[i].nc == nc) return i;
     return -1;
 }
 
 std::once_flag g_chain_once;
-int g_num_cus = 0;
 unsigned* g_status_host = nullptr;     // pinned, device-mapped: timeouts of every chain launch of this process
 unsigned* g_status_dev = nullptr;
 
@@ -311,7 +373,7 @@ bool chain_eligible(int M, int H)
         bool ok = g_num_cus > 0;
         for (const ChainCfg& c : kChain)
             ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (c.ng * 256 + 4 * 16 * 20) * 4) == hipSuccess;
+                                           (c.ng * c.nc * 256 + 4 * 16 * 20) * 4) == hipSuccess;
         void* hp = nullptr;
         if (ok && hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
             g_status_host = static_cast<unsigned*>(hp);
@@ -333,13 +395,17 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
     const ChainCfg& c = kChain[ci];
     ChainArgs a2 = a;
     a2.status = g_status_dev;
+    const int tiles = (a.M + 15) / 16, parts = c.nc;           // (two column tiles go with two row parts)
+    a2.ncg = a.H / (4 * c.nc);
+    a2.tpp = parts == 1 ? 4 * c.tmw : (tiles + 1) / 2;
+    a2.img_tiles = parts * 4 * c.tmw;
     // every polled word and the fragment images start from zero on EVERY call (a memset node ahead of the launch)
     hipError_t e = hipMemsetAsync(a.sync, 0, kChainSyncBytes, st);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.abuf, 0, (size_t)2 * 4 * c.tmw * c.ng * 256 * 4, st);
+    e = hipMemsetAsync(a.abuf, 0, (size_t)2 * a2.img_tiles * c.ng * 256 * 4, st);
     if (e != hipSuccess) return e;
-    const int lds = (c.ng * 256 + 4 * 16 * 20) * 4;
-    const dim3 grid((unsigned)(a.H / 4));
+    const int lds = (c.ng * c.nc * 256 + 4 * 16 * 20) * 4;
+    const dim3 grid((unsigned)(parts * a2.ncg));
     const double flops = 2.0 * a.M * (double)a.H * 4.0 * a.H * a.T;
     if (!prof_wants(5, ci)) {
         hipLaunchKernelGGL(c.fn, grid, dim3(256), lds, st, a2);

@@ -78,6 +78,7 @@ struct ChainArgs {
     float* abuf;                                       // chain_scratch_floats(H) floats, 16-byte aligned
     unsigned* sync;                                    // kChainSyncBytes bytes: arrival counters + timeout word
     unsigned* status;                                  // (set by the launcher) host-mapped count of timed-out waits
+    int ncg, tpp, img_tiles;                           // (set by the launcher) column groups, row tiles per row part, row tiles of one state image
 };
 constexpr size_t kChainSyncBytes = 9 * 128;            // 8 counter shards + the status line, a block of its own (multiple of 16)
 bool chain_eligible(int M, int H);                     // shape fits the persistent form on this device (and S2VT_CHAIN != 0)

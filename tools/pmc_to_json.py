@@ -29,9 +29,10 @@ def prof_key(kname):
         return f"3:tn{WM * TM * 16}x{WN * TN * 16}({WM}x{WN})"
     if "gemm_tn_dma_kernel" in kname:
         return "3:tn128x128(dma)"
-    m = re.search(r"lstm_chain_kernel<(\d+)>", kname)
+    m = re.search(r"lstm_chain_kernel<(\d+), (\d+), (\d+)>", kname)
     if m:
-        return f"5:chain(ng{m.group(1)})"
+        ng, tmw, nc = [int(x) for x in m.groups()]
+        return f"5:chain{2 if nc == 2 else ''}(ng{ng},m{tmw * 64 * nc})"
     return "x:" + re.sub(r"^void ", "", kname).split("(")[0][-48:]
 
 
