@@ -29,8 +29,11 @@ SHAPES = [  # M, E, H, T, steps with a carried partial
     (32, 500, 1000, 25, 25),       # the multitask per-GPU batch, a partial at every step (LSTM2 form)
     (17, 500, 1000, 3, 1),
     (100, 8, 64, 4, 4), (130, 12, 128, 3, 0),   # two / three row tiles per wave
-    (320, 500, 1000, 25, 25),                     # LSTM2 of build_loss at K * B = 320 rows: five row tiles per wave
-    (384, 500, 1000, 4, 2), (200, 500, 1000, 3, 3),
+    # above 64 rows at H > 128, H % 8 == 0: the two-part form (8 units x half the row tiles per workgroup)
+    (320, 500, 1000, 25, 25),                     # LSTM2 of build_loss at K * B = 320 rows: parts of 10 row tiles, 3 / 3 / 3 / 1 per wave
+    (384, 500, 1000, 4, 2), (200, 500, 1000, 3, 3),   # 12 tiles per part (3 per wave); 13 row tiles: parts of 7 and 6
+    (128, 500, 1000, 3, 3), (96, 16, 136, 3, 1),      # one row tile per wave; a part whose last waves are idle (3 tiles)
+    (100, 8, 132, 3, 1),                              # H % 8 != 0: the one-part form at two row tiles per wave, 64 k groups
 ]
 
 
