@@ -96,10 +96,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 issue_b(g + NB - 1, nbuf);
                 const int b1 = buf + 1 == NB ? 0 : buf + 1;
                 const float* b = &Bs[b1][lq * 48 + l15];
+#ifndef PP_NOLDS
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int j = 0; j < TNC; ++j) bvn[e][j] = b[e * 4 * 48 + j * 16];
+#else
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TNC; ++j) bvn[e][j] = bvc[e][j] + (float)(size_t)b * 0.f;
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, 4>([&](auto e_) {
                     constexpr int e = decltype(e_)::value;
@@ -123,8 +130,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+#ifndef PP_NOBAR
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
