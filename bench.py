@@ -8,19 +8,30 @@ One step (default workload "rl", BASELINE configs[2]) = frame-embed + encode + K
 global-norm clip + TF-form Adam -- the device work of reinforcement_multisampling_tf_s2vt.py:743-753 and :823-826.  The
 reward (external CIDEr-D host code) is replaced by synthetic r, b.
 
-  python bench.py --gpus N --steps K --warmup W [--workload rl|xe|multitask]
-N>1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce (weak scaling).
+  python bench.py --gpus N --steps K --warmup W [--workload rl|xe|multitask|e2e|e2e_xe]
+N>1: one rank per GPU, RCCL all-reduce of the flat gradient bucket (weak scaling: B per GPU fixed).  Either launched by
+torch.distributed.run (WORLD_SIZE in the environment), or -- plain `python bench.py --gpus N` -- this process starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` itself, BEFORE anything here touches the GPU, relays
+rank 0's line and exits with the children's code.  The N>1 line proves itself: config.rccl_ranks (world size of the
+"nccl" group), config.replica_max_abs_diff (max-min over ranks of checksums of the variables after the timed region:
+0.0), config.allreduce_ms (HIP events around the bucket exchange, per step).
 Prints ONE JSON line on rank 0.
 
 Other single-GPU configurations of BASELINE.json (their own metric names; the default line is unchanged):
   --workload xe         configs[1]: tf_s2vt.py XE train step, B=64 (label smoothing, Q1, weight decay, clip 10)
   --workload multitask  configs[3] per-GPU shape: B=32 (256 / 8 GPUs), K=1, attribute-FC head (400 labels) + XE mix
                         (lambda 0.5) + REINFORCE (reinforce_multitask_e2e_attribute_s2vt.py:850, ..._loss.py:957)
+  --workload e2e        configs[4] per-GPU shape: B=16 (128 / 8 GPUs) x 5 frames x 299^2 through Inception-ResNet-v2
+                        (torch / MIOpen fp32) + the captioner, REINFORCE step K=1 (reinforcement_e2e.py:1085-1140);
+                        e2e_xe: the XE step of e2e_tf_s2vt.py:482-700.  CNN-bound: the roofline object still describes
+                        the dominant kernel of THIS library, `config.cnn_ms` says what MIOpen took.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,7 +56,52 @@ WORKLOADS = {
                       metric="sampled caption tokens/sec (multitask REINFORCE step)",
                       desc="multitask attribute-FC + XE mix + REINFORCE step, per-GPU shape of BASELINE configs[3]: B=32 "
                            "(256 / 8 GPUs), K=1, 400 attribute labels, lambda=0.5, alpha=0.05, features precomputed"),
+    "e2e": dict(B=16, K=1, seqfwd=lambda B, K: 8 * B, tokens=lambda B, K: K * B * TC,
+                metric="sampled caption tokens/sec (end-to-end IRv2 REINFORCE step)",
+                desc="end-to-end Inception-ResNet-v2 fine-tune + REINFORCE step, per-GPU shape of BASELINE configs[4]: B=16 "
+                     "(128 / 8 GPUs) x 5 frames x 3x299x299, K=1, |V|=12000; CNN on torch/MIOpen fp32, captioner on this library"),
+    "e2e_xe": dict(B=16, K=0, seqfwd=lambda B, K: 3 * B, tokens=lambda B, K: B * TC,
+                   metric="caption tokens/sec (end-to-end IRv2 XE step)",
+                   desc="end-to-end Inception-ResNet-v2 fine-tune, XE step of e2e_tf_s2vt.py (BASELINE configs[4] path): B=16 per GPU "
+                        "x 5 frames x 3x299x299, |V|=12000; CNN on torch/MIOpen fp32, captioner on this library"),
 }
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start N ranks under torch.distributed.run as a CHILD process and relay
+    rank 0's JSON line.  Nothing in this process has touched the GPU (torch is not even imported; a process that has
+    initialised HIP must never exec / fork workers on this pool)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup",
+           str(args.warmup), "--workload", args.workload]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    return r.returncode if (r.returncode or line) else 1
 
 
 def kernel_signature():
@@ -113,7 +169,7 @@ def cpu_baseline():
     torch.set_num_threads(cores)
     est = tp * (4 * K + 1)                         # (4K+1) sequence-forward equivalents per step
     if est > 90.0:
-        return {"value": K * B * TC / est, "unit": "tokens/s", "cores": cores, "kind": "port",
+        return {"value": K * B * TC / est, "unit": "tokens/s", "cores": cores, "host_cores": ncpu, "cpu_model": cpu_model(), "kind": "port",
                 "sample": f"one greedy sampler pass at B={B} ({tp:.1f} s, torch-CPU fp32); step rate extrapolated x{4 * K + 1} by flops"}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
@@ -122,15 +178,48 @@ def cpu_baseline():
     for i in range(nsteps):
         T.reference_structured_step(p, m, v, i, video, K, TC, r, b, gen=g)
     dt = (time.time() - t0) / nsteps
-    return {"value": K * B * TC / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+    return {"value": K * B * TC / dt, "unit": "tokens/s", "cores": cores, "host_cores": ncpu, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{nsteps} full REINFORCE step(s) (B={B}, K={K}, Tc={TC}, |V|={V}) structured as the reference: "
                       f"{K}+1 sampler passes + fwd/bwd at {K * B} rows + clip + Adam, torch-CPU fp32, {cores} threads, {dt:.1f} s/step"}
 
 
-def make_step(workload, mdl, dev, rank, B, K):
+def make_e2e_step(workload, mdl, dev, rank, B, K, info):
+    """configs[4]: frames [B, 5, 3, 299, 299] resident in HBM -> Inception-ResNet-v2 (torch / MIOpen) -> captioner."""
+    import numpy as np
+    import torch
+    from s2vt_amd import e2e, irv2, hostglue
+    torch.manual_seed(1234)                                                                # identical CNN replicas
+    tr = e2e.EndToEnd(mdl, irv2.InceptionResnetV2(), seed=1234)
+    info["cnn_params"] = int(tr.theta.numel())
+    info["trainer"] = tr
+    rng = np.random.default_rng(1234 + rank)
+    frames = torch.as_tensor(rng.uniform(-1, 1, (B, TV, 3, 299, 299)).astype(np.float32)).to(dev)
+    g = torch.Generator().manual_seed(1234 + rank)
+    r_dev = (torch.rand(max(K, 1) * B, generator=g) * 2).to(dev)
+    b_dev = (torch.rand(B, generator=g) * 2).to(dev)
+    if workload == "e2e":
+        def step(i):
+            return tr.reinforce_step(frames, lambda s_, g_: (r_dev, b_dev), lr=1e-6, K=K, clip_norm=10.0, video_base=rank * B,
+                                     sample_seed=2024 + i)
+        return step
+    ln = 1 + np.minimum(rng.poisson(6, B), TC - 2)
+    cap = rng.integers(2, V, (B, TC)).astype(np.int32)
+    for j in range(B):
+        cap[j, ln[j]:] = 0
+    gt = torch.as_tensor(cap).to(dev)
+    gt_mask = torch.as_tensor(hostglue.masks_from_ids(cap)).to(dev)
+
+    def step(i):
+        return tr.xe_step(frames, gt, gt_mask, lr=1e-5, clip_norm=10.0, video_base=rank * B)
+    return step
+
+
+def make_step(workload, mdl, dev, rank, B, K, info=None):
     """Synthetic inputs, resident in HBM, and the step closure of the workload."""
     import numpy as np
     import torch
+    if workload.startswith("e2e"):
+        return make_e2e_step(workload, mdl, dev, rank, B, K, info if info is not None else {})
     g = torch.Generator().manual_seed(1234 + rank)                                        # per-rank data shard
     video = (torch.randn(B, TV, D, generator=g) * 0.5).abs().to(dev)                      # post-ReLU IRv2 pool features
     rewards = (torch.rand(max(K, 1) * B, generator=g) * 2).to(dev)
@@ -177,34 +266,32 @@ def main():
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     B, K = wl["B"], wl["K"]
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))                 # before torch / HIP is touched in this process
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} rank(s); "
+              "the launcher's world is what runs and what n_gpus reports", file=sys.stderr)
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    ndev = max(torch.cuda.device_count(), 1)
-    local = local % ndev                          # (functional tests may put several ranks on one GPU)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("S2VT_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for single-GPU functional tests
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
     import s2vt_amd
+    from s2vt_amd import dist as dp
     from s2vt_amd import model as M
     from s2vt_amd import ops
+    backend = os.environ.get("S2VT_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm; "gloo" only for single-GPU functional tests
+    if int(os.environ.get("WORLD_SIZE", "1")) > max(torch.cuda.device_count(), 1) and backend == "nccl":
+        sys.exit(f"bench.py: {os.environ['WORLD_SIZE']} ranks but {torch.cuda.device_count()} GPU(s) visible: RCCL needs one GPU per rank")
+    rank, world, dev = dp.init_from_env()
     s2vt_amd.lib()                                   # no fallback: raises if the HIP library is missing
 
     multitask = args.workload == "multitask"
     mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, device=dev, seed=1234, multisample=max(K, 1),
                                     label_dim=400 if multitask else 0, alpha=0.05 if multitask else 0.0)   # identical replicas
     mdl.world_size, mdl.rank = world, rank
-    step = make_step(args.workload, mdl, dev, rank, B, K)
+    info = {}
+    step = make_step(args.workload, mdl, dev, rank, B, K, info)
 
     # Warm-up: every contraction launch is bracketed by HIP events (in-library, on the launching stream) to get the
     # per-kernel table and find the dominant kernel; inside the timed region only THAT kernel keeps its events
@@ -222,6 +309,7 @@ def main():
         ops.prof_filter(3, 6)          # --warmup 0: no table to pick from; the weight-gradient contraction (tn128x128, LDS-DMA form) is the known dominant kernel
     # per-step durations: one event per step boundary on the launching stream (negligible next to ~600 launches)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    dp.timing_enable(world > 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -242,6 +330,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    ar_ms, ar_n = dp.timing_collect()
+    dp.timing_enable(False)
+    drift = dp.replica_drift(mdl.store.theta)         # every rank takes part (collective); must be exactly 0.0
+    if "trainer" in info:
+        drift = max(drift, dp.replica_drift(info["trainer"].theta))
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -280,6 +373,18 @@ def main():
                           "dp_overlap": bool(mdl.dp_overlap), "loss": float(st.loss),
                           "persistent_recurrence_timeouts": ops.chain_timeouts()},      # grid-wide waits that gave up: must be 0
                "roofline": roof}
+        if world > 1:
+            out["config"].update({
+                "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,    # 0 = NOT an RCCL run (functional gloo run)
+                "dist_backend": dist.get_backend(),
+                "replica_max_abs_diff": drift,                                                   # checksums of the variables, max - min over ranks
+                "allreduce_ms": round(ar_ms / max(args.steps, 1), 4),                            # per step, rank 0's stream, HIP events
+                "allreduce_brackets_per_step": round(ar_n / max(args.steps, 1), 2),
+                "gradient_bucket_bytes": int(mdl.store.grad.numel() * 4)})
+        if "cnn_params" in info:
+            out["config"]["cnn_params"] = info["cnn_params"]
+            out["config"]["note"] = ("CNN-bound step: the convolutions run on MIOpen through PyTorch (not a kernel of this library); "
+                                     "the roofline object describes this library's dominant kernel only")
         if world == 1 and not args.no_cpu_baseline and args.workload == "rl":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

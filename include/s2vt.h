@@ -39,6 +39,8 @@ extern "C" {
 #define S2VT_E_ALIGN (-2)    /* workspace not 256-byte aligned */
 #define S2VT_E_WORKSPACE (-3)/* workspace too small */
 #define S2VT_E_HIP (-4)      /* a HIP call failed: see s2vt_last_hip_error() */
+#define S2VT_E_CHAIN_TIMEOUT (-5) /* a persistent recurrence timed out earlier (starved of CUs): activations since are suspect, variable
+                                     updates queued behind it were SKIPPED on the device; see s2vt_chain_fault / s2vt_chain_ack */
 
 typedef void* s2vt_stream;   /* hipStream_t */
 
@@ -246,6 +248,12 @@ int s2vt_grad_finalize(float* g, const float* theta, int64_t n, const float* gsc
                        s2vt_stream stream);
 int s2vt_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
                  float lr, int64_t step, float beta1, float beta2, float eps, s2vt_stream stream);
+/* The same update with a receipt: when the launch applies the update it writes `step` to *applied_step (device int32).
+ * Every s2vt_adam_tf* launch is a no-op ON THE DEVICE while a persistent-recurrence fault is pending (s2vt_chain_fault):
+ * gradients computed from a starved recurrence never reach the variables, and after a device synchronise
+ * *applied_step tells the host which update was the last one applied. */
+int s2vt_adam_tf_guarded(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
+                         float lr, int64_t step, float beta1, float beta2, float eps, int32_t* applied_step, s2vt_stream stream);
 
 /* ---- temporal attention, one decode step (original_attention.py:106-128) ----------------------
  * Inputs: hWa [B,H] = h_prev @ embed_att_Wa (s2vt_gemm); P [Tv,B,H] = Vt @ embed_att_Ua + ba (hoisted,
@@ -362,6 +370,17 @@ int s2vt_lstm_recurrence_fwd(const float* W, int32_t kw0, const float* b, const 
 /* Grid-wide waits of the persistent recurrence that gave up (bounded spins), over all launches of this process; 0 =
  * healthy.  Read after synchronising the stream. */
 int s2vt_chain_timeouts(void);
+/* The persistent recurrence needs all its workgroups resident at once.  The launcher checks the occupancy and never
+ * overlaps two persistent grids of one process, but it cannot see another process on the same GPU: if a grid-wide wait
+ * gives up, a fault is raised (host-visible counter + device-resident word) and stays raised until acknowledged:
+ *   - s2vt_chain_fault(): 1 while a fault is pending (a host-memory read: no synchronisation, callable every step);
+ *   - every entry point that launches a recurrence or updates variables returns S2VT_E_CHAIN_TIMEOUT while it is pending,
+ *     and s2vt_adam_tf* launches already queued behind the faulting kernel skip their update on the device;
+ *   - s2vt_chain_ack(disable): synchronises the device, clears the fault; disable != 0 turns the persistent form off for
+ *     the rest of the process (the per-step launches give the same bits).  The caller then repeats the work since the
+ *     last applied update. */
+int s2vt_chain_fault(void);
+int s2vt_chain_ack(int disable_persistent);
 
 /* In-place SUM all-reduce of the flat gradient bucket over an existing RCCL communicator (ncclComm_t as
  * void*), on `stream` -- the exchange step of SURVEY.md section 8(e) for C/C++ hosts (Python hosts use

@@ -13,6 +13,12 @@ class S2VTLibraryError(RuntimeError):
     pass
 
 
+class S2VTChainTimeout(S2VTLibraryError):
+    """A persistent recurrence (csrc/chain.hip) was starved of CUs and gave up a grid-wide wait (S2VT_E_CHAIN_TIMEOUT):
+    activations computed since are suspect, variable updates queued behind it were skipped on the device.  Recover with
+    Video_Caption_Generator.recover() (synchronise, acknowledge, fall back to per-step launches) and repeat the step."""
+
+
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim_image", "n_words", "word_dim", "lstm_dim", "n_video_lstm_step",
                                          "n_caption_lstm_step", "label_dim", "reserved")]
@@ -99,6 +105,9 @@ SIGNATURES = {
     "s2vt_lstm_recurrence_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _u64, _vp, _vp,
                                            _u32, _i32, _vp, _sz, _vp]),
     "s2vt_chain_timeouts": (C.c_int, []),
+    "s2vt_chain_fault": (C.c_int, []),
+    "s2vt_chain_ack": (C.c_int, [C.c_int]),
+    "s2vt_adam_tf_guarded": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "s2vt_allreduce_grads": (C.c_int, [_vp, _i64, _vp, _vp]),
     "s2vt_set_rccl_allreduce": (C.c_int, [_vp]),
 }
@@ -133,4 +142,6 @@ def check(rc: int, what: str = "s2vt call"):
         L = lib()
         msg = L.s2vt_error_string(rc).decode()
         extra = f" hipError={L.s2vt_last_hip_error()}" if rc == -4 else ""
+        if rc == -5:
+            raise S2VTChainTimeout(f"{what} refused: {msg} (code {rc})")
         raise S2VTLibraryError(f"{what} failed: {msg} (code {rc}){extra}")

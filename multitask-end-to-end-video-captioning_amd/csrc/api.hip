@@ -66,6 +66,7 @@ const char* s2vt_error_string(int code)
         case S2VT_E_ALIGN: return "workspace not 256-byte aligned";
         case S2VT_E_WORKSPACE: return "workspace too small";
         case S2VT_E_HIP: return "HIP error (see s2vt_last_hip_error)";
+        case S2VT_E_CHAIN_TIMEOUT: return "a persistent recurrence timed out (GPU shared with another persistent kernel?): results since are suspect, updates were skipped; s2vt_chain_ack() and repeat";
         default: return "unknown error";
     }
 }
@@ -236,7 +237,7 @@ hipError_t lstm_recurrence(const float* W, int kw0, const float* bias, const flo
                            float* out, size_t out_tstride, int M, int H, int T, float keep, const NoiseIds& ids,
                            uint32_t drop_code0, float* chain_abuf, unsigned* chain_sync, hipStream_t st)
 {
-    if (chain_abuf && chain_sync && chain_eligible(M, H)) {
+    if (chain_abuf && chain_sync && chain_eligible(M, H) && chain_operands_ok(W, 4 * H, chain_abuf)) {    // (unaligned W: per-step launches)
         ChainArgs a;
         std::memset(&a, 0, sizeof(a));
         a.W = W; a.ldw = 4 * H; a.kw0 = kw0; a.bias = bias;
@@ -362,6 +363,7 @@ int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, in
     if (!dims_ok(d) || !sampler_params_ok(p) || !video || !ids_out || !workspace || B <= 0 || K < 0 || (K == 0 && !with_greedy))
         return S2VT_E_BADARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     const int R = (K + (with_greedy ? 1 : 0)) * B;
     Carver c(workspace, workspace_bytes);
     SampleWs w;

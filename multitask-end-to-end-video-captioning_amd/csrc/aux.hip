@@ -497,8 +497,10 @@ hipError_t launch_grad_finalize(float* g, const float* theta, int64_t n, const f
 
 __global__ __launch_bounds__(256) void adam_tf_kernel(float* theta, const float* g, float* m, float* v, int64_t n,
                                                       const float* sumsq, float clip, float lr_t, float b1, float b2,
-                                                      float eps)
+                                                      float eps, const unsigned* fault, int32_t* applied_step, int32_t step)
 {
+    if (fault && *fault != 0u) return;             // a persistent recurrence upstream timed out: leave the variables alone
+    if (applied_step && blockIdx.x == 0 && threadIdx.x == 0) *applied_step = step;
     float s = 1.0f;
     if (sumsq && clip > 0.f) {
         const float nrm = sqrtf(*sumsq);
@@ -516,12 +518,14 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* theta, const float*
 }
 
 hipError_t launch_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip,
-                          float lr_t, float b1, float b2, float eps, hipStream_t st)
+                          float lr_t, float b1, float b2, float eps, hipStream_t st, const unsigned* fault, int32_t* applied_step,
+                          int32_t step)
 {
     if (n <= 0) return hipSuccess;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adam_tf_kernel, dim3(blocks), dim3(256), 0, st, theta, g, m, v, n, sumsq, clip, lr_t, b1, b2, eps);
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(blocks), dim3(256), 0, st, theta, g, m, v, n, sumsq, clip, lr_t, b1, b2, eps, fault,
+                       applied_step, step);
     return hipGetLastError();
 }
 

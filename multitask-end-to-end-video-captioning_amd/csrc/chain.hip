@@ -19,10 +19,19 @@
 // Arithmetic contract unchanged: each pre-activation is cinit (+) the ascending-k fp32 chain over the
 // recurrent rows, v_mfma_f32_16x16x4_f32 in k order; the pointwise part is the EPI_LSTM expression sequence, so states,
 // gates and dropped outputs are bit-identical to T per-step launches (tests/test_gpu_chain.py).
-// All workgroups must be co-resident (grid = H / 4 <= CU count, one 256-thread workgroup per CU); every spin is bounded
-// and a timeout sets a status word instead of hanging (s2vt_chain_status).
+// All workgroups must be co-resident (grid = H / 4 <= CU count, one 256-thread workgroup per CU).  What guards that:
+//   * the launcher checks hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs >= grid per configuration and device;
+//   * persistent launches of one process never overlap: a launch on another stream first waits for the event recorded
+//     behind the previous one (two half-resident grids would starve each other);
+//   * every spin is bounded; a timeout raises a host-mapped counter AND a device-resident fault word.  The fault is
+//     sticky until acknowledged (s2vt_chain_ack): every later library call that would launch a recurrence or update the
+//     variables returns S2VT_E_CHAIN_TIMEOUT, and adam_tf_kernel launches already queued behind the fault SKIP their
+//     update on the device -- a starved recurrence can produce garbage activations, never garbage variables.
+// Another PROCESS on the same GPU running its own persistent grid cannot be seen from here: the GPU must be exclusive to
+// the process, or S2VT_CHAIN=0.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -47,7 +56,7 @@ __device__ __forceinline__ f32x4 bload16_sc1(__amdgpu_buffer_rsrc_t rsrc, int vo
 }
 
 constexpr int kShards = 8;             // counter shards, one 128-byte line each; word kShards * 32 = timeout flag
-constexpr unsigned kSpinLimit = 1u << 21;
+constexpr unsigned kSpinLimitDefault = 1u << 21;   // polls (each >= ~0.3 us: s_sleep + an L2 round trip) before a wait gives up: ~1-2 s
 
 // The grid-wide hand-off of the persistent kernels (MI355X_MICROARCH.md "Valid forms", row 1): every storing wave drains its
 // write-through stores / atomics, the workgroup's barrier, ONE lane adds to its shard of the arrival counter; one wave per
@@ -57,6 +66,8 @@ constexpr unsigned kSpinLimit = 1u << 21;
 struct GridSync {
     gu32* sync;
     unsigned* status;
+    unsigned* fault;
+    unsigned spin_limit;
     int nwg;
     bool dead;
     __device__ __forceinline__ void arrive(int tid)
@@ -73,9 +84,10 @@ struct GridSync {
             for (;;) {
                 const unsigned v = lane < kShards ? __hip_atomic_load(sync + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 if (__all(lane >= kShards || v >= mine)) break;
-                if (++spins > kSpinLimit) {                    // never hang: flag it and go on (results are then garbage, status says so)
+                if (++spins > spin_limit) {                    // never hang: flag it and go on (results are then garbage; the fault words say so)
                     if (lane == 0) {
                         __hip_atomic_store(sync + kShards * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (fault) __hip_atomic_store((gu32*)fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-resident: later update kernels skip
                         if (status) __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible
                     }
                     dead = true;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* const abuf0 = g.abuf;
     float* const abuf1 = g.abuf + (size_t)g.img_tiles * NG * 256;
 
-    GridSync gs{(gu32*)g.sync, g.status, nwg, false};
+    GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, nwg, false};
     auto arrive = [&]() __attribute__((always_inline)) { gs.arrive(tid); };
     auto wait_all = [&](unsigned arrival) __attribute__((always_inline)) { gs.wait_all(arrival, pwave, lane); };
 
@@ -329,25 +341,84 @@ const ChainCfg kChain[] = {
     {64, 1, 2, lstm_chain_kernel<64, 1, 2>, "chain2(ng64,m128)"}, {64, 2, 2, lstm_chain_kernel<64, 2, 2>, "chain2(ng64,m256)"},
     {64, 3, 2, lstm_chain_kernel<64, 3, 2>, "chain2(ng64,m384)"},
 };
-int g_num_cus = 0;
+constexpr int kNumCfg = (int)(sizeof(kChain) / sizeof(kChain[0]));
+constexpr int kMaxDev = 32;
+// one-time state PER DEVICE (a process may drive several): CU count, the dynamic-LDS attribute of every configuration, how
+// many workgroups of each configuration one CU holds, the device-resident fault word
+struct DevState {
+    std::once_flag once;
+    int num_cus = 0;                       // 0 = the persistent form is unavailable on this device
+    int per_cu[kNumCfg] = {};
+    unsigned* fault = nullptr;             // device memory, 1 after a timed-out wait until chain_ack()
+};
+DevState g_dev[kMaxDev];
+std::mutex g_launch_mu;
+hipEvent_t g_last_done = nullptr;          // recorded behind the most recent persistent launch of this process
+hipStream_t g_last_stream = nullptr;
+int g_last_device = -1;
+std::atomic<unsigned> g_acked{0};          // timeouts acknowledged so far (chain_ack)
+std::atomic<bool> g_disabled{false};       // chain_ack(disable): per-step launches from here on
+
+int chain_lds_bytes(const ChainCfg& c) { return (c.ng * c.nc * 256 + 4 * 16 * 20) * 4; }
+
+int current_num_cus()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 0;
+    return g_dev[dev].num_cus;
+}
 bool chain_two_parts(int M, int H)                             // the 8-unit / half-the-rows form serves this shape
 {
     static const bool off = [] { const char* e = getenv("S2VT_CHAIN2"); return e && e[0] == '0'; }();          // dev knob
-    return !off && M > 64 && (H + 15) / 16 > 8 && (H & 7) == 0 && 2 * (H / 8) <= g_num_cus;
+    return !off && M > 64 && (H + 15) / 16 > 8 && (H & 7) == 0 && 2 * (H / 8) <= current_num_cus();
 }
 int chain_cfg(int M, int H)                                    // index into kChain, or -1
 {
     const int tiles = (M + 15) / 16;
     const bool two = chain_two_parts(M, H);
     const int ng = (H + 15) / 16 <= 8 ? 8 : 64, tmw = two ? ((tiles + 1) / 2 + 3) / 4 : (M + 63) / 64, nc = two ? 2 : 1;
-    for (int i = 0; i < (int)(sizeof(kChain) / sizeof(kChain[0])); ++i)
+    for (int i = 0; i < kNumCfg; ++i)
         if (kChain[i].ng == ng && kChain[i].tmw == tmw && kChain[i].nc == nc) return i;
     return -1;
 }
 
-std::once_flag g_chain_once;
-unsigned* g_status_host = nullptr;     // pinned, device-mapped: timeouts of every chain launch of this process
+std::once_flag g_status_once;
+unsigned* g_status_host = nullptr;     // pinned, device-mapped (portable): timeouts of every chain launch of this process
 unsigned* g_status_dev = nullptr;
+
+DevState* dev_state()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    std::call_once(g_status_once, [] {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+            g_status_host = static_cast<unsigned*>(hp);
+            *g_status_host = 0u;
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) g_status_dev = static_cast<unsigned*>(dp);
+        }
+    });
+    DevState& d = g_dev[dev];
+    std::call_once(d.once, [&d, dev] {
+        hipDeviceProp_t p;
+        int cus = 0;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        bool ok = cus > 0 && g_status_dev;
+        for (int i = 0; ok && i < kNumCfg; ++i) {
+            const ChainCfg& c = kChain[i];
+            ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(c)) == hipSuccess;
+            int n = 0;
+            // co-residency is CHECKED, not assumed: workgroups of this configuration one CU can hold (registers, LDS, waves)
+            if (ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(c.fn), 256, chain_lds_bytes(c)) == hipSuccess)
+                d.per_cu[i] = n;
+        }
+        void* f = nullptr;
+        if (ok && hipMalloc(&f, 256) == hipSuccess && hipMemset(f, 0, 256) == hipSuccess) d.fault = static_cast<unsigned*>(f);
+        d.num_cus = (ok && d.fault) ? cus : 0;                // an LDS request refused / no status word: the per-step path serves
+    });
+    return &d;
+}
 
 }  // namespace
 
@@ -366,50 +437,69 @@ static int chain_max_rows()
 bool chain_eligible(int M, int H)
 {
     static const bool off = [] { const char* e = getenv("S2VT_CHAIN"); return e && e[0] == '0'; }();
-    std::call_once(g_chain_once, [] {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cus = p.multiProcessorCount;
-        bool ok = g_num_cus > 0;
-        for (const ChainCfg& c : kChain)
-            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (c.ng * c.nc * 256 + 4 * 16 * 20) * 4) == hipSuccess;
-        void* hp = nullptr;
-        if (ok && hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
-            g_status_host = static_cast<unsigned*>(hp);
-            *g_status_host = 0u;
-            void* dp = nullptr;
-            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) g_status_dev = static_cast<unsigned*>(dp);
-        }
-        if (!ok || !g_status_dev) g_num_cus = 0;               // an LDS request refused / no status word: the per-step path serves
-    });
-    return !off && M >= 1 && chain_cfg(M, H) >= 0 && M <= chain_max_rows() && H >= 4 && (H & 3) == 0 && H <= 1024 && H / 4 <= g_num_cus;
+    if (off || g_disabled.load(std::memory_order_relaxed)) return false;
+    DevState* d = dev_state();
+    if (!d || d->num_cus <= 0) return false;
+    if (!(M >= 1 && M <= chain_max_rows() && H >= 4 && (H & 3) == 0 && H <= 1024 && H / 4 <= d->num_cus)) return false;
+    const int ci = chain_cfg(M, H);
+    if (ci < 0) return false;
+    const int grid = kChain[ci].nc * (H / (4 * kChain[ci].nc));
+    return (long)d->per_cu[ci] * d->num_cus >= grid;           // every workgroup of the grid fits on the chip at once
+}
+
+static unsigned spin_limit()
+{
+    static const unsigned v = [] { const char* e = getenv("S2VT_CHAIN_SPIN_LIMIT"); return e ? (unsigned)strtoul(e, nullptr, 10) : kSpinLimitDefault; }();   // dev / test knob
+    return v;
 }
 
 hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
 {
     if (!chain_eligible(a.M, a.H)) return hipErrorInvalidValue;
     if (a.T <= 0) return hipSuccess;
-    if ((reinterpret_cast<uintptr_t>(a.W) & 15) || (a.ldw & 3) || (reinterpret_cast<uintptr_t>(a.abuf) & 15)) return hipErrorInvalidValue;
+    if (!chain_operands_ok(a.W, a.ldw, a.abuf)) return hipErrorInvalidValue;
+    DevState* d = dev_state();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     const int ci = chain_cfg(a.M, a.H);
     const ChainCfg& c = kChain[ci];
     ChainArgs a2 = a;
     a2.status = g_status_dev;
+    a2.fault = d->fault;
+    a2.spin_limit = spin_limit();
     const int tiles = (a.M + 15) / 16, parts = c.nc;           // (two column tiles go with two row parts)
     a2.ncg = a.H / (4 * c.nc);
     a2.tpp = parts == 1 ? 4 * c.tmw : (tiles + 1) / 2;
     a2.img_tiles = parts * 4 * c.tmw;
+    // One persistent grid at a time per process: a launch on a different stream (or device) waits for the previous one.
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    if (g_last_done && (g_last_stream != st || g_last_device != dev)) {
+        hipError_t we = hipStreamWaitEvent(st, g_last_done, 0);
+        if (we != hipSuccess) return we;
+    }
     // every polled word and the fragment images start from zero on EVERY call (a memset node ahead of the launch)
     hipError_t e = hipMemsetAsync(a.sync, 0, kChainSyncBytes, st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.abuf, 0, (size_t)2 * a2.img_tiles * c.ng * 256 * 4, st);
     if (e != hipSuccess) return e;
-    const int lds = (c.ng * c.nc * 256 + 4 * 16 * 20) * 4;
+    const int lds = chain_lds_bytes(c);
     const dim3 grid((unsigned)(parts * a2.ncg));
     const double flops = 2.0 * a.M * (double)a.H * 4.0 * a.H * a.T;
+    auto mark_done = [&]() -> hipError_t {
+        if (!g_last_done || g_last_device != dev) {            // (an event belongs to the device it was created on)
+            if (g_last_done) (void)hipEventDestroy(g_last_done);
+            g_last_done = nullptr;
+            hipError_t ce = hipEventCreateWithFlags(&g_last_done, hipEventDisableTiming);
+            if (ce != hipSuccess) return ce;
+        }
+        g_last_stream = st;
+        g_last_device = dev;
+        return hipEventRecord(g_last_done, st);
+    };
     if (!prof_wants(5, ci)) {
         hipLaunchKernelGGL(c.fn, grid, dim3(256), lds, st, a2);
-        return hipGetLastError();
+        e = hipGetLastError();
+        return e != hipSuccess ? e : mark_done();
     }
     hipEvent_t e0, e1;
     hipError_t pe = prof_events(&e0, &e1);
@@ -418,9 +508,40 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
     hipLaunchKernelGGL(c.fn, grid, dim3(256), lds, st, a2);
     (void)hipEventRecord(e1, st);
     prof_record(5, ci, c.name, flops, e0, e1);
-    return hipGetLastError();
+    e = hipGetLastError();
+    return e != hipSuccess ? e : mark_done();
+}
+
+bool chain_operands_ok(const float* W, int ldw, const float* abuf)
+{
+    return !(reinterpret_cast<uintptr_t>(W) & 15) && !(ldw & 3) && !(reinterpret_cast<uintptr_t>(abuf) & 15);
 }
 
 unsigned chain_timeouts() { return g_status_host ? *static_cast<volatile unsigned*>(g_status_host) : 0u; }
+
+bool chain_fault() { return chain_timeouts() != g_acked.load(std::memory_order_relaxed); }
+
+const unsigned* chain_fault_word()
+{
+    DevState* d = dev_state();
+    return d ? d->fault : nullptr;
+}
+
+hipError_t chain_ack(bool disable)
+{
+    // the caller has synchronised the device (s2vt_chain_ack does): no kernel is reading or raising the words now
+    g_acked.store(chain_timeouts(), std::memory_order_relaxed);
+    if (disable) g_disabled.store(true, std::memory_order_relaxed);
+    for (int i = 0; i < kMaxDev; ++i)
+        if (g_dev[i].fault) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            (void)hipSetDevice(i);
+            const hipError_t e = hipMemset(g_dev[i].fault, 0, 256);
+            (void)hipSetDevice(cur);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
 
 }  // namespace s2vt

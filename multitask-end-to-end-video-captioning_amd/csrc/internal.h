@@ -60,8 +60,11 @@ hipError_t launch_scatter_add_rows(const float* dE, int ld, const int32_t* idx, 
 hipError_t launch_transpose(const float* in, int ldi, float* out, int ldo, int R, int Cc, hipStream_t st);
 hipError_t launch_grad_finalize(float* g, const float* theta, int64_t n, const float* gscale, float wd, float* sumsq,
                                 hipStream_t st);
+// fault: optional device word -- nonzero makes the launch a no-op (a persistent recurrence timed out upstream: the
+// gradients are garbage); applied_step: optional device word that receives `step` when the update IS applied
 hipError_t launch_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip,
-                          float lr_t, float b1, float b2, float eps, hipStream_t st);
+                          float lr_t, float b1, float b2, float eps, hipStream_t st, const unsigned* fault = nullptr,
+                          int32_t* applied_step = nullptr, int32_t step = 0);
 
 // ---- a whole LSTM recurrence (T steps, M <= 64 rows) in one persistent launch (chain.hip)
 struct ChainArgs {
@@ -78,6 +81,8 @@ struct ChainArgs {
     float* abuf;                                       // chain_scratch_floats(H) floats, 16-byte aligned
     unsigned* sync;                                    // kChainSyncBytes bytes: arrival counters + timeout word
     unsigned* status;                                  // (set by the launcher) host-mapped count of timed-out waits
+    unsigned* fault;                                   // (set by the launcher) device-resident fault word: 1 after a timeout until chain_ack()
+    unsigned spin_limit;                               // (set by the launcher) polls before a grid-wide wait gives up
     int ncg, tpp, img_tiles;                           // (set by the launcher) column groups, row tiles per row part, row tiles of one state image
 };
 constexpr size_t kChainSyncBytes = 9 * 128;            // 8 counter shards + the status line, a block of its own (multiple of 16)
@@ -85,6 +90,10 @@ bool chain_eligible(int M, int H);                     // shape fits the persist
 size_t chain_scratch_floats(int H);
 hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st);
 unsigned chain_timeouts();                             // grid-wide waits that gave up, all launches of this process (0 = healthy)
+bool chain_operands_ok(const float* W, int ldw, const float* abuf);   // alignment the persistent form needs (else: per-step launches)
+bool chain_fault();                                    // a timeout has happened and has not been acknowledged: results since are suspect
+const unsigned* chain_fault_word();                    // device word of the current device (1 = fault), NULL when the persistent form is unavailable
+hipError_t chain_ack(bool disable);                    // acknowledge (device idle!); disable: per-step launches for the rest of the process
 
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.

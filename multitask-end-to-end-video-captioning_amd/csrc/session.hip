@@ -92,6 +92,7 @@ int s2vt_destroy(s2vt_handle* h)
 int s2vt_encode_fwd(s2vt_handle* h, const s2vt_params* p, const float* video, int32_t B, s2vt_stream stream)
 {
     if (!h || !sampler_params_ok(p) || !video || B <= 0 || B > h->max_B) return S2VT_E_BADARG;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     Carver c(h->ws, h->ws_bytes);
     SampleWs w;
     carve_sample(c, &h->dims, B, (h->max_K + 1) * B, &w);
@@ -105,6 +106,7 @@ static int decode_common(s2vt_handle* h, const s2vt_params* p, int K, int greedy
                          s2vt_stream stream)
 {
     if (!h || !sampler_params_ok(p) || !ids_out || h->enc_B <= 0 || K < 0 || K > h->max_K) return S2VT_E_BADARG;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;          // the encode this decode continues may be the one that was starved
     Carver c(h->ws, h->ws_bytes);
     SampleWs w;
     carve_sample(c, &h->dims, h->enc_B, (h->max_K + 1) * h->enc_B, &w);     // same layout as the encode call
@@ -264,8 +266,10 @@ int s2vt_lstm_recurrence_fwd(const float* W, int32_t kw0, const float* b, const 
     if (!(keep > 0.0f) || (keep < 1.0f && (!out || !video_id || !sample_id))) return S2VT_E_BADARG;
     float* abuf = nullptr;
     unsigned* sync = nullptr;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     if (persistent != 0) {
         if (persistent == 1 && !chain_eligible(M, H)) return S2VT_E_BADARG;
+        if (persistent == 1 && !chain_operands_ok(W, 4 * H, W)) return S2VT_E_ALIGN;       // (-1 falls back to per-step launches)
         if (chain_eligible(M, H)) {
             if (!scratch) return S2VT_E_BADARG;
             if (reinterpret_cast<uintptr_t>(scratch) & 255u) return S2VT_E_ALIGN;
@@ -283,6 +287,15 @@ int s2vt_lstm_recurrence_fwd(const float* W, int32_t kw0, const float* b, const 
 }
 
 int s2vt_chain_timeouts(void) { return (int)chain_timeouts(); }
+
+int s2vt_chain_fault(void) { return chain_fault() ? 1 : 0; }
+
+int s2vt_chain_ack(int disable_persistent)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(chain_ack(disable_persistent != 0));
+    return S2VT_OK;
+}
 
 // ncclAllReduce of the RCCL instance that OWNS the caller's communicator.  A communicator must never be handed to a
 // second copy of the library, so nothing is ever loaded here: (1) an entry point registered by the host

@@ -166,6 +166,7 @@ int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, cons
         return S2VT_E_BADARG;
     if (!(keep > 0.0f) || (keep < 1.0f && (!video_id || !sample_id))) return S2VT_E_BADARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
     const int T = Tv + Tc;
     Carver c(workspace, workspace_bytes);
@@ -271,6 +272,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
     if (!dims_ok(d) || !params_ok(p) || !params_ok(grads) || !video || !dlogits || !workspace || B <= 0 || N <= 0 || N % B)
         return S2VT_E_BADARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, D = d->dim_image, Tv = d->n_video_lstm_step,
               Tc = d->n_caption_lstm_step;
     const int T = Tv + Tc;
@@ -398,10 +400,18 @@ int s2vt_grad_finalize(float* g, const float* theta, int64_t n, const float* gsc
 int s2vt_adam_tf(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
                  float lr, int64_t step, float beta1, float beta2, float eps, s2vt_stream stream)
 {
+    return s2vt_adam_tf_guarded(theta, g, m, v, n, sumsq, clip_norm, lr, step, beta1, beta2, eps, nullptr, stream);
+}
+
+int s2vt_adam_tf_guarded(float* theta, const float* g, float* m, float* v, int64_t n, const float* sumsq, float clip_norm,
+                         float lr, int64_t step, float beta1, float beta2, float eps, int32_t* applied_step, s2vt_stream stream)
+{
     if (!theta || !g || !m || !v || n < 0 || step < 1) return S2VT_E_BADARG;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;        // (a fault raised after this check is caught by the kernel itself)
     // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t), epsilon outside the bias correction
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
-    HIP_TRY(launch_adam_tf(theta, g, m, v, n, sumsq, clip_norm, (float)lr_t, beta1, beta2, eps, S(stream)));
+    HIP_TRY(launch_adam_tf(theta, g, m, v, n, sumsq, clip_norm, (float)lr_t, beta1, beta2, eps, S(stream), chain_fault_word(), applied_step,
+                           (int32_t)step));
     return S2VT_OK;
 }
 

@@ -97,7 +97,7 @@ class EndToEnd:
 
     def _cnn_apply(self, lr, clip_norm):
         m = self.model
-        ops.adam_tf(self.theta, self.grad, self.m, self.v, m._sumsq, clip_norm, lr, m.global_step)
+        ops.adam_tf(self.theta, self.grad, self.m, self.v, m._sumsq, clip_norm, lr, m.adam_t)
 
     # ---------------------------------------------------------------- training steps
     def xe_step(self, frames, caption, caption_mask, lr, clip_norm=10.0, video_base=0):

@@ -81,27 +81,37 @@ class ParamStore:
             if n in self.p:
                 self.p[n].copy_(torch.as_tensor(np.asarray(a)).to(self.p[n].device))
 
-    def state_dict(self, global_step=None):
-        """Checkpoint with the reference's TF variable names.  With global_step given, also what tf.train.Saver stores
-        beside the variables (tf_s2vt.py:438, reinforcement_multisampling_tf_s2vt.py:661): the Adam slots
-        `<var>/Adam` (m), `<var>/Adam_1` (v), `beta1_power`, `beta2_power` and the step counter, so a resumed run
-        continues the moments, the bias correction and the learning-rate staircase."""
+    def state_dict(self, global_step=None, adam_t=None, step_name="g_step"):
+        """Checkpoint with the reference's TF variable names.  With global_step given, also what a tf.train.Saver created
+        AFTER the optimizer stores beside the variables (reinforcement_multisampling_tf_s2vt.py:661; the saver of
+        tf_s2vt.py:440 is created before the optimizer and holds the model variables only): the Adam slots `<var>/Adam` (m),
+        `<var>/Adam_1` (v), `beta1_power`, `beta2_power` and the step counter, so a resumed run continues the moments, the
+        bias correction and the learning-rate staircase.  The counter is stored under `step_name` -- 'g_step' is the
+        REINFORCE script's name (:637), 'Variable' what the unnamed tf.Variable(0, trainable=False) of the other scripts gets
+        (tf_s2vt.py:441) -- and under 'global_step'.  adam_t: Adam's own count of applied updates (what beta*_power encode);
+        defaults to global_step."""
         sd = {TF_NAMES[n]: self.p[n].detach().cpu().numpy() for n in self.names}
         if global_step is not None:
+            t = int(global_step if adam_t is None else adam_t)
             for n in self.names:
                 sd[TF_NAMES[n] + "/Adam"] = self._view(self.m, n).detach().cpu().numpy()
                 sd[TF_NAMES[n] + "/Adam_1"] = self._view(self.v, n).detach().cpu().numpy()
-            sd["beta1_power"] = np.float32(0.9 ** (int(global_step) + 1))      # TF keeps beta^(t+1) after t applied steps
-            sd["beta2_power"] = np.float32(0.999 ** (int(global_step) + 1))
+            sd["beta1_power"] = np.float32(0.9 ** (t + 1))      # TF keeps beta^(t+1) after t applied steps
+            sd["beta2_power"] = np.float32(0.999 ** (t + 1))
             sd["global_step"] = np.int64(global_step)
+            sd[step_name] = np.int64(global_step)
         return sd
 
     def load_state_dict(self, sd: dict):
         """optimistic_restore: load every variable whose NAME and SHAPE match, ignore the rest (Adam slots included).
-        Returns the loaded names; `self.restored_step` is the checkpoint's step counter or None."""
+        Returns the loaded names; `self.restored_step` is the checkpoint's step counter or None (names 'global_step',
+        'g_step' -- reinforcement_multisampling_tf_s2vt.py:637 -- or 'Variable', the unnamed counter of tf_s2vt.py:441);
+        `self.restored_adam_t` is Adam's count of applied updates decoded from `beta1_power` (= 0.9^(t+1)) or None: the two
+        differ when a REINFORCE run starts from an XE checkpoint (slots and beta powers match by name, 'g_step' does not)."""
         inv = {v: k for k, v in TF_NAMES.items()}
         loaded = []
         self.restored_step = None
+        self.restored_adam_t = None
 
         def put(dst, arr):
             dst.copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(dst.device))
@@ -115,8 +125,14 @@ class ParamStore:
             if n in self.p and tuple(np.shape(arr)) == tuple(self.shapes[n]):
                 put(self.p[n] if slot is None else self._view(self.m if slot == "/Adam" else self.v, n), arr)
                 loaded.append(name)
-            elif name in ("global_step", "g_step") and np.ndim(arr) == 0:
-                self.restored_step = int(arr)
+            elif name in ("global_step", "g_step", "Variable") and np.ndim(arr) == 0 and np.issubdtype(np.asarray(arr).dtype, np.integer):
+                if name == "global_step" or self.restored_step is None:
+                    self.restored_step = int(arr)
+                loaded.append(name)
+            elif name == "beta1_power" and np.ndim(arr) == 0:
+                b = float(arr)
+                if 0.0 < b < 1.0:
+                    self.restored_adam_t = max(0, int(round(math.log(b) / math.log(0.9))) - 1)
                 loaded.append(name)
         return loaded
 
@@ -180,12 +196,21 @@ class Session:
                     raise KeyError(f"Session.run: fetch {f.name!r} needs a value for placeholder(s) {missing}")
                 cache[key] = f.fn(*[feed[p] for p in f.inputs])
             return cache[key]
-        for f in fl:                                  # state-changing fetches first: what they yield for other fetches is
-            if f.provides:                            # the value those had when the update read them
+        # As in TF, every fetch of one run() sees the SAME pre-update state: (1) fetches that no state-changing fetch yields
+        # (build_model's probs next to a train_op, a sampler's ids) are evaluated first, on the variables, step counter and
+        # dropout seed the update is about to read; (2) then the state-changing fetches, whose by-products (the loss the
+        # update differentiated) stand for the fetches they provide.
+        will_give = {id(o) for f in fl if f.provides for o in f.provides}
+        early = {}
+        for f in fl:
+            if not f.provides and id(f) not in will_give:
+                early[id(f)] = evaluate(f)[f.name]
+        for f in fl:
+            if f.provides:
                 res = evaluate(f)
                 for other, k in f.provides.items():
                     given[id(other)] = res[k]
-        out = [given[id(f)] if id(f) in given else evaluate(f)[f.name] for f in fl]
+        out = [early[id(f)] if id(f) in early else (given[id(f)] if id(f) in given else evaluate(f)[f.name]) for f in fl]
         return out[0] if single else out
 
 
@@ -215,13 +240,17 @@ class Video_Caption_Generator:
         init_reference(self.store, seed)
         if bias_init_vector is not None:
             self.store.p["embed_word_b"].copy_(torch.as_tensor(np.asarray(bias_init_vector, np.float32)).to(self.device))
-        self.global_step = 0
+        self.global_step = 0                     # the step counter the learning-rate staircase and the noise seeds read
+        self.adam_t = 0                          # Adam's count of applied updates (beta*_power); differs after a restore that
+                                                 # matched the optimizer slots but not the counter (XE checkpoint -> REINFORCE run)
         self.sample_seed = seed
         self.dropout_seed = seed + 1
         self.world_size = 1
         self.rank = 0
         import os
         self.dp_overlap = os.environ.get("S2VT_DP_OVERLAP", "0") == "1"
+        self._debug_checks = os.environ.get("S2VT_DEBUG_CHECKS", "0") == "1"
+        self._applied = torch.zeros(1, dtype=torch.int32, device=self.device)   # step number of the last Adam update the device APPLIED
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._gscale = torch.ones(1, dtype=torch.float32, device=self.device)
         self._ascale = torch.ones(1, dtype=torch.float32, device=self.device)
@@ -243,10 +272,13 @@ class Video_Caption_Generator:
         tiling -- LSTM1 and the frame embedding then run once per video; any other [N, ...] block is N videos."""
         K = self.multisample
         if v.shape[0] == N and K > 1 and N % K == 0:
+            # decided from the feed contract alone (build_loss's video placeholder IS the K-times tiled block, :228,:779):
+            # comparing the copies would force a device-to-host sync into every step.  S2VT_DEBUG_CHECKS=1 verifies it.
             B = N // K
             blocks = v.view(K, B, *v.shape[1:])
-            if bool((blocks == blocks[0]).all()):
-                return blocks[0].contiguous(), B
+            if self._debug_checks:
+                assert bool((blocks == blocks[0]).all()), "build_loss feed: rows k*B+j must repeat video j (np.tile of the feature block)"
+            return blocks[0].contiguous(), B
         return v.contiguous(), v.shape[0]
 
     # -------------------------------------------------------------------------------- samplers
@@ -391,9 +423,7 @@ class Video_Caption_Generator:
             pend = getattr(self, "_pending", [])
             pend.append(dp.allreduce_async(st.grad[:lo]))
             pend.append(dp.allreduce_async(st.grad[hi:]))            # includes the tail slot carrying sum(mask)
-            for w in pend:
-                if w is not None:
-                    w.wait()
+            dp.wait_all(pend, st.grad)
             self._pending, self._early = [], None
             gsum = st.grad[st.numel:st.numel + 1]
         else:
@@ -410,8 +440,45 @@ class Video_Caption_Generator:
         if extra_sumsq is not None:
             self._sumsq += extra_sumsq(self._gscale)
         self.global_step += 1
+        self.adam_t += 1
         self._sampler_state = None                 # the variables change: a saved sampler trajectory is stale from here on
-        ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, self._sumsq, clip_norm, lr, self.global_step)
+        ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, self._sumsq, clip_norm, lr, self.adam_t, applied_step=self._applied)
+
+    def set_step(self, global_step: int, adam_t=None):
+        """Position the step counters (a restored checkpoint): the learning-rate / noise-seed counter and Adam's count of
+        applied updates (defaults to the same number)."""
+        self.global_step = int(global_step)
+        self.adam_t = int(global_step if adam_t is None else adam_t)
+        self._applied.fill_(self.adam_t)
+        self._sampler_state = None
+
+    # -------------------------------------------------------------------------------- persistent-recurrence health
+    def check_health(self):
+        """Raise S2VTChainTimeout if a persistent recurrence (csrc/chain.hip) gave up a grid-wide wait since the last
+        recover().  A host-memory read, no device synchronisation: call it wherever the host has just synchronised anyway
+        (after reading the loss / the ids) -- the training drivers do, every step.  Independently of this call, every
+        library entry point that launches a recurrence or updates variables refuses to run while the fault is pending, and
+        Adam launches queued behind the faulting kernel skip their update ON THE DEVICE: the variables are never touched by
+        gradients of a starved recurrence."""
+        if ops.chain_fault():
+            from ._lib import S2VTChainTimeout
+            raise S2VTChainTimeout("a persistent LSTM recurrence timed out (is another process running persistent kernels on this GPU?); "
+                                   "the variables are intact: call recover() and repeat the step")
+
+    def recover(self, disable_persistent=True):
+        """After S2VTChainTimeout: synchronise, learn from the device which update was the last one APPLIED (updates behind
+        the fault were skipped), rewind the host-side step counter to it, acknowledge the fault and (default) switch the
+        recurrences to per-step launches for the rest of the process (same bits, ~5 % slower).  Returns (the step counter
+        the variables are at, the number of updates that were skipped); the caller repeats its work from there."""
+        torch.cuda.synchronize(self.device)
+        applied = int(self._applied.item())
+        ops.chain_ack(disable_persistent)
+        lost = max(0, self.adam_t - applied)
+        self.adam_t -= lost
+        self.global_step -= lost
+        self._sampler_state = None
+        self._pending, self._early = [], None
+        return self.global_step, lost
 
     def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
                          true_labels=None, reuse_sampler_state=False, extra_sumsq=None, reward_fn=None):

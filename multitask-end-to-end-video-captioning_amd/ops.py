@@ -278,10 +278,24 @@ def grad_finalize(g, theta, gscale, weight_decay, sumsq):
           "s2vt_grad_finalize")
 
 
-def adam_tf(theta, g, m, v, sumsq, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_tf(theta, g, m, v, sumsq, clip_norm, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, applied_step=None):
+    """applied_step: optional CUDA int32 tensor [1] that receives `step` when the update is applied (it is skipped on the
+    device while a persistent-recurrence fault is pending, see chain_fault())."""
     _chk_f32(theta, g, m, v, sumsq)
-    check(lib().s2vt_adam_tf(_ptr(theta), _ptr(g), _ptr(m), _ptr(v), theta.numel(), _ptr(sumsq), float(clip_norm), float(lr),
-                             int(step), beta1, beta2, eps, _stream()), "s2vt_adam_tf")
+    if applied_step is not None:
+        assert applied_step.is_cuda and applied_step.dtype == torch.int32
+    check(lib().s2vt_adam_tf_guarded(_ptr(theta), _ptr(g), _ptr(m), _ptr(v), theta.numel(), _ptr(sumsq), float(clip_norm), float(lr),
+                                     int(step), beta1, beta2, eps, _ptr(applied_step), _stream()), "s2vt_adam_tf")
+
+
+def chain_fault() -> bool:
+    """True while a persistent-recurrence timeout is pending (a host-memory read: no synchronisation)."""
+    return bool(lib().s2vt_chain_fault())
+
+
+def chain_ack(disable_persistent: bool = True):
+    """Synchronise the device, clear the fault; disable_persistent: per-step launches for the rest of the process."""
+    check(lib().s2vt_chain_ack(1 if disable_persistent else 0), "s2vt_chain_ack")
 
 
 def prof_enable(on: bool):

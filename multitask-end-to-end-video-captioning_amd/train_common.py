@@ -1,5 +1,8 @@
-"""Pieces shared by the two training drivers (train_xe.py / train_rl.py): configuration, corpus loading,
-the epoch iterator of the reference's train() loops, greedy evaluation, checkpoints."""
+"""Pieces shared by the training drivers (train_xe.py / train_rl.py / train_e2e.py): configuration, corpus loading,
+the epoch iterator of the reference's train() loops, greedy evaluation, checkpoints, and the data-parallel frame:
+one process per GPU under torch.distributed.run, every rank walks the SAME shuffled epoch (same seed) and takes its
+contiguous shard of each global batch (dist.shard_range); noise counters carry global video indices, so n ranks x B/n
+train exactly as one rank x B does."""
 from __future__ import annotations
 
 import os
@@ -9,6 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import data, hostglue, reward
+from . import dist as dp
 
 
 @dataclass
@@ -73,31 +77,120 @@ def epoch_batches(n_items: int, batch_size: int, rng: random.Random):
         yield index[start:end]
 
 
-def greedy_eval(model, corpus: Corpus, ixtoword, scorer: "reward.CiderD | None", batch_size: int):
+class DataParallel:
+    """The data-parallel frame of a training driver.  world == 1 (no WORLD_SIZE in the environment) is the plain
+    single-GPU run of the reference."""
+
+    def __init__(self, device=None):
+        import torch
+        if device is None and not torch.cuda.is_available():
+            raise RuntimeError("the training drivers need a GPU: the HIP library has no CPU fallback")
+        self.rank, self.world, self.device = dp.init_from_env(device)
+
+    @property
+    def chief(self) -> bool:
+        return self.rank == 0
+
+    def per_rank(self, global_batch: int) -> int:
+        assert global_batch % self.world == 0, f"batch_size {global_batch} must divide over {self.world} ranks"
+        return global_batch // self.world
+
+    def shard(self, idx):
+        """This rank's contiguous slice of one global batch and the GLOBAL index of its first video."""
+        lo, hi = dp.shard_range(len(idx), self.rank, self.world)
+        return idx[lo:hi], lo
+
+    def attach(self, model):
+        model.world_size, model.rank = self.world, self.rank
+        return model
+
+    def mean(self, total: float, count: float):
+        """Mean over all ranks of per-rank (sum, count) pairs."""
+        import torch
+        if self.world == 1:
+            return total / count if count else None
+        t = torch.tensor([total, count], dtype=torch.float64, device=self.device)
+        dp.allreduce_small(t)
+        return float(t[0] / t[1]) if float(t[1]) else None
+
+    def gather_dict(self, d: dict) -> dict:
+        if self.world == 1:
+            return d
+        import torch.distributed as dist
+        parts = [None] * self.world
+        dist.all_gather_object(parts, d)
+        out = {}
+        for q in parts:
+            out.update(q)
+        return out
+
+
+def run_step(model, fn, log=print, retries: int = 1):
+    """One training step with the persistent-recurrence guard: fn() runs the step and returns its statistics; the host then
+    reads the loss (the synchronisation point the reference's sess.run is) and checks the library's health.  On
+    S2VTChainTimeout -- a persistent LSTM recurrence was starved of CUs, e.g. by another process on the GPU -- the
+    variables are intact (Adam launches behind the fault skip on the device): recover() rewinds the step counter to the
+    last applied update, switches to per-step launches, and the SAME batch is repeated."""
+    from ._lib import S2VTChainTimeout
+    for attempt in range(retries + 1):
+        try:
+            st = fn()
+            loss = float(st.loss)                      # device -> host: everything queued for this step has run
+            model.check_health()
+            return st, loss
+        except S2VTChainTimeout as e:
+            if attempt == retries:
+                raise
+            step, lost = model.recover()
+            log(f"persistent recurrence timed out ({e}); variables intact at step {step} ({lost} update(s) skipped); "
+                "continuing with per-step launches and repeating the batch")
+    raise AssertionError("unreachable")
+
+
+def greedy_eval(model, corpus: Corpus, ixtoword, scorer: "reward.CiderD | None", batch_size: int, par: "DataParallel | None" = None):
     """Greedy captions for every test video (tf_s2vt.py:508-524) and their mean CIDEr-D against the video's own
     references when a scorer over that corpus is given (the reference reports BLEU/METEOR/ROUGE/CIDEr through
-    the external coco-caption package, which is not part of this build)."""
+    the external coco-caption package, which is not part of this build).  Data parallel: the videos are dealt
+    round-robin over the ranks, captions gathered, the score averaged over all of them."""
     vids = corpus.index.video_ids
-    decoded, scores = {}, []
+    if par is not None and par.world > 1:
+        vids = vids[par.rank::par.world]
+    decoded, total, count = {}, 0.0, 0
     for a in range(0, len(vids), batch_size):
         ids = vids[a:a + batch_size]
         _, g = model.sample(corpus.features.batch(ids), 0, True)
         g = g.cpu().numpy()
+        model.check_health()
         for v, s in zip(ids, hostglue.decode_captions(g, ixtoword)):
             decoded[v] = s
         if scorer is not None:
-            scores.append(scorer.score_ids(g, [corpus.index.row[v] for v in ids]))
-    return decoded, (float(np.concatenate(scores).mean()) if scores else None)
+            sc = scorer.score_ids(g, [corpus.index.row[v] for v in ids])
+            total += float(sc.sum()); count += len(sc)
+    if par is not None and par.world > 1:
+        return par.gather_dict(decoded), (par.mean(total, count) if scorer is not None else None)
+    return decoded, (total / count if count else None)
 
 
-def save_checkpoint(model, cfg: Config, epoch: int):
+def save_checkpoint(model, cfg: Config, epoch: int, step_name: str = "g_step"):
+    """Variables under the reference's TF names plus what its tf.train.Saver keeps beside them when it is created after
+    the optimizer (reinforcement_multisampling_tf_s2vt.py:661): Adam slots, beta powers, the step counter -- a resumed
+    run continues the moments, the bias correction, the learning-rate staircase and the noise streams."""
     os.makedirs(cfg.model_path, exist_ok=True)
     path = os.path.join(cfg.model_path, f"{cfg.model_name}-{epoch}.npz")
-    np.savez(path, **model.store.state_dict())           # keys = the reference's TF variable names
+    np.savez(path, **model.store.state_dict(global_step=model.global_step, adam_t=model.adam_t, step_name=step_name))
     return path
 
 
-def optimistic_restore(model, path):
-    """Load every variable whose name and shape match (reinforcement_multisampling_tf_s2vt.py:47-61)."""
+def optimistic_restore(model, path, restore_step: bool = True, step_names=("global_step", "g_step", "Variable")):
+    """Load every variable whose name and shape match (reinforcement_multisampling_tf_s2vt.py:47-61) -- Adam slots and
+    beta powers included, as there -- and position the model's counters: the step counter when the checkpoint holds one
+    under a name this run's graph would have (`step_names`: a REINFORCE run started from an XE checkpoint passes
+    ('g_step',) and so starts its staircase at 0, as the reference does), Adam's update count from beta1_power."""
     with np.load(path) as z:
-        return model.store.load_state_dict({k: z[k] for k in z.files})
+        sd = {k: z[k] for k in z.files if k in step_names or k not in ("global_step", "g_step", "Variable")}
+    loaded = model.store.load_state_dict(sd)
+    st = model.store
+    if restore_step and (st.restored_step is not None or st.restored_adam_t is not None):
+        step = st.restored_step if st.restored_step is not None else 0
+        model.set_step(step, st.restored_adam_t if st.restored_adam_t is not None else step)
+    return loaded

@@ -17,7 +17,7 @@ import time
 import numpy as np
 
 from . import data, hostglue
-from .train_common import Config, epoch_batches, learning_rate, optimistic_restore, save_checkpoint
+from .train_common import Config, DataParallel, epoch_batches, learning_rate, optimistic_restore, run_step, save_checkpoint
 
 
 def e2e_config(**kw):
@@ -38,11 +38,15 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
           cnn_variables=None, log=print):
     import torch
     from . import e2e, irv2, model as M
+    par = DataParallel(model.device if model is not None else None)      # cfg.batch_size is the GLOBAL batch (16 in the reference)
+    if not par.chief:
+        log = lambda *_: None
     wordtoix, _ = hostglue.preProBuildWordVocab(vocabulary)
     if model is None:
-        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, cfg.batch_size,
+        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, par.per_rank(cfg.batch_size),
                                           cfg.n_video_lstm_step + cfg.n_caption_lstm_step, cfg.n_video_lstm_step,
-                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed)
+                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed, device=par.device)
+    par.attach(model)
     if restore:
         log(f"restored: {optimistic_restore(model, restore)}")
     if cnn is None:
@@ -54,20 +58,24 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
     history = []
     for epoch in range(cfg.n_epochs):
         losses = []
-        for it, idx in enumerate(epoch_batches(len(sents), cfg.batch_size, rng)):
+        for it, gidx in enumerate(epoch_batches(len(sents), cfg.batch_size, rng)):
             if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
                 break
             t0 = time.time()
+            idx, lo = par.shard(gidx)
             vid, sentence = sents[idx, 0], sents[idx, 1].tolist()
-            frames = data.image_reading_processing([video_frames[v] for v in vid], width, height)
+            frames = torch.from_numpy(data.image_reading_processing([video_frames[v] for v in vid], width, height))
             captions_ind, captions_mask = hostglue.sentence_padding_toix(sentence, wordtoix, cfg.n_caption_lstm_step)
-            st = trainer.xe_step(torch.from_numpy(frames), np.asarray(captions_ind, np.int32), captions_mask,
-                                 lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm)
-            losses.append(float(st.loss))
+            st, loss = run_step(model, lambda: trainer.xe_step(frames, np.asarray(captions_ind, np.int32), captions_mask,
+                                                               lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm,
+                                                               video_base=lo), log)
+            losses.append(loss)
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
                 f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")
-        entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None,
-                 "checkpoint": save_checkpoint(model, cfg, epoch), "cnn_checkpoint": save_cnn(trainer, cfg, epoch)}
+        entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None}
+        if par.chief:
+            entry["checkpoint"] = save_checkpoint(model, cfg, epoch, step_name="Variable")
+            entry["cnn_checkpoint"] = save_cnn(trainer, cfg, epoch)
         history.append(entry)
         log(f"Epoch {epoch} is done: {entry}")
     return trainer, history

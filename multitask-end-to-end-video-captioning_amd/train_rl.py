@@ -11,6 +11,8 @@ get_captions scan + evaluate_captions_cider x2 (:787-803| reward.CiderD.score_id
 features tiled x8 on the host (:779-782)                | never tiled: rows address video n % B
 sess.run([train_op, sum_loss]) (:823)                   | model.reinforce_update (forward with dropout, reward-scaled
                                                         |   NLL, BPTT, all-reduce, clip 5, Adam, lr 1e-6 * 0.5^(step//1000))
+single GPU (:21)                                        | one process per GPU: `python -m torch.distributed.run --nproc-per-node N
+                                                        |   -m s2vt_amd.train_rl ...`; batch_size stays the GLOBAL batch
 """
 from __future__ import annotations
 
@@ -21,7 +23,8 @@ import time
 import numpy as np
 
 from . import hostglue, reward
-from .train_common import Config, Corpus, StepLog, epoch_batches, greedy_eval, learning_rate, optimistic_restore, save_checkpoint
+from .train_common import (Config, Corpus, DataParallel, StepLog, epoch_batches, greedy_eval, learning_rate, optimistic_restore,
+                           run_step, save_checkpoint)
 
 
 def rl_config(**kw):
@@ -31,55 +34,73 @@ def rl_config(**kw):
     return Config(**base)
 
 
-def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, restore=None, log=print):
+def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, restore=None, log=print, resume=None):
+    """cfg.batch_size is the GLOBAL batch (the reference's batch_size).  Under torch.distributed.run every rank walks the
+    same shuffled epoch, takes its shard of each batch (videos [lo, hi) of the global batch, global indices in the noise
+    counters), scores its own captions, and the gradient bucket is all-reduced inside reinforce_update; rank 0 logs and
+    writes checkpoints.  restore: variables of an earlier model (optimistic, :667 -- the step counter of an XE checkpoint
+    does not match this script's 'g_step', Adam's slots do); resume: a checkpoint of THIS driver, counters included."""
     import torch
     from . import model as M
+    par = DataParallel(model.device if model is not None else None)
+    if not par.chief:
+        log = lambda *_: None
     wordtoix, ixtoword = hostglue.preProBuildWordVocab(train_corpus.vocabulary)
     K = cfg.multisample
+    B = par.per_rank(cfg.batch_size)
     if model is None:
-        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, cfg.batch_size,
+        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, B,
                                           cfg.n_video_lstm_step + cfg.n_caption_lstm_step, cfg.n_video_lstm_step,
-                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed, multisample=K)
+                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed, multisample=K, device=par.device)
+    par.attach(model)
     if restore:
-        log(f"restored: {optimistic_restore(model, restore)}")
+        log(f"restored: {optimistic_restore(model, restore, step_names=('g_step',))}")
+    if resume:
+        log(f"resumed: {optimistic_restore(model, resume)} at step {model.global_step}")
     scorer = reward.CiderD(train_corpus.index.refs_by_video(), wordtoix)
     test_scorer = reward.CiderD(test_corpus.index.refs_by_video(), wordtoix) if test_corpus is not None else None
     rng = random.Random(cfg.seed)
     caps = train_corpus.captions
     history = []
-    steplog = StepLog(cfg.step_log)
+    steplog = StepLog(cfg.step_log if par.chief else None)
     if test_corpus is not None:
-        log(f"before train: ciderD {greedy_eval(model, test_corpus, ixtoword, test_scorer, cfg.batch_size)[1]}")
+        log(f"before train: ciderD {greedy_eval(model, test_corpus, ixtoword, test_scorer, B, par)[1]}")
     for epoch in range(cfg.n_epochs):
         losses, adv = [], []
-        for it, idx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
+        for it, gidx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
             if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
                 break
             t0 = time.time()
+            idx, lo = par.shard(gidx)
             vid = caps[idx, 0]
             video = model._dev(train_corpus.features.batch(vid), torch.float32)      # one H2D copy, shared by sample + update
-            samples, greedy_words = model.sample(video, K, True, seed=cfg.seed + 7919 * (model.global_step + 1))
-            is_eos = samples == 0
-            mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()        # 1 up to and incl. the first <eos>
             rows = np.asarray([train_corpus.index.row[v] for v in vid], np.int32)
-            s_host, g_host = samples.cpu().numpy(), greedy_words.cpu().numpy()
             rb = {}
 
-            def rewards():                  # runs on the host while the GPU does the teacher-forced forward
-                rb["r"] = scorer.score_ids(s_host, np.tile(rows, K))                     # [K*B], sample-major like the ids
-                rb["b"] = scorer.score_ids(g_host, rows)                                # [B]
-                return rb["r"], hostglue.tile_baseline(rb["b"], K)
-            st = model.reinforce_update(video, samples, mask, None, None, lr=learning_rate(cfg, model.global_step),
-                                        clip_norm=cfg.clip_norm, reuse_sampler_state=True, reward_fn=rewards)
+            def step():
+                samples, greedy_words = model.sample(video, K, True, seed=cfg.seed + 7919 * (model.global_step + 1), video_base=lo)
+                is_eos = samples == 0
+                mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()    # 1 up to and incl. the first <eos>
+                s_host, g_host = samples.cpu().numpy(), greedy_words.cpu().numpy()
+                model.check_health()            # the ids just came to the host: a starved sampler recurrence is caught before it is scored
+
+                def rewards():                  # runs on the host while the GPU does the teacher-forced forward
+                    rb["r"] = scorer.score_ids(s_host, np.tile(rows, K))                 # [K*B], sample-major like the ids
+                    rb["b"] = scorer.score_ids(g_host, rows)                            # [B]
+                    return rb["r"], hostglue.tile_baseline(rb["b"], K)
+                return model.reinforce_update(video, samples, mask, None, None, lr=learning_rate(cfg, model.global_step),
+                                              clip_norm=cfg.clip_norm, video_base=lo, reuse_sampler_state=True, reward_fn=rewards)
+            st, loss = run_step(model, step, log)
             r, b = rb["r"], rb["b"]
-            losses.append(float(st.loss)); adv.append(float(r.mean() - b.mean()))
+            losses.append(loss); adv.append(float(r.mean() - b.mean()))
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} loss: {losses[-1]:.5f} "
                 f"r: {r.mean():.4f} b: {b.mean():.4f} Elapsed time: {time.time() - t0:.3f}")
             steplog.write(kind="step", epoch=epoch, step=model.global_step, lr=learning_rate(cfg, model.global_step), loss=losses[-1], reward=float(r.mean()), baseline=float(b.mean()), seconds=time.time() - t0)
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None, "r_minus_b": float(np.mean(adv)) if adv else None}
         if test_corpus is not None:
-            _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, test_scorer, cfg.batch_size)
-        entry["checkpoint"] = save_checkpoint(model, cfg, epoch)
+            _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, test_scorer, B, par)
+        if par.chief:
+            entry["checkpoint"] = save_checkpoint(model, cfg, epoch, step_name="g_step")
         history.append(entry)
         steplog.write(kind="epoch", **entry)
         log(f"Epoch {epoch} is done: {entry}")
@@ -91,14 +112,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train-sents", required=True); ap.add_argument("--train-feats", required=True)
     ap.add_argument("--test-sents"); ap.add_argument("--test-feats")
-    ap.add_argument("--vocab", required=True); ap.add_argument("--restore")
+    ap.add_argument("--vocab", required=True); ap.add_argument("--restore"); ap.add_argument("--resume")
     ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--samples", type=int, default=8); ap.add_argument("--model-path", default="./new_multisamp_reinforcement_models")
     a = ap.parse_args()
     cfg = rl_config(n_epochs=a.epochs, batch_size=a.batch_size, multisample=a.samples, model_path=a.model_path)
     tr = Corpus(a.train_sents, a.train_feats, vocabulary_file=a.vocab)
     te = Corpus(a.test_sents, a.test_feats, vocabulary=tr.vocabulary) if a.test_sents and a.test_feats else None
-    train(cfg, tr, te, restore=a.restore)
+    train(cfg, tr, te, restore=a.restore, resume=a.resume)
 
 
 if __name__ == "__main__":

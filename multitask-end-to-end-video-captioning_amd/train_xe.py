@@ -14,40 +14,53 @@ import time
 import numpy as np
 
 from . import hostglue, reward
-from .train_common import Config, Corpus, StepLog, epoch_batches, greedy_eval, learning_rate, save_checkpoint
+from .train_common import (Config, Corpus, DataParallel, StepLog, epoch_batches, greedy_eval, learning_rate, optimistic_restore, run_step,
+                           save_checkpoint)
 
 
-def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, log=print):
-    import torch
+def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, log=print, resume=None):
+    """cfg.batch_size is the GLOBAL batch; data parallel as in train_rl.train (shards of each shuffled batch, Q1's per-step
+    mask sums and the gradient bucket all-reduced inside xe_update, rank 0 logs and saves)."""
     from . import model as M
+    par = DataParallel(model.device if model is not None else None)
+    if not par.chief:
+        log = lambda *_: None
     wordtoix, ixtoword = hostglue.preProBuildWordVocab(train_corpus.vocabulary)
+    B = par.per_rank(cfg.batch_size)
     if model is None:
-        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, cfg.batch_size,
+        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, B,
                                           cfg.n_video_lstm_step + cfg.n_caption_lstm_step, cfg.n_video_lstm_step,
-                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed)
+                                          cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed, device=par.device)
+    par.attach(model)
+    if resume:
+        log(f"resumed: {optimistic_restore(model, resume)} at step {model.global_step}")
     scorer = reward.CiderD(test_corpus.index.refs_by_video(), wordtoix) if test_corpus is not None else None
     rng = random.Random(cfg.seed)
     caps = train_corpus.captions
     history = []
-    steplog = StepLog(cfg.step_log)
+    steplog = StepLog(cfg.step_log if par.chief else None)
     for epoch in range(cfg.n_epochs):
         losses = []
-        for it, idx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
+        for it, gidx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
             if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
                 break
             t0 = time.time()
+            idx, lo = par.shard(gidx)
             vid, sentence = caps[idx, 0], caps[idx, 1].tolist()
             captions_ind, captions_mask = hostglue.sentence_padding_toix(sentence, wordtoix, cfg.n_caption_lstm_step)
-            st = model.xe_update(train_corpus.features.batch(vid), np.asarray(captions_ind, np.int32), captions_mask,
-                                 lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm)
-            losses.append(float(st.loss))
+            feats = train_corpus.features.batch(vid)
+            st, loss = run_step(model, lambda: model.xe_update(feats, np.asarray(captions_ind, np.int32), captions_mask,
+                                                               lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm,
+                                                               video_base=lo), log)
+            losses.append(loss)
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
                 f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")
             steplog.write(kind="step", epoch=epoch, step=model.global_step, lr=learning_rate(cfg, model.global_step), loss=losses[-1], seconds=time.time() - t0)
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None}
         if test_corpus is not None:
-            _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, scorer, cfg.batch_size)
-        entry["checkpoint"] = save_checkpoint(model, cfg, epoch)
+            _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, scorer, B, par)
+        if par.chief:
+            entry["checkpoint"] = save_checkpoint(model, cfg, epoch, step_name="Variable")      # tf_s2vt.py:441: the unnamed counter
         history.append(entry)
         steplog.write(kind="epoch", **entry)
         log(f"Epoch {epoch} is done: {entry}")
@@ -59,14 +72,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train-sents", required=True); ap.add_argument("--train-feats", required=True)
     ap.add_argument("--test-sents"); ap.add_argument("--test-feats")
-    ap.add_argument("--vocab", required=True)
+    ap.add_argument("--vocab", required=True); ap.add_argument("--resume")
     ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--model-path", default="./new_s2vt_models")
     a = ap.parse_args()
     cfg = Config(n_epochs=a.epochs, batch_size=a.batch_size, model_path=a.model_path, model_name=f"batch_size{a.batch_size}_s2vt_model")
     tr = Corpus(a.train_sents, a.train_feats, vocabulary_file=a.vocab)
     te = Corpus(a.test_sents, a.test_feats, vocabulary=tr.vocabulary) if a.test_sents and a.test_feats else None
-    train(cfg, tr, te)
+    train(cfg, tr, te, resume=a.resume)
 
 
 if __name__ == "__main__":

@@ -99,3 +99,121 @@ def test_persistent_form_refuses_shapes_it_cannot_hold(gpu):
     W = torch.zeros(4 + 8, 32, device="cuda"); b = torch.zeros(32, device="cuda"); h0 = torch.zeros(385, 8, device="cuda")
     with pytest.raises(RuntimeError, match="bad argument"):
         gpu.lstm_recurrence_fwd(W, 4, b, h0, h0, 2, persistent=1)            # M = 385 rows: more than 6 row tiles per wave
+
+
+# ---- a starved persistent recurrence must never corrupt a training run silently
+CHILD_STARVED = r"""
+import os, sys
+sys.path.insert(0, os.environ["S2VT_ROOT"])
+import numpy as np, torch
+import s2vt_amd
+from s2vt_amd import model as M, hostglue, ops
+from s2vt_amd._lib import S2VTChainTimeout
+from s2vt_amd.train_common import run_step
+mode = sys.argv[1]
+rng = np.random.default_rng(2)
+B, K, Tv, Tc, D, V, E, H = 16, 2, 3, 6, 64, 300, 32, 1000
+video = torch.as_tensor(np.abs(rng.standard_normal((B, Tv, D)) * 0.5).astype(np.float32)).cuda()
+mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, Tv, Tc, seed=3, dropout_rate=0.9)
+theta0 = mdl.store.theta.clone()
+r = (rng.random(K * B) * 2).astype(np.float32); b = np.tile((rng.random(B) * 2).astype(np.float32), K)
+
+def one_step(sync_ids):
+    s, _ = mdl.sample(video, K, True, seed=50 + mdl.global_step)
+    if sync_ids:
+        s.cpu(); mdl.check_health()
+    mask = ((torch.cumsum((s == 0).int(), 1) - (s == 0).int()) == 0).float()
+    return mdl.reinforce_update(video, s, mask, r, b, lr=1e-2, reuse_sampler_state=True), s
+
+if mode == "clean":                 # S2VT_CHAIN=0 in the environment: per-step launches, the reference result
+    st, s = one_step(False); st2, s2 = one_step(False)
+    torch.cuda.synchronize()
+    assert ops.chain_timeouts() == 0 and not ops.chain_fault()
+    np.savez(sys.argv[2], theta=mdl.store.theta.cpu().numpy(), ids=s2.cpu().numpy(), loss=float(st2.loss))
+elif mode == "starved":             # S2VT_CHAIN_SPIN_LIMIT=0: the first grid-wide wait of every persistent launch gives up
+    # (1) nothing synchronises inside the step (bench-like caller): the sampler's recurrence times out on the device, every
+    # later entry point either refuses on the host or -- already queued -- skips on the device; the variables never move
+    try:
+        one_step(False); one_step(False)
+        torch.cuda.synchronize()
+        raised = False
+    except S2VTChainTimeout:
+        raised = True
+    torch.cuda.synchronize()
+    assert ops.chain_timeouts() > 0 and ops.chain_fault()
+    assert torch.equal(mdl.store.theta, theta0), "a starved recurrence reached the variables"
+    try:
+        mdl.sample(video, K, True, seed=1)
+        assert False, "the fault must be sticky"
+    except S2VTChainTimeout:
+        pass
+    try:
+        mdl.check_health(); assert False
+    except S2VTChainTimeout:
+        pass
+    step, lost = mdl.recover()
+    assert step == 0 and mdl.global_step == 0 and mdl.adam_t == 0 and not ops.chain_fault()
+    # (2) the driver's loop (run_step): repeat from the intact variables on per-step launches -> the clean run's result
+    n = ops.chain_timeouts()
+    st, s = one_step(True); st2, s2 = one_step(True)
+    torch.cuda.synchronize()
+    assert ops.chain_timeouts() == n and not ops.chain_fault(), "the persistent form is off after recover()"
+    np.savez(sys.argv[2], theta=mdl.store.theta.cpu().numpy(), ids=s2.cpu().numpy(), loss=float(st2.loss), raised=raised)
+else:                               # "driver": run_step itself catches the fault, recovers and repeats the batch
+    logs = []
+    for i in range(2):
+        st, loss = run_step(mdl, lambda: one_step(True)[0], logs.append)
+    torch.cuda.synchronize()
+    assert len(logs) == 1 and "timed out" in logs[0], logs
+    assert mdl.global_step == 2 and not ops.chain_fault()
+    s2, _ = mdl.sample(video, K, True, seed=50 + 1)       # (ids of step 2 are re-derivable only with the old weights: compare theta)
+    np.savez(sys.argv[2], theta=mdl.store.theta.cpu().numpy(), loss=loss)
+print("child ok", mode)
+"""
+
+
+def test_starved_recurrence_is_an_error_never_wrong_state(gpu, tmp_path):
+    """A persistent recurrence that cannot get all its workgroups resident (another persistent kernel on the GPU) gives up
+    its grid-wide wait.  Forced here with S2VT_CHAIN_SPIN_LIMIT=0.  Required: the variables are never updated from the
+    garbage (Adam launches queued behind the fault skip on the device, later calls refuse on the host with
+    S2VT_E_CHAIN_TIMEOUT), the fault is sticky until recover(), and after recover() the same steps on per-step launches
+    give the result of a run that never used the persistent form."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode, env in (("clean", {"S2VT_CHAIN": "0"}), ("starved", {"S2VT_CHAIN_SPIN_LIMIT": "0"}), ("driver", {"S2VT_CHAIN_SPIN_LIMIT": "0"})):
+        out = str(tmp_path / f"{mode}.npz")
+        e = dict(os.environ, S2VT_ROOT=root, **env)
+        r = subprocess.run([sys.executable, "-c", CHILD_STARVED, mode, out], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "child ok" in r.stdout, f"{mode}: rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+        res[mode] = dict(np.load(out))
+    assert np.array_equal(res["clean"]["ids"], res["starved"]["ids"])                     # token ids: bit-exact, as always
+    for mode in ("starved", "driver"):
+        assert np.abs(res["clean"]["theta"] - res[mode]["theta"]).max() <= 5e-4, mode     # two Adam steps at lr 1e-2, atomic-order noise only
+        assert abs(float(res["clean"]["loss"]) - float(res[mode]["loss"])) <= 1e-3
+
+
+def test_persistent_launch_waits_for_the_previous_one_on_another_stream(gpu):
+    """Two persistent grids of one process must never be in flight together (each needs ~every CU): a launch on a second
+    stream is ordered behind the previous one by the library.  Both results bit-identical to per-step launches, no timeout."""
+    import torch
+    M_, E, H, T = 64, 500, 1000, 25
+    W, b, h0, c0, cinit, vid, sid = _case(M_, E, H, T, 5, seed=5)
+    args = dict(T=T, cinit=_dev(cinit), cinit_steps=5, keep=1.0, seed=7, video_id=_dev(vid), sample_id=_dev(sid), drop_code0=0,
+                want_gates=True, want_out=False)
+    ref = gpu.lstm_recurrence_fwd(_dev(W), E, _dev(b), _dev(h0), _dev(c0), persistent=0, **args)
+    Wd, bd, hd, cd = _dev(W), _dev(b), _dev(h0), _dev(c0)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):                 # (both streams also share ONE scratch buffer: overlapping launches would clobber it)
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(gpu.lstm_recurrence_fwd(Wd, E, bd, hd, cd, persistent=1, **args))
+    torch.cuda.synchronize()
+    assert gpu.chain_timeouts() == 0
+    for got in outs[-2:]:
+        for r, g in zip(ref[:3], got[:3]):
+            assert torch.equal(r, g)

@@ -115,3 +115,30 @@ def test_e2e_two_ranks_equal_one_rank(tmp_path):
     assert all(q.exitcode == 0 for q in ps)
     a, b = np.load(one), np.load(two)
     assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max())
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two ranks ITSELF (the driver's N>1
+    command is torch.distributed.run, but a bare invocation may not silently run one rank) and print a line that proves
+    it: n_gpus 2, the backend, replica drift 0.0, an all-reduce time.  Two ranks share this box's one GPU, so the
+    functional backend is gloo here (rccl_ranks reports 0 for it: not an RCCL run)."""
+    import json
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    nccl = torch.cuda.device_count() >= 2
+    env["S2VT_DIST_BACKEND"] = "nccl" if nccl else "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["parallelism"] == "dp2" and cfg["global_batch"] == 128
+    assert cfg["dist_backend"] == ("nccl" if nccl else "gloo") and cfg["rccl_ranks"] == (2 if nccl else 0)
+    assert cfg["replica_max_abs_diff"] == 0.0
+    assert cfg["allreduce_ms"] > 0.0 and cfg["persistent_recurrence_timeouts"] == 0
+    assert "cpu_baseline" not in out                       # rank 0 at N = 1 only

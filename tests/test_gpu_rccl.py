@@ -116,3 +116,75 @@ def test_one_rank_rccl_process_group_matches_no_dist(gpu, tmp_path):
 
 def test_c_host_allreduce_on_a_one_rank_communicator(gpu):
     _run(CHILD_CABI)
+
+
+# ---- two ranks on two GPUs over RCCL (skipped on a one-GPU box; the driver's 8-GPU node and any >= 2-GPU box run it)
+CHILD_DP2 = r"""
+import os, sys
+sys.path.insert(0, os.environ["S2VT_ROOT"])
+import numpy as np, torch
+import torch.distributed as dist
+world, out = int(sys.argv[1]), sys.argv[2]
+import s2vt_amd
+from s2vt_amd import model as M, hostglue, dist as dp
+rank, w, dev = dp.init_from_env()
+assert w == world
+if world > 1:
+    assert dist.get_backend() == "nccl" and dp.active()
+BG, K = 8, 3
+rng = np.random.default_rng(1)
+video = np.abs(rng.standard_normal((BG, 5, 128)) * 0.5).astype(np.float32)
+cap = rng.integers(0, 260, (K, BG, 8)).astype(np.int32); cap[..., -1] = 0
+r = (rng.random((K, BG)) * 2).astype(np.float32); b = (rng.random(BG) * 2).astype(np.float32)
+gt = rng.integers(0, 260, (BG, 8)).astype(np.int32); gt[:, -2:] = 0
+per = BG // world
+lo, hi = rank * per, (rank + 1) * per
+mdl = M.Video_Caption_Generator(128, 260, 32, 64, per, 0, 5, 8, seed=5, dropout_rate=0.9, device=dev)
+mdl.world_size, mdl.rank = world, rank
+c = cap[:, lo:hi].reshape(K * per, -1)
+mask = hostglue.masks_from_ids(c)
+for it in range(3):
+    mdl.reinforce_update(video[lo:hi], c, mask, r[:, lo:hi].reshape(-1), np.tile(b[lo:hi], K), lr=1e-3, clip_norm=5.0, video_base=lo)
+mdl.xe_update(video[lo:hi], gt[lo:hi], hostglue.masks_from_ids(gt[lo:hi]), lr=1e-3, video_base=lo)
+torch.cuda.synchronize()
+drift = dp.replica_drift(mdl.store.theta)
+assert drift == 0.0, drift
+if rank == 0:
+    np.save(out, mdl.store.theta.cpu().numpy())
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+print("child ok", rank)
+"""
+
+
+def _run_ranks(code, world, out, port, overlap):
+    env = dict(os.environ, S2VT_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               WORLD_SIZE=str(world), S2VT_DP_OVERLAP="1" if overlap else "0")
+    env.pop("S2VT_DP_FORCE", None)
+    env.pop("S2VT_DIST_BACKEND", None)
+    ps = []
+    for rk in range(world):
+        e = dict(env, RANK=str(rk), LOCAL_RANK=str(rk))
+        ps.append(subprocess.Popen([sys.executable, "-c", code, str(world), out], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in ps:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0 and "child ok" in so, f"rc={p.returncode}\n{so[-2000:]}\n{se[-4000:]}"
+
+
+def test_two_rank_nccl_equals_one_rank(gpu, tmp_path):
+    """2 ranks x B/2 on two GPUs over RCCL (one bucket all-reduce, and the overlapped slices) == 1 rank x B, and the two
+    replicas hold bit-identical variables (checksum drift 0.0).  reinforcement_multisampling_tf_s2vt.py:643,650: the global
+    sum(mask) and the clip come after the reduce."""
+    import numpy as np
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    one = str(tmp_path / "one.npy")
+    _run_ranks(CHILD_DP2, 1, one, 29631, False)
+    ref = np.load(one)
+    for i, overlap in enumerate((False, True)):
+        two = str(tmp_path / f"two{i}.npy")
+        _run_ranks(CHILD_DP2, 2, two, 29633 + i, overlap)
+        got = np.load(two)
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) + 2e-4, overlap

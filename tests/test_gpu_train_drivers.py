@@ -86,3 +86,123 @@ def test_e2e_driver_frames_to_checkpoint(tmp_path):
     assert os.path.exists(hist[-1]["checkpoint"]) and os.path.exists(hist[-1]["cnn_checkpoint"])
     g = trainer.generate(torch.from_numpy(data.image_reading_processing([frames["vid0"], frames["vid1"]], 24, 24)))
     assert g.shape == (2, 8)
+
+
+def test_checkpoint_resume_continues_adam_and_counters(tmp_path):
+    """save -> restore into a fresh model -> one step == the uninterrupted run: the checkpoint carries Adam's moments, the
+    bias-correction count, the step counter (learning-rate staircase, dropout / sampling seeds), as the reference's
+    tf.train.Saver does (reinforcement_multisampling_tf_s2vt.py:661)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import s2vt_amd
+    from s2vt_amd import hostglue, model as M, train_common as tc
+    rng = np.random.default_rng(3)
+    video = np.abs(rng.standard_normal((6, 3, 24)) * 0.5).astype(np.float32)
+    cap = rng.integers(2, 40, (6, 8)).astype(np.int32); cap[:, -2:] = 0
+    mask = hostglue.masks_from_ids(cap)
+    cfg = tc.Config(model_path=str(tmp_path / "m"), model_name="ck", decay_steps=2, start_learning_rate=1e-2)
+
+    def make():
+        return M.Video_Caption_Generator(24, 40, 16, 32, 6, 0, 3, 8, seed=11, dropout_rate=0.9)
+
+    def step(m):
+        return m.xe_update(video, cap, mask, lr=tc.learning_rate(cfg, m.global_step), clip_norm=10.0)
+    a = make()
+    for _ in range(3):
+        step(a)
+    b = make()
+    for _ in range(2):
+        step(b)
+    path = tc.save_checkpoint(b, cfg, 0, step_name="Variable")
+    with np.load(path) as z:
+        assert int(z["Variable"]) == 2 and "Wemb/Adam" in z.files and abs(float(z["beta1_power"]) - 0.9 ** 3) < 1e-6
+    c = make()
+    loaded = tc.optimistic_restore(c, path)
+    assert c.global_step == 2 and c.adam_t == 2 and "s2vt/LSTM2/basic_lstm_cell/weights/Adam_1" in loaded
+    step(c)                                                               # lr halves at step 2 (decay_steps = 2): the staircase continued
+    torch.cuda.synchronize()
+    ta, tc_ = a.store.theta.cpu().numpy(), c.store.theta.cpu().numpy()
+    assert np.abs(ta - tc_).max() <= 5e-4                                 # (atomic-order noise of the weight-gradient reductions x Adam)
+    # without the optimizer state the third step lands elsewhere: the test can tell the difference
+    d = make()
+    d.store.load_state_dict({k: v for k, v in b.store.state_dict().items()})
+    step(d)
+    assert np.abs(ta - d.store.theta.cpu().numpy()).max() > 1e-3
+    # a REINFORCE run started from this XE checkpoint: slots + Adam's count restored, the staircase starts at 0 (:637 'g_step')
+    e = make()
+    tc.optimistic_restore(e, path, step_names=("g_step",))
+    assert e.global_step == 0 and e.adam_t == 2
+
+
+CHILD_DP_TRAIN = r"""
+import os, sys
+sys.path.insert(0, os.environ["S2VT_ROOT"])
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.environ["S2VT_ROOT"], "tests"))
+from test_gpu_train_drivers import _corpus
+import s2vt_amd
+from s2vt_amd import train_common as tc, train_rl, train_xe
+tmp, out, which = sys.argv[1], sys.argv[2], sys.argv[3]
+rank = int(os.environ.get("RANK", "0"))
+corpus = tc.Corpus(os.path.join(tmp, "train_sents.txt"), os.path.join(tmp, "train_feat.txt"), vocabulary=eval(open(os.path.join(tmp, "vocab.txt")).read()))
+quiet = lambda *_: None
+if which == "rl":
+    cfg = train_rl.rl_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=1, batch_size=8,
+                             multisample=3, start_learning_rate=1e-2, max_steps_per_epoch=3, model_path=os.path.join(tmp, "m%d" % rank), model_name="rl")
+    model, hist = train_rl.train(cfg, corpus, corpus, log=quiet)
+else:
+    cfg = tc.Config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=1, batch_size=8,
+                    start_learning_rate=1e-2, max_steps_per_epoch=3, model_path=os.path.join(tmp, "m%d" % rank), model_name="xe")
+    model, hist = train_xe.train(cfg, corpus, corpus, log=quiet)
+torch.cuda.synchronize()
+assert model.global_step == 3
+if rank == 0:
+    np.save(out, np.concatenate([model.store.theta.cpu().numpy(), [hist[-1]["ciderD"]]]))
+    assert os.path.exists(hist[-1]["checkpoint"])
+else:
+    assert "checkpoint" not in hist[-1]
+import torch.distributed as dist
+if dist.is_initialized():
+    dist.barrier(); dist.destroy_process_group()
+print("child ok", rank)
+"""
+
+
+@pytest.mark.parametrize("which", ["rl", "xe"])
+def test_data_parallel_drivers_two_ranks_equal_one(tmp_path, which):
+    """train_rl.train / train_xe.train under two ranks (each B/2 of every shuffled global batch, both on this box's one GPU,
+    collective over gloo -- the product's RCCL path differs only in the all_reduce call) for 3 steps end in the variables
+    of one rank x B: same epoch order, global video indices in the sampling / dropout counters, sum(mask) and the clip
+    after the reduce (reinforcement_multisampling_tf_s2vt.py:727-829, :643-650); rank 0 alone writes the checkpoint and
+    the evaluation score is the mean over both ranks' videos."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    sents, feats, vocab = _corpus(tmp_path, "train", rng, n_videos=16)
+    open(tmp_path / "vocab.txt", "w").write(repr(vocab))
+    outs = {}
+    for world in (1, 2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        out = str(tmp_path / f"w{world}.npy")
+        base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        base.update(S2VT_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), S2VT_DIST_BACKEND="gloo")
+        ps = []
+        for rk in range(world):
+            env = dict(base)
+            if world > 1:
+                env.update(RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(world))
+            ps.append(subprocess.Popen([sys.executable, "-c", CHILD_DP_TRAIN, str(tmp_path), out, which], env=env, stdout=subprocess.PIPE,
+                                       stderr=subprocess.PIPE, text=True))
+        for p in ps:
+            so, se = p.communicate(timeout=600)
+            assert p.returncode == 0 and "child ok" in so, f"rc={p.returncode}\n{so[-2000:]}\n{se[-4000:]}"
+        outs[world] = np.load(out)
+    a, b = outs[1], outs[2]
+    assert np.abs(a[:-1] - b[:-1]).max() <= 5e-4, np.abs(a[:-1] - b[:-1]).max()     # 3 Adam steps at lr 1e-2: a wrong exchange moves entries by ~1e-2
+    assert abs(a[-1] - b[-1]) <= 0.05 * max(1.0, abs(a[-1]))                          # CIDEr-D of the greedy captions, averaged over all videos

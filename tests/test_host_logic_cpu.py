@@ -58,7 +58,18 @@ def test_checkpoint_keeps_tf_names_adam_slots_and_step():
     assert int(sd["global_step"]) == 7 and abs(float(sd["beta1_power"]) - 0.9 ** 8) < 1e-7
     b = M.ParamStore(shapes, torch.device("cpu"))
     loaded = b.load_state_dict(sd)
-    assert b.restored_step == 7 and len(loaded) == 3 * len(a.names) + 1
+    assert b.restored_step == 7 and b.restored_adam_t == 7
+    assert len(loaded) == 3 * len(a.names) + 3                          # + global_step, g_step (the REINFORCE script's name), beta1_power
+    # a REINFORCE run started from an XE checkpoint: Adam's slots and beta powers match by name, the unnamed counter
+    # ('Variable', tf_s2vt.py:441) is a different variable from 'g_step' (reinforcement_multisampling_tf_s2vt.py:637)
+    sdx = a.state_dict(global_step=12, adam_t=12, step_name="Variable")
+    assert int(sdx["Variable"]) == 12 and "g_step" not in sdx
+    d = M.ParamStore(shapes, torch.device("cpu"))
+    d.load_state_dict({k: v for k, v in sdx.items() if k not in ("global_step", "Variable")})
+    assert d.restored_step is None and d.restored_adam_t == 12
+    e = M.ParamStore(shapes, torch.device("cpu"))
+    e.load_state_dict({"Variable": np.int64(5)})                         # the reference's own name for the counter is understood
+    assert e.restored_step == 5
     for n in a.names:
         assert torch.equal(a.p[n], b.p[n]) and torch.equal(a._view(a.m, n), b._view(b.m, n)) and torch.equal(a._view(a.v, n), b._view(b.v, n))
     # optimistic_restore: a variable of another shape is skipped, unknown names are ignored, variables-only dumps load too
@@ -67,6 +78,32 @@ def test_checkpoint_keeps_tf_names_adam_slots_and_step():
     c = M.ParamStore(shapes, torch.device("cpu"))
     names = c.load_state_dict(sd2)
     assert "Wemb" not in names and "something/else" not in names and "encode_image_W" in names and c.restored_step is None
+
+
+def test_session_run_evaluates_plain_fetches_before_state_changing_ones():
+    """sess.run([train_op, loss, probs]): in TF all three come from the same pre-update pass.  Here `loss` is a by-product
+    of the train op; `probs` (nobody provides it) must be evaluated BEFORE the update runs."""
+    import s2vt_amd
+    from s2vt_amd import model as M
+    x = M.Placeholder("x", (None,), np.float32)
+    state = {"w": 1.0, "order": []}
+
+    def fwd(v):
+        state["order"].append("fwd")
+        return {"loss": state["w"] * 10.0, "probs": state["w"]}
+
+    def upd(v):
+        state["order"].append("update")
+        l = state["w"] * 10.0
+        state["w"] += 1.0
+        return {"train_op": None, "loss": l}
+    loss, probs = M.Output("loss", fwd, [x]), M.Output("probs", fwd, [x])
+    train_op = M.Output("train_op", upd, [x], provides={loss: "loss"})
+    _, l, p = M.Session(None).run([train_op, loss, probs], {x: 0})
+    assert state["order"] == ["fwd", "update"] and l == 10.0 and p == 1.0       # probs saw w = 1 (pre-update), one forward for it
+    state["order"].clear()
+    _, l = M.Session(None).run([train_op, loss], {x: 0})
+    assert state["order"] == ["update"] and l == 20.0                            # nothing to evaluate early: ONE pass
 
 
 def test_step_log_is_one_json_object_per_line(tmp_path):
