@@ -222,3 +222,56 @@ def test_e2e_real_inception_resnet_v2_step(gpu):
     mdl.global_step = 0
     losses = [float(tr.xe_step(frames, cap, mask, lr=1e-3).loss) for _ in range(4)]
     assert losses[-1] < losses[0] and np.isfinite(losses).all()
+
+
+def test_config4_per_gpu_shape_xe_and_reinforce_steps(gpu):
+    """BASELINE configs[4] at its per-GPU size -- B = 16 (128 over 8 GPUs) x 5 frames x 3 x 299 x 299 through the real
+    Inception-ResNet-v2, d = 1536, E = 500, H = 1000, Tc = 20, |V| = 12000 -- one XE step (e2e_tf_s2vt.py:482-700) and one
+    REINFORCE step (reinforcement_e2e.py:1085-1140).  Seam checks as in test_e2e_real_inception_resnet_v2_step: the
+    captioner's input is the CNN's pooled output under the step's slim.dropout mask, ONE global norm spans both halves, the
+    update moves both halves, the sampler's ids are the captioner's own on those features; no persistent-recurrence fault."""
+    import torch
+    from s2vt_amd import e2e, hostglue, irv2, model as M, ops
+    torch.manual_seed(0)
+    B, TV, TC, D, E, H, V = 16, 5, 20, 1536, 500, 1000, 12000
+    cnn = irv2.InceptionResnetV2()
+    mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, dropout_rate=0.9, seed=3)
+    tr = e2e.EndToEnd(mdl, cnn, seed=5)
+    rng = np.random.default_rng(0)
+    frames = torch.as_tensor(rng.uniform(-1, 1, (B, TV, 3, 299, 299)).astype(np.float32)).cuda()
+    ln = 1 + np.minimum(rng.poisson(6, B), TC - 2)
+    cap = rng.integers(2, V, (B, TC)).astype(np.int32)
+    for j in range(B):
+        cap[j, ln[j]:] = 0
+    mask = hostglue.masks_from_ids(cap)
+    # ---- the seam, forward: features with the step's dropout mask == pooled output x mask / keep, rows zeroed ~10 %
+    feats, _ = tr.extract(frames, dropout=True)
+    clean, _ = tr.extract(frames, dropout=False)
+    assert feats.shape == (B, TV, D) and bool(torch.isfinite(feats).all()) and float(clean.min()) >= 0.0
+    kept = feats != 0
+    assert torch.allclose(feats[kept], (clean / 0.9)[kept], rtol=2e-4, atol=1e-6)
+    assert 0.85 < float(kept.float().mean() / (clean != 0).float().mean()) < 0.95
+    # ---- XE step, lr 0: gradients of both halves, one norm
+    theta_c, theta_s = tr.theta.clone(), mdl.store.theta.clone()
+    st = tr.xe_step(frames, cap, mask, lr=0.0)
+    cap_sq = sum(float((mdl.store.g[n].double() ** 2).sum()) for n in mdl.store.names)
+    cnn_sq = float((tr.grad.double() ** 2).sum())
+    assert cnn_sq > 0 and np.isfinite(cnn_sq) and np.isfinite(float(st.loss))
+    assert abs(float(st.grad_sumsq) - (cap_sq + cnn_sq)) <= 1e-3 * (cap_sq + cnn_sq)
+    assert 8.0 < float(st.loss) < 11.0                        # ~ log(12000) = 9.39 at initialisation
+    # ---- XE step with the reference's learning rate: both halves move, by at most ~lr per entry (Adam)
+    st = tr.xe_step(frames, cap, mask, lr=1e-5)
+    for new, old in ((tr.theta, theta_c), (mdl.store.theta, theta_s)):
+        d = (new - old).abs().max()
+        assert 0 < float(d) <= 2.5e-5
+    # ---- REINFORCE step: sample (dropout on) + greedy (off) through the CNN, PG update through the CNN
+    r = rng.random(B).astype(np.float32); b = rng.random(B).astype(np.float32)
+    theta_c = tr.theta.clone()
+    st = tr.reinforce_step(frames, lambda s_, g_: (r, b), lr=1e-6, K=1, sample_seed=77)
+    assert st.samples.shape == (B, TC) and st.greedy.shape == (B, TC) and np.isfinite(float(st.loss))
+    assert int(st.samples.min()) >= 0 and int(st.samples.max()) < V
+    assert 0 < float((tr.theta - theta_c).abs().max()) <= 2.5e-6
+    torch.cuda.synchronize()
+    assert ops.chain_timeouts() == 0 and not ops.chain_fault()
+    g = tr.generate(frames)                                   # build_generator through the updated network
+    assert g.shape == (B, TC) and int(g.min()) >= 0 and int(g.max()) < V
