@@ -367,6 +367,22 @@ int s2vt_lstm_recurrence_fwd(const float* W, int32_t kw0, const float* b, const 
                              int32_t cinit_steps, float* C_hist, float* H_hist, float* gates, float* out, int32_t M, int32_t H,
                              int32_t T, float keep, uint64_t seed, const int32_t* video_id, const int32_t* sample_id,
                              uint32_t drop_code0, int32_t persistent, void* scratch, size_t scratch_bytes, s2vt_stream stream);
+/* ---- back-propagation through that recurrence (tf.gradients through the unroll, reinforcement_multisampling_tf_s2vt.py:650):
+ * for t = T-1 .. 0:  dh = dext_t (through the DropoutWrapper mask, Philox code drop_code0 + t; dext_t = dext + (t - dext_t0) *
+ * dext_tstride, rows ld_ext apart, for t >= dext_t0; dext NULL = none) + dZ[t+1] @ W[kw0 : kw0 + H, :]^T;  dZ[t] ([T, M, 4H],
+ * pre-activation gradients in the i | j | f | o column order) from dh, the carried cell gradient, gates[t] ([T, M, 4H]
+ * activated, as s2vt_lstm_recurrence_fwd saved them) and C_hist ([T+1, M, H]).  persistent = 1: ONE launch -- workgroup
+ * (unit group, gate) keeps its [H x 16] slice of the recurrent rows in LDS, dz crosses the chip as per-gate images in MFMA
+ * operand order, the four gate partials of a unit group meet through a 4-workgroup exchange, the cell gradient stays in
+ * registers (M <= 256, H % 4 == 0, H <= 1024, 4 * ceil(H / 16) <= the CU count; S2VT_E_BADARG otherwise); 0: per step one
+ * pointwise launch + split-K slabs of the product; -1: persistent when the shape fits and M <= 128.  Results agree to
+ * reduction order (gradients are order-free).  scratch: s2vt_lstm_recurrence_bwd_scratch_bytes(M, H)
+ * bytes, 256-byte aligned. */
+size_t s2vt_lstm_recurrence_bwd_scratch_bytes(int32_t M, int32_t H);
+int s2vt_lstm_recurrence_bwd(const float* W, int32_t kw0, const float* gates, const float* C_hist, const float* dext, int64_t dext_tstride,
+                             int32_t ld_ext, int32_t dext_t0, float* dZ, int32_t M, int32_t H, int32_t T, float keep, uint64_t seed,
+                             const int32_t* video_id, const int32_t* sample_id, uint32_t drop_code0, int32_t persistent, void* scratch,
+                             size_t scratch_bytes, s2vt_stream stream);
 /* Grid-wide waits of the persistent recurrence that gave up (bounded spins), over all launches of this process; 0 =
  * healthy.  Read after synchronising the stream. */
 int s2vt_chain_timeouts(void);

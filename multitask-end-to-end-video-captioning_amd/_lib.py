@@ -104,6 +104,9 @@ SIGNATURES = {
     "s2vt_lstm_recurrence_scratch_bytes": (_sz, [_i32]),
     "s2vt_lstm_recurrence_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _u64, _vp, _vp,
                                            _u32, _i32, _vp, _sz, _vp]),
+    "s2vt_lstm_recurrence_bwd_scratch_bytes": (_sz, [_i32, _i32]),
+    "s2vt_lstm_recurrence_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _u64, _vp, _vp, _u32, _i32,
+                                           _vp, _sz, _vp]),
     "s2vt_chain_timeouts": (C.c_int, []),
     "s2vt_chain_fault": (C.c_int, []),
     "s2vt_chain_ack": (C.c_int, [C.c_int]),

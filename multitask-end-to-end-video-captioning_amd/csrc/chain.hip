@@ -33,6 +33,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "detmath.h"
@@ -55,6 +56,12 @@ __device__ __forceinline__ f32x4 bload16_sc1(__amdgpu_buffer_rsrc_t rsrc, int vo
     return __builtin_bit_cast(f32x4, v);
 }
 
+// 16-byte write-through store (sc1: the bytes leave this XCD's L2 -- the store form of the hand-off)
+__device__ __forceinline__ void bstore16_sc1(__amdgpu_buffer_rsrc_t rsrc, u32x4v v, int voff, int soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, 16);                    // aux 16 = sc1
+}
+
 constexpr int kShards = 8;             // counter shards, one 128-byte line each; word kShards * 32 = timeout flag
 constexpr unsigned kSpinLimitDefault = 1u << 21;   // polls (each >= ~0.3 us: s_sleep + an L2 round trip) before a wait gives up: ~1-2 s
 
@@ -68,8 +75,38 @@ struct GridSync {
     unsigned* status;
     unsigned* fault;
     unsigned spin_limit;
-    int nwg;
+    int nwg;                               // arrivers per step = mult x (nwg units dealt round-robin over the shards by id & 7)
     bool dead;
+    unsigned mult = 1u;
+    __device__ __forceinline__ void raise(int lane)
+    {
+        if (lane == 0) {
+            __hip_atomic_store(sync + kShards * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fault) __hip_atomic_store((gu32*)fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-resident: later update kernels skip
+            if (status) __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible
+        }
+        dead = true;
+    }
+    // one counter, `expected` arrivals (a small group of workgroups handing tiles to each other)
+    __device__ __forceinline__ void arrive_one(gu32* counter, int tid)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void wait_one(gu32* counter, unsigned expected, int pwave, int lane)
+    {
+        if (pwave == 0 && !dead) {
+            unsigned spins = 0;
+            for (;;) {
+                const unsigned v = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= expected) break;
+                if (++spins > spin_limit) { raise(lane); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
     __device__ __forceinline__ void arrive(int tid)
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -79,20 +116,12 @@ struct GridSync {
     __device__ __forceinline__ void wait_all(unsigned arrival, int pwave, int lane)
     {
         if (pwave == 0 && !dead) {
-            const unsigned mine = lane < kShards ? (unsigned)((nwg + kShards - 1 - lane) / kShards) * (arrival + 1u) : 0u;
+            const unsigned mine = lane < kShards ? mult * (unsigned)((nwg + kShards - 1 - lane) / kShards) * (arrival + 1u) : 0u;
             unsigned spins = 0;
             for (;;) {
                 const unsigned v = lane < kShards ? __hip_atomic_load(sync + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
                 if (__all(lane >= kShards || v >= mine)) break;
-                if (++spins > spin_limit) {                    // never hang: flag it and go on (results are then garbage; the fault words say so)
-                    if (lane == 0) {
-                        __hip_atomic_store(sync + kShards * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (fault) __hip_atomic_store((gu32*)fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-resident: later update kernels skip
-                        if (status) __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-visible
-                    }
-                    dead = true;
-                    break;
-                }
+                if (++spins > spin_limit) { raise(lane); break; }   // never hang: flag it and go on (results are then garbage; the fault words say so)
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -327,6 +356,234 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The BACKWARD recurrence of a BasicLSTMCell (back-propagation through the unroll of tf_s2vt.py:113-153; tf.gradients,
+// reinforcement_multisampling_tf_s2vt.py:650) in one launch.  Step t (T-1 down to 0), per row m and unit u:
+//     dh = dext_t[m,u] (through the DropoutWrapper mask) + sum_{g,k} dz_{t+1}[m, gH + k] * Whh[u, gH + k]
+//     dz_t[m, gH + u] = pointwise(dh, dc, gates_t, c_t, c_{t-1});   dc <- dc_t * sf
+// Per-step launches spent ~25 us on this at M = 64 whatever M is (a 7 us pointwise launch + 4-16 split-K slabs of a skinny
+// product at 17-36 % of the matrix peak, dz and the slabs through HBM).  Here, as in the forward kernel above, nothing but
+// the per-step operands moves:
+//   * workgroup (j, g) owns 16 hidden units (output columns) and ONE gate's quarter of the reduction: its [H x 16] slice
+//     Whh[16j .. 16j+15, gH .. gH+H) (64 KB) is gathered into LDS once, in MFMA B-fragment order;
+//   * dz_{t+1} crosses the chip as four per-gate images in A-fragment order (write-through 16-byte stores, sc1 loads
+//     straight into a register ring): a CU streams M*H*4 bytes per step, what the forward streams;
+//   * the four gate partials of a unit group meet through a 4 KB-per-workgroup exchange among the FOUR workgroups (j, 0..3)
+//     (same blockIdx % 8: one XCD under round-robin placement -- speed only): a cluster counter, not a grid-wide wait;
+//     workgroup (j, g) then finishes row tiles g*TMW .. of its 16 units: one (row, unit) per thread, dc stays in a register
+//     for all T steps, the next step's gates / states / upstream gradient are already in registers (prefetched under the MFMAs);
+//   * ONE grid-wide hand-off per step (dz_t images), the form of the forward kernel.
+// The reduction is order-free (gradients; compared with float64 autograd within tolerance): two accumulators
+// per tile break the dependent MFMA chain, the gate partials are summed in gate order.
+struct BwdChainArgs {
+    const float* W; int ldw; int kw0;                  // cell matrix [*, 4H]; Whh[u][c] = W[(kw0 + u) * ldw + c]
+    const float* gates; size_t gates_tstride;          // activated gates [T][M][4H] (si | tj | sf | so) of the forward pass
+    const float* C; size_t state_tstride;              // cell states [T+1][M][H]: c_{t-1} = slot t, c_t = slot t + 1
+    const float* dext; size_t dext_tstride; int ld_ext; int dext_t0;   // d loss / d out_t for t >= dext_t0 at dext + (t - dext_t0) * tstride (rows ld_ext apart); NULL = none
+    float* dZ; size_t dz_tstride;                      // [T][M][4H] pre-activation gradients (what the weight-gradient contractions read)
+    int M, H, T;
+    float keep; uint32_t seed_lo, seed_hi, drop_code0; // DropoutWrapper of `out`: code = drop_code0 + t
+    const int32_t* video_id; const int32_t* sample_id;
+    float* img;                                        // 2 x 4 gate images of dz in A-fragment order
+    float* ex;                                         // [unit groups][4 gates][row tiles][256] partial tiles
+    unsigned* sync;                                    // grid counters (kChainSyncBytes) then one 128-byte line per unit group
+    unsigned* status; unsigned* fault; unsigned spin_limit;
+    int ncg;                                           // unit groups = ceil(H / 16)
+};
+
+template <int NG, int TMW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_chain_kernel(const BwdChainArgs g)
+{
+    constexpr int ZS = 20;
+    constexpr int NT = 4 * TMW;                                // row tiles of an image
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                          // [NG][64 lanes][4]: B fragments of this workgroup's slice
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* zb = smem + NG * 256 + pwave * (16 * ZS);           // per-wave transpose tile
+    float* dzl = smem + NG * 256 + 4 * 16 * ZS;                // [4 gates][16 rows][17]: dz of one finished row tile, regrouped for the image stores
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int H = g.H, M = g.M, T = g.T;
+    // workgroup id -> (unit group, gate): the four gates of a unit group share blockIdx % 8
+    const int wg = (int)blockIdx.x;
+    const int jj = (wg >> 5) * 8 + (wg & 7), gate = (wg >> 3) & 3;
+    if (jj >= g.ncg) return;                                   // (grid padded to whole groups of 8: these never take part)
+    const int u0 = jj * 16;
+    const size_t img_floats = (size_t)NT * NG * 256;           // one gate image
+
+    // ---- this workgroup's slice of Whh -> LDS, once.  B[k][n] = Whh[u0 + n][gate * H + k]; element (k, n) goes to group
+    // k / 16, lane (k % 4) * 16 + n, component (k % 16) / 4.
+    for (int idx = tid; idx < 16 * NG * 4; idx += 256) {
+        const int k4 = idx % (NG * 4), n = idx / (NG * 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (u0 + n < H && 4 * k4 < H) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)(g.kw0 + u0 + n) * g.ldw + (size_t)gate * H + 4 * k4);
+        const int grp = k4 >> 2, e = k4 & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Wl[((grp * 64 + i * 16 + n) << 2) + e] = v[i];
+    }
+
+    // ---- the (row, unit) this thread finishes at every step, per row tile gate * TMW + i
+    const int pr = tid >> 4, pn = tid & 15;                    // row within the tile, unit within the group
+    const int pu = u0 + pn;
+    float dc_reg[TMW], cnew[TMW];
+    uint32_t vid[TMW], sid[TMW];
+    bool pok[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        const int m = (gate * TMW + i) * 16 + pr;
+        pok[i] = m < M && pu < H;
+        dc_reg[i] = 0.0f;
+        cnew[i] = pok[i] ? g.C[(size_t)T * g.state_tstride + (size_t)m * H + pu] : 0.0f;      // c_{T-1}
+        vid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.video_id[m] : 0u;
+        sid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.sample_id[m] : 0u;
+    }
+    gu32* const ccount = (gu32*)g.sync + (kChainSyncBytes / 4) + jj * 32;
+    const __amdgpu_buffer_rsrc_t rsEx = __builtin_amdgcn_make_buffer_rsrc(g.ex, 0, g.ncg * 4 * NT * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(g.img, 0, (int)(8 * img_floats * 4), 0x00020000);
+    GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, g.ncg, false, 4u};
+    bool wok[TMW];                                             // MFMA side: row tile pwave * TMW + i holds rows of the problem
+    int voff[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        wok[i] = (pwave * TMW + i) * 16 < M;
+        voff[i] = wok[i] ? lane * 16 : (int)0x80000000u;
+    }
+    __syncthreads();
+
+    float sg[TMW][4], cprev[TMW], dx[TMW];
+    auto load_step = [&](int t) __attribute__((always_inline)) {                // operands of step t's pointwise part (independent of the recurrence)
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            const int m = (gate * TMW + i) * 16 + pr;
+            const float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)m * 4 * H + pu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sg[i][q] = pok[i] ? gp[(size_t)q * H] : 0.0f;
+            cprev[i] = pok[i] ? g.C[(size_t)t * g.state_tstride + (size_t)m * H + pu] : 0.0f;
+            dx[i] = (pok[i] && g.dext && t >= g.dext_t0) ? g.dext[(size_t)(t - g.dext_t0) * g.dext_tstride + (size_t)m * g.ld_ext + pu] : 0.0f;
+        }
+    };
+    load_step(T - 1);
+
+    unsigned arrival = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        float dh[TMW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) dh[i] = 0.0f;
+        if (t < T - 1) {
+            // ---- dz_{t+1}[:, gate block] @ slice^T for this wave's row tiles: A fragments straight into registers
+            gs.wait_all(arrival, pwave, lane);
+            const float* acur = g.img + (size_t)((t + 1) & 1) * 4 * img_floats + (size_t)gate * img_floats;
+            const __amdgpu_buffer_rsrc_t rsA =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)pwave * TMW * NG * 256), 0, TMW * NG * 1024, 0x00020000);
+            constexpr int RING0 = TMW == 1 ? 32 : 40 / TMW;
+            constexpr int RING = NG < RING0 ? NG : RING0;
+            f32x4 a[RING][TMW];
+            f32x4 acc[2][TMW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) { acc[0][i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            static_for<0, RING>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j][i] = bload16_sc1(rsA, voff[i], (i * NG + j) * 1024); });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4* bl = reinterpret_cast<const f32x4*>(Wl) + lane;
+            constexpr int PB = NG < 4 ? NG : 4;
+            f32x4 b[PB];
+            static_for<0, PB>([&](auto j_) { constexpr int j = decltype(j_)::value; b[j] = bl[j * 64]; });
+            static_for<0, NG>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                const f32x4 bj4 = b[j % PB];
+                if constexpr (j + PB < NG) b[j % PB] = bl[(j + PB) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    static_for<0, TMW>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        acc[e & 1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][i][e], bj4[e], acc[e & 1][i], 0, 0, 0);
+                    });
+                });
+                if constexpr (j + RING < NG) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j % RING][i] = bload16_sc1(rsA, voff[i], (i * NG + j + RING) * 1024); });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            // ---- partial tiles -> the unit group's exchange (row-major 16 x 16, one write-through 16-byte store per lane)
+            float* exw = g.ex + ((size_t)(jj * 4 + gate) * NT + (size_t)pwave * TMW) * 256;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[0][i][r] + acc[1][i][r];
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 row = *reinterpret_cast<const f32x4*>(zb + (lane >> 2) * ZS + (lane & 3) * 4);
+                __builtin_amdgcn_wave_barrier();
+                const u32x4v bits = __builtin_bit_cast(u32x4v, row);
+                bstore16_sc1(rsEx, bits, (int)(((size_t)(exw - g.ex) + (size_t)i * 256 + lane * 4) * 4), 0);
+            }
+            gs.arrive_one(ccount, tid);
+            gs.wait_one(ccount, 4u * (arrival + 1u), pwave, lane);
+            ++arrival;
+            const float* exr = g.ex + ((size_t)jj * 4 * NT + (size_t)gate * TMW) * 256;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                float s = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    s += __uint_as_float(__hip_atomic_load((const gu32*)(exr + ((size_t)q * NT + i) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                dh[i] = s;
+            }
+        }
+        // ---- BasicLSTMCell backward pointwise (the expressions of lstm_bwd_pointwise_kernel), one (row, unit) per thread
+        float dzv[TMW][4];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            float d = dx[i];
+            if (g.keep < 1.0f && g.dext && t >= g.dext_t0)
+                d = (d / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)pu, g.keep);
+            const float dht = dh[i] + d;
+            const float si = sg[i][0], tj = sg[i][1], sf = sg[i][2], so = sg[i][3];
+            const float tc = dm_tanhf(cnew[i]);
+            const float dc = dht * so * (1.f - tc * tc) + dc_reg[i];
+            dzv[i][0] = dc * tj * si * (1.f - si);
+            dzv[i][1] = dc * si * (1.f - tj * tj);
+            dzv[i][2] = dc * cprev[i] * sf * (1.f - sf);
+            dzv[i][3] = dht * tc * so * (1.f - so);
+            dc_reg[i] = dc * sf;
+            cnew[i] = cprev[i];                                  // c_{t-1} is the next step's c_t
+        }
+        if (t > 0) {
+            // ---- dz_t -> the four gate images of the other parity, regrouped through LDS so that every thread writes ONE
+            // 16-byte fragment slot: thread (gate q = tid / 64, slot L = tid % 64) takes row L % 16, units L / 16 + 4e
+            float* inext = g.img + (size_t)(t & 1) * 4 * img_floats;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dzl[(q * 16 + pr) * 17 + pn] = pok[i] ? dzv[i][q] : 0.0f;
+                __syncthreads();
+                const int q = tid >> 6, L = tid & 63, r = L & 15, kq = L >> 4;
+                u32x4v w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(dzl[(q * 16 + r) * 17 + kq + 4 * e]);
+                float* dst = inext + (size_t)q * img_floats + ((size_t)((gate * TMW + i) * NG + jj) * 64 + L) * 4;
+                bstore16_sc1(rsImg, w, (int)((size_t)(dst - g.img) * 4), 0);
+            }
+            gs.arrive(tid);
+        }
+        // ---- history: dZ[t] (read by the weight-gradient contractions after the launch), then the next step's operands
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            if (!pok[i]) continue;
+            const int m = (gate * TMW + i) * 16 + pr;
+            float* zp = g.dZ + (size_t)t * g.dz_tstride + (size_t)m * 4 * H + pu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zp[(size_t)q * H] = dzv[i][q];
+        }
+        if (t > 0) load_step(t - 1);
+    }
+}
+
 typedef void (*ChainFn)(const ChainArgs);
 struct ChainCfg { int ng, tmw, nc; ChainFn fn; const char* name; };
 constexpr int kMaxTmw = 6;                                     // 6 row tiles per wave x 4 waves x 16 rows = 384 rows
@@ -416,6 +673,46 @@ DevState* dev_state()
         void* f = nullptr;
         if (ok && hipMalloc(&f, 256) == hipSuccess && hipMemset(f, 0, 256) == hipSuccess) d.fault = static_cast<unsigned*>(f);
         d.num_cus = (ok && d.fault) ? cus : 0;                // an LDS request refused / no status word: the per-step path serves
+    });
+    return &d;
+}
+
+
+// ---- backward recurrence: configurations, eligibility, launcher
+typedef void (*BwdFn)(const BwdChainArgs);
+struct BwdCfg { int ng, tmw; BwdFn fn; const char* name; };
+const BwdCfg kBwd[] = {
+    {8, 1, lstm_bwd_chain_kernel<8, 1>, "bchain(ng8,m64)"},    {8, 2, lstm_bwd_chain_kernel<8, 2>, "bchain(ng8,m128)"},
+    {8, 4, lstm_bwd_chain_kernel<8, 4>, "bchain(ng8,m256)"},   {64, 1, lstm_bwd_chain_kernel<64, 1>, "bchain(ng64,m64)"},
+    {64, 2, lstm_bwd_chain_kernel<64, 2>, "bchain(ng64,m128)"}, {64, 4, lstm_bwd_chain_kernel<64, 4>, "bchain(ng64,m256)"},
+};
+constexpr int kNumBwd = (int)(sizeof(kBwd) / sizeof(kBwd[0]));
+int bwd_lds_bytes(const BwdCfg& c) { return (c.ng * 256 + 4 * 16 * 20 + 4 * 16 * 17) * 4; }
+int bwd_cfg(int M, int H)
+{
+    const int ng = (H + 15) / 16 <= 8 ? 8 : 64;
+    const int tmw = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
+    for (int i = 0; i < kNumBwd; ++i)
+        if (kBwd[i].ng == ng && kBwd[i].tmw == tmw) return i;
+    return -1;
+}
+struct BwdDev { std::once_flag once; bool ok = false; int per_cu[kNumBwd] = {}; };
+BwdDev g_bdev[kMaxDev];
+BwdDev* bwd_dev_state()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    BwdDev& d = g_bdev[dev];
+    std::call_once(d.once, [&d] {
+        bool ok = true;
+        for (int i = 0; ok && i < kNumBwd; ++i) {
+            const BwdCfg& c = kBwd[i];
+            ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(c)) == hipSuccess;
+            int n = 0;
+            if (ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(c.fn), 256, bwd_lds_bytes(c)) == hipSuccess)
+                d.per_cu[i] = n;
+        }
+        d.ok = ok;
     });
     return &d;
 }
@@ -515,6 +812,99 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
 bool chain_operands_ok(const float* W, int ldw, const float* abuf)
 {
     return !(reinterpret_cast<uintptr_t>(W) & 15) && !(ldw & 3) && !(reinterpret_cast<uintptr_t>(abuf) & 15);
+}
+
+
+constexpr int kBwdMaxRows = 256;
+
+bool bwd_chain_eligible(int M, int H)
+{
+    static const bool off = [] { const char* e = getenv("S2VT_BCHAIN"); return e && e[0] == '0'; }();      // dev knob: per-step launches
+    if (off || g_disabled.load(std::memory_order_relaxed)) return false;
+    DevState* d = dev_state();
+    BwdDev* b = bwd_dev_state();
+    if (!d || d->num_cus <= 0 || !b || !b->ok) return false;
+    if (!(M >= 1 && M <= kBwdMaxRows && H >= 4 && (H & 3) == 0 && H <= 1024)) return false;
+    const int ci = bwd_cfg(M, H);
+    if (ci < 0) return false;
+    const int ncg = (H + 15) / 16;
+    return (long)b->per_cu[ci] * d->num_cus >= 4L * ncg;        // every ACTIVE workgroup fits on the chip at once
+}
+
+bool bwd_chain_auto(int M, int H)
+{
+    static const int maxm = [] { const char* e = getenv("S2VT_BCHAIN_MAXM"); return e ? atoi(e) : 128; }();  // rows up to which the persistent form is chosen unasked
+    return M <= maxm && bwd_chain_eligible(M, H);
+}
+
+void bwd_chain_scratch(int H, int M, size_t* img_floats, size_t* ex_floats, size_t* sync_bytes)
+{
+    const int ng = (H + 15) / 16 <= 8 ? 8 : 64;
+    const int tmw = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
+    const int ncg = (H + 15) / 16;
+    *img_floats = (size_t)8 * 4 * tmw * ng * 256;
+    *ex_floats = (size_t)ncg * 4 * 4 * tmw * 256;
+    *sync_bytes = kChainSyncBytes + (size_t)ncg * 128;
+}
+
+hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
+{
+    if (!bwd_chain_eligible(a.M, a.H)) return hipErrorInvalidValue;
+    if (a.T <= 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(a.W) & 15) || (a.ldw & 3) || (reinterpret_cast<uintptr_t>(a.img) & 15) || (reinterpret_cast<uintptr_t>(a.ex) & 15))
+        return hipErrorInvalidValue;
+    DevState* d = dev_state();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int ci = bwd_cfg(a.M, a.H);
+    const BwdCfg& c = kBwd[ci];
+    BwdChainArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.W = a.W; k.ldw = a.ldw; k.kw0 = a.kw0;
+    k.gates = a.gates; k.gates_tstride = a.gates_tstride; k.C = a.C; k.state_tstride = a.state_tstride;
+    k.dext = a.dext; k.dext_tstride = a.dext_tstride; k.ld_ext = a.ld_ext; k.dext_t0 = a.dext_t0;
+    k.dZ = a.dZ; k.dz_tstride = a.dz_tstride; k.M = a.M; k.H = a.H; k.T = a.T;
+    k.keep = a.keep; k.seed_lo = a.seed_lo; k.seed_hi = a.seed_hi; k.drop_code0 = a.drop_code0;
+    k.video_id = a.video_id; k.sample_id = a.sample_id;
+    k.img = a.img; k.ex = a.ex; k.sync = a.sync;
+    k.status = g_status_dev; k.fault = d->fault; k.spin_limit = spin_limit();
+    k.ncg = (a.H + 15) / 16;
+    size_t imgf, exf, syncb;
+    bwd_chain_scratch(a.H, a.M, &imgf, &exf, &syncb);
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    if (g_last_done && (g_last_stream != st || g_last_device != dev)) {
+        hipError_t we = hipStreamWaitEvent(st, g_last_done, 0);
+        if (we != hipSuccess) return we;
+    }
+    hipError_t e = hipMemsetAsync(a.sync, 0, syncb, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.img, 0, imgf * 4, st);                // rows >= M and k >= H of the images must read as zeros
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((k.ncg + 7) / 8 * 32));
+    const double flops = 2.0 * a.M * (double)a.H * 4.0 * a.H * (a.T - 1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = prof_wants(6, ci);
+    if (prof) {
+        hipError_t pe = prof_events(&e0, &e1);
+        if (pe != hipSuccess) return pe;
+        (void)hipEventRecord(e0, st);
+    }
+    hipLaunchKernelGGL(c.fn, grid, dim3(256), bwd_lds_bytes(c), st, k);
+    if (prof) {
+        (void)hipEventRecord(e1, st);
+        prof_record(6, ci, c.name, flops, e0, e1);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (!g_last_done || g_last_device != dev) {
+        if (g_last_done) (void)hipEventDestroy(g_last_done);
+        g_last_done = nullptr;
+        hipError_t ce = hipEventCreateWithFlags(&g_last_done, hipEventDisableTiming);
+        if (ce != hipSuccess) return ce;
+    }
+    g_last_stream = st;
+    g_last_device = dev;
+    return hipEventRecord(g_last_done, st);
 }
 
 unsigned chain_timeouts() { return g_status_host ? *static_cast<volatile unsigned*>(g_status_host) : 0u; }

@@ -95,6 +95,23 @@ bool chain_fault();                                    // a timeout has happened
 const unsigned* chain_fault_word();                    // device word of the current device (1 = fault), NULL when the persistent form is unavailable
 hipError_t chain_ack(bool disable);                    // acknowledge (device idle!); disable: per-step launches for the rest of the process
 
+// ---- the backward recurrence of one cell in one persistent launch (chain.hip): dZ[t] for t = T-1 .. 0
+struct BwdChainLaunch {
+    const float* W; int ldw; int kw0;                  // cell matrix [*, 4H]; the recurrent rows start at kw0
+    const float* gates; size_t gates_tstride;          // activated gates [T][M][4H]
+    const float* C; size_t state_tstride;              // cell states [T+1][M][H]
+    const float* dext; size_t dext_tstride; int ld_ext; int dext_t0;   // upstream gradient w.r.t. the (dropped) output of step t >= dext_t0; NULL = none
+    float* dZ; size_t dz_tstride;                      // [T][M][4H]
+    int M, H, T;
+    float keep; uint32_t seed_lo, seed_hi, drop_code0;
+    const int32_t* video_id; const int32_t* sample_id;
+    float* img; float* ex; unsigned* sync;             // scratch, sizes from bwd_chain_scratch (16-byte aligned)
+};
+bool bwd_chain_eligible(int M, int H);               // the shape fits the persistent form on this device
+bool bwd_chain_auto(int M, int H);                   // ... and it is the faster form there (chosen when the caller does not say)
+void bwd_chain_scratch(int H, int M, size_t* img_floats, size_t* ex_floats, size_t* sync_bytes);
+hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st);
+
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.
 struct NnBwdArgs {

@@ -32,6 +32,8 @@ struct TrainWs {
     int32_t* decidx;     // inverse of encidx: row of dX1 (time-major) for row j*Tv + t of d_video
     float* chain_abuf;   // persistent-recurrence scratch (chain.hip)
     unsigned* chain_sync;
+    float *bimg, *bex;   // persistent BACKWARD recurrence scratch (chain.hip): dz images, partial-tile exchange
+    unsigned* bsync;
 };
 
 // Split-K plan of the recurrent data-gradient product dz[M,4H] @ Whh^T[4H,H] (order-free): enough K slabs
@@ -74,6 +76,11 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.decidx = c.take<int32_t>(Tv * b);
     w.chain_sync = c.take<unsigned>(kChainSyncBytes / 4);
     w.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
+    {
+        size_t imgf, exf, syncb;
+        bwd_chain_scratch((int)H, N < 256 ? N : 256, &imgf, &exf, &syncb);       // (sized for the larger of the two recurrences: N >= B rows)
+        w.bimg = c.take<float>(imgf); w.bex = c.take<float>(exf); w.bsync = c.take<unsigned>(syncb / 4);
+    }
     if (out) *out = w;
     return c.off;
 }
@@ -136,9 +143,80 @@ hipError_t nn_bwd(const float* A, int lda, const float* Wt, int ldw, float* C, i
     return launch_gemm(a, EPI_STORE_NT, splits > 1 ? cfg_ : -1, st);
 }
 
+// Back-propagation through one cell's unroll: dZ[t] for t = T-1 .. 0.  ONE persistent launch when the shape fits
+// (bwd_chain_eligible: M <= 128 rows by default), else per step {pointwise, split-K slabs of dz @ Whh^T summed by the next
+// pointwise launch}.  dext: upstream gradient w.r.t. the (dropped) output of step t >= dext_t0.
+struct BwdScratch { float* slab; float* dc; float* bimg; float* bex; unsigned* bsync; };
+hipError_t lstm_recurrence_bwd(const float* W, int kw0, const float* gates, const float* C, const float* dext, size_t dext_tstride,
+                               int ld_ext, int dext_t0, float* dZ, int M, int H, int T, float keep, uint64_t seed, uint32_t drop_code0,
+                               const int32_t* video_id, const int32_t* sample_id, const BwdScratch& sc, int persistent, hipStream_t st)
+{
+    const size_t MH = (size_t)M * H;
+    const bool can = sc.bimg && sc.bex && sc.bsync && bwd_chain_eligible(M, H) && !(reinterpret_cast<uintptr_t>(W) & 15);
+    if (persistent == 1 && !can) return hipErrorInvalidValue;
+    if (persistent == 1 || (persistent == -1 && can && bwd_chain_auto(M, H))) {
+        BwdChainLaunch a;
+        std::memset(&a, 0, sizeof(a));
+        a.W = W; a.ldw = 4 * H; a.kw0 = kw0; a.gates = gates; a.gates_tstride = 4 * MH; a.C = C; a.state_tstride = MH;
+        a.dext = dext; a.dext_tstride = dext_tstride; a.ld_ext = ld_ext; a.dext_t0 = dext_t0;
+        a.dZ = dZ; a.dz_tstride = 4 * MH; a.M = M; a.H = H; a.T = T;
+        a.keep = keep; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code0 = drop_code0;
+        a.video_id = video_id; a.sample_id = sample_id;
+        a.img = sc.bimg; a.ex = sc.bex; a.sync = sc.bsync;
+        return launch_lstm_bwd_chain(a, st);
+    }
+    const SlabPlan sp = slab_plan(M, H);
+    for (int t = T - 1; t >= 0; --t) {
+        hipError_t e = launch_lstm_bwd_pointwise(gates + (size_t)t * 4 * MH, C + (t + 1) * MH, C + t * MH, t == T - 1 ? nullptr : sc.slab, sp.nslab, MH,
+                                                 (dext && t >= dext_t0) ? dext + (size_t)(t - dext_t0) * dext_tstride : nullptr, ld_ext,
+                                                 t == T - 1 ? nullptr : sc.dc, sc.dc, dZ + (size_t)t * 4 * MH, M, H, keep, seed, drop_code0 + (uint32_t)t,
+                                                 video_id, sample_id, st);
+        if (e != hipSuccess) return e;
+        if (t > 0) {
+            e = nn_bwd(dZ + (size_t)t * 4 * MH, 4 * H, W + (size_t)kw0 * 4 * H, 4 * H, sc.slab, H, M, H, 4 * H, sp.splits, MH, st);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t s2vt_lstm_recurrence_bwd_scratch_bytes(int32_t M, int32_t H)
+{
+    if (M <= 0 || H <= 0) return 0;
+    Carver c(nullptr, 0);
+    size_t imgf, exf, syncb;
+    bwd_chain_scratch(H, M < 256 ? M : 256, &imgf, &exf, &syncb);
+    c.take<float>((size_t)kMaxSlabs * M * H); c.take<float>((size_t)M * H);
+    c.take<float>(imgf); c.take<float>(exf); c.take<unsigned>(syncb / 4);
+    return c.off;
+}
+
+int s2vt_lstm_recurrence_bwd(const float* W, int32_t kw0, const float* gates, const float* C_hist, const float* dext, int64_t dext_tstride,
+                             int32_t ld_ext, int32_t dext_t0, float* dZ, int32_t M, int32_t H, int32_t T, float keep, uint64_t seed,
+                             const int32_t* video_id, const int32_t* sample_id, uint32_t drop_code0, int32_t persistent, void* scratch,
+                             size_t scratch_bytes, s2vt_stream stream)
+{
+    if (!W || !gates || !C_hist || !dZ || M <= 0 || H <= 0 || T < 0 || kw0 < 0 || persistent < -1 || persistent > 1 || !scratch) return S2VT_E_BADARG;
+    if (dext && (ld_ext < H || dext_t0 < 0)) return S2VT_E_BADARG;
+    if (!(keep > 0.0f) || (keep < 1.0f && (!video_id || !sample_id))) return S2VT_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(scratch) & 255u) return S2VT_E_ALIGN;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
+    Carver c(scratch, scratch_bytes);
+    size_t imgf, exf, syncb;
+    bwd_chain_scratch(H, M < 256 ? M : 256, &imgf, &exf, &syncb);
+    BwdScratch sc;
+    sc.slab = c.take<float>((size_t)kMaxSlabs * M * H); sc.dc = c.take<float>((size_t)M * H);
+    sc.bimg = c.take<float>(imgf); sc.bex = c.take<float>(exf); sc.bsync = c.take<unsigned>(syncb / 4);
+    if (!c.ok()) return S2VT_E_WORKSPACE;
+    if (persistent == 1 && !bwd_chain_eligible(M, H)) return S2VT_E_BADARG;
+    HIP_TRY(lstm_recurrence_bwd(W, kw0, gates, C_hist, dext, (size_t)dext_tstride, ld_ext, dext_t0, dZ, M, H, T, keep, seed, drop_code0, video_id,
+                                sample_id, sc, persistent, S(stream)));
+    return S2VT_OK;
+}
 
 size_t s2vt_train_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t N)
 {
@@ -299,18 +377,11 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         HIP_TRY(launch_gemm_tn(a, sv));
         HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2, H, Tc * N, H, V, 1, 0, st));
     }
-    const SlabPlan sp2 = slab_plan(N, H), sp1 = slab_plan(B, H);
     if (do_l2) {
-    // ---- LSTM2 back through time
-    for (int t = T - 1; t >= 0; --t) {
-        HIP_TRY(launch_lstm_bwd_pointwise(w.G2 + (size_t)t * 4 * NH, w.C2 + (t + 1) * NH, w.C2 + t * NH,
-                                          t == T - 1 ? nullptr : w.slab, sp2.nslab, NH,
-                                          t >= Tv ? w.dO2 + (size_t)(t - Tv) * NH : nullptr, H, t == T - 1 ? nullptr : w.dc,
-                                          w.dc, w.dZ2 + (size_t)t * 4 * NH, N, H, keep, seed, 512u + (uint32_t)t, video_id,
-                                          sample_id, st));
-        if (t > 0) {
-            HIP_TRY(nn_bwd(w.dZ2 + (size_t)t * 4 * NH, 4 * H, p->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, w.slab, H, N, H, 4 * H, sp2.splits, NH, st));
-        }
+    // ---- LSTM2 back through time (one persistent launch up to 128 rows: chain.hip)
+    {
+        BwdScratch sc{w.slab, w.dc, w.bimg, w.bex, w.bsync};
+        HIP_TRY(lstm_recurrence_bwd(p->lstm2_W, H + E, w.G2, w.C2, w.dO2, NH, H, Tv, w.dZ2, N, H, T, keep, seed, 512u, video_id, sample_id, sc, -1, st));
     }
     // dZ2 is complete: LSTM2's weight gradients go to the side stream, beside dX2 and LSTM1's recurrence
     if (sd != st) HIP_TRY(fork_to(st, sd, ss.ev[1]));
@@ -332,12 +403,9 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
     // first reduced over the rep sample rows of each video (with their dropout masks)
     const size_t BH = (size_t)B * H;
     HIP_TRY(launch_reduce_dropout(w.dX2, H + E, w.dH1, T, B, N, H, keep, seed, 256u, video_id, sample_id, st));
-    for (int t = T - 1; t >= 0; --t) {
-        HIP_TRY(launch_lstm_bwd_pointwise(w.G1 + (size_t)t * 4 * BH, w.C1 + (t + 1) * BH, w.C1 + t * BH,
-                                          t == T - 1 ? nullptr : w.slab, sp1.nslab, BH, w.dH1 + t * BH, H,
-                                          t == T - 1 ? nullptr : w.dc, w.dc, w.dZ1 + (size_t)t * 4 * BH, B, H, 1.0f, seed, 0u,
-                                          nullptr, nullptr, st));
-        if (t > 0) HIP_TRY(nn_bwd(w.dZ1 + (size_t)t * 4 * BH, 4 * H, p->lstm1_W + (size_t)E * 4 * H, 4 * H, w.slab, H, B, H, 4 * H, sp1.splits, BH, st));
+    {
+        BwdScratch sc{w.slab, w.dc, w.bimg, w.bex, w.bsync};
+        HIP_TRY(lstm_recurrence_bwd(p->lstm1_W, E, w.G1, w.C1, w.dH1, BH, H, 0, w.dZ1, B, H, T, 1.0f, seed, 0u, nullptr, nullptr, sc, -1, st));
     }
     HIP_TRY(nn_bwd(w.dZ1, 4 * H, p->lstm1_W, 4 * H, w.dX1, E, Tv * B, E, 4 * H, 1, 0, st));
 

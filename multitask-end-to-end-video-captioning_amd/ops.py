@@ -137,6 +137,26 @@ def lstm_recurrence_fwd(W, kw0, b, h0, c0, T, cinit=None, cinit_steps=0, keep=1.
     return Ch, Hh, gates, out
 
 
+def lstm_recurrence_bwd(W, kw0, gates, C_hist, dext=None, dext_t0=0, keep=1.0, seed=0, video_id=None, sample_id=None, drop_code0=0,
+                        persistent=-1):
+    """Back-propagation through lstm_recurrence_fwd's unroll: returns dZ [T, M, 4H].  gates [T, M, 4H] activated, C_hist
+    [T+1, M, H], dext [T - dext_t0, M, H] = gradient w.r.t. the (dropped) outputs of steps dext_t0 .. T-1 or None.
+    persistent: 1 = the one-launch form, 0 = per-step launches, -1 = auto."""
+    _chk_f32(W, gates, C_hist, dext)
+    T, M, H4 = gates.shape
+    H = H4 // 4
+    assert gates.is_contiguous() and C_hist.is_contiguous() and C_hist.shape == (T + 1, M, H)
+    if dext is not None:
+        assert dext.is_contiguous() and dext.shape == (T - dext_t0, M, H)
+    dZ = torch.empty((T, M, 4 * H), dtype=torch.float32, device=W.device)
+    nb = lib().s2vt_lstm_recurrence_bwd_scratch_bytes(M, H)
+    ws = workspace(nb, W.device, "bchain")
+    check(lib().s2vt_lstm_recurrence_bwd(_ptr(W), kw0, _ptr(gates), _ptr(C_hist), _ptr(dext), M * H, H, dext_t0, _ptr(dZ), M, H, T, float(keep),
+                                         seed, _ptr(video_id), _ptr(sample_id), drop_code0, persistent, _ptr(ws), ws.numel(), _stream()),
+          "s2vt_lstm_recurrence_bwd")
+    return dZ
+
+
 def chain_timeouts() -> int:
     """Timed-out grid-wide waits of the persistent recurrence so far (0 = healthy); synchronises the device."""
     torch.cuda.synchronize()

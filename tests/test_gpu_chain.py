@@ -217,3 +217,65 @@ def test_persistent_launch_waits_for_the_previous_one_on_another_stream(gpu):
     for got in outs[-2:]:
         for r, g in zip(ref[:3], got[:3]):
             assert torch.equal(r, g)
+
+
+# ---- the persistent BACKWARD recurrence against per-step launches and against float64
+BWD_SHAPES = [  # M, E, H, T, first step with an upstream gradient
+    (4, 12, 20, 6, 2), (64, 32, 64, 9, 0), (33, 8, 64, 5, 3), (1, 4, 128, 4, 0),
+    (64, 500, 1000, 25, 5),        # LSTM2 of the XE step / LSTM1 of every step at the bench dims
+    (32, 500, 1000, 25, 0), (17, 500, 1000, 3, 1),
+    (100, 8, 64, 4, 0), (128, 500, 1000, 6, 2),          # two row tiles per wave
+    (200, 16, 136, 3, 0), (256, 500, 1000, 3, 1),        # four row tiles per wave (persistent = 1 only: auto stops at 128 rows)
+    (64, 8, 1024, 3, 0),                                  # H = 1024: 64 unit groups x 4 gates = every CU
+]
+
+
+@pytest.mark.parametrize("M,E,H,T,t0", BWD_SHAPES)
+@pytest.mark.parametrize("keep", [1.0, 0.9])
+def test_persistent_backward_recurrence(gpu, M, E, H, T, t0, keep):
+    """dZ of the one-launch backward recurrence == per-step {pointwise, split-K slabs} launches (to reduction order) and ==
+    a float64 restatement of BasicLSTMCell's backward (tf.gradients through tf_s2vt.py:113-153) within 2e-5 of the largest
+    entry per step; twice back to back (nothing stale), no timeout."""
+    import torch
+    W, b, h0, c0, cinit, vid, sid = _case(M, E, H, T, T, seed=M + H + 1)
+    Wd = _dev(W)
+    C, Hh, gates, _ = gpu.lstm_recurrence_fwd(Wd, E, _dev(b), _dev(h0), _dev(c0), T=T, cinit=_dev(cinit), cinit_steps=T, want_gates=True)
+    rng = np.random.default_rng(M * 7 + H)
+    dext = (rng.standard_normal((T - t0, M, H)) * 0.1).astype(np.float32)
+    args = dict(dext=_dev(dext), dext_t0=t0, keep=keep, seed=99, video_id=_dev(vid), sample_id=_dev(sid), drop_code0=512)
+    ref = gpu.lstm_recurrence_bwd(Wd, E, gates, C, persistent=0, **args)
+    for rep in range(2):
+        got = gpu.lstm_recurrence_bwd(Wd, E, gates, C, persistent=1, **args)
+        assert gpu.chain_timeouts() == 0
+        scale = ref.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
+        assert float(((got - ref).abs() / scale).max()) <= 2e-5, rep
+    if M <= 128:
+        auto = gpu.lstm_recurrence_bwd(Wd, E, gates, C, persistent=-1, **args)
+        assert torch.equal(auto, got)                       # auto takes the persistent form here (deterministic: no atomics)
+    # float64 restatement
+    g64 = gates.double().cpu().numpy(); C64 = C.double().cpu().numpy(); Whh = W[E:].astype(np.float64)
+    dc = np.zeros((M, H)); dh_rec = np.zeros((M, H))
+    for t in range(T - 1, -1, -1):
+        dh = dh_rec.copy()
+        if t >= t0:
+            d = dext[t - t0].astype(np.float64)
+            if keep < 1:
+                mask = gpu_mask(gpu, 99, vid, sid, 512 + t, keep, H)
+                d = d / np.float64(np.float32(keep)) * mask
+            dh = dh + d
+        si, tj, sf, so = (g64[t][:, q * H:(q + 1) * H] for q in range(4))
+        tc = np.tanh(C64[t + 1])
+        dcur = dh * so * (1 - tc * tc) + dc
+        dz = np.concatenate([dcur * tj * si * (1 - si), dcur * si * (1 - tj * tj), dcur * C64[t] * sf * (1 - sf), dh * tc * so * (1 - so)], 1)
+        dc = dcur * sf
+        dh_rec = dz @ Whh.T
+        err = np.abs(got[t].double().cpu().numpy() - dz).max() / max(np.abs(dz).max(), 1e-30)
+        assert err <= 2e-5, (t, err)
+
+
+def gpu_mask(gpu, seed, video, sample, code, keep, H):
+    """DropoutWrapper keep masks [M, H] from the library's own stream (s2vt_dropout_bwd of ones = mask / keep; the stream
+    itself is pinned to the oracle in test_gpu_fwd.py)."""
+    import torch
+    ones = torch.ones((len(video), H), dtype=torch.float32, device="cuda")
+    return (gpu.dropout_bwd(ones, keep, seed, code, _dev(video), _dev(sample)) > 0).double().cpu().numpy()
