@@ -1,6 +1,7 @@
 // fwd.hip -- instantiations + shape dispatch of the forward contraction kernel (gemm_mfma.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -283,7 +284,33 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     const int mt = ceil_div(a.M, e.BM), nt = ceil_div(a.N, e.CG);
     GemmArgs a2 = a;
     a2.xcd_map = (mt <= 16 && nt >= 8) ? 1 : 0;
-    const unsigned gx = a2.xcd_map ? (unsigned)(mt * ceil_div(nt, 8) * 8) : (unsigned)(mt * nt);
+    // L2-sized supertiles for the many-tile store shapes (forward products and W^T data gradients): S2VT_SUP="gm,gn"
+    // forces a shape (dev knob; "0" = the previous banded order)
+    if (!a2.xcd_map && (epi == EPI_STORE || epi == EPI_STORE_NT) && a.splits <= 1 && (long)mt * nt >= 512 && mt >= 4) {
+        static const int knob = [] {
+            const char* e = getenv("S2VT_SUP");
+            if (!e) return -1;
+            int gm = 0, gn = 0;
+            if (sscanf(e, "%d,%d", &gm, &gn) == 2 && gm > 0 && gn > 0) return gm * 1000 + gn;
+            return 0;
+        }();
+        int gm = 0, gn = 0;
+        if (knob > 0) { gm = knob / 1000; gn = knob % 1000; }
+        else if (knob < 0) {
+            // ~64-96 workgroups per XCD at a time (32 CUs x 2-3): 6 row tiles x 11 column tiles (whole rows of a grid with few
+            // column tiles).  Measured (tools/ab_supertile_traffic.sh, profiles/r03_supertile_ab.jsonl): fetches of the logits
+            // product 2035 -> 768 MB per launch, of dO2 3950 -> 1770; 8x8 / 4x8 / 4x16 within 4 % of it, 16x4 and 12x11
+            // 25-50 % worse (a strip of 6 x 128 rows of A stays in the XCD's 4 MB L2 while the column tiles walk past it)
+            gn = nt <= 12 ? nt : 11;
+            gm = 6;
+        }
+        if (gm > 0 && gn > 0) {
+            if (gn > nt) gn = nt;
+            if (gm > mt) gm = mt;
+            a2.xcd_map = 2; a2.sup_gm = gm; a2.sup_gn = gn;
+        }
+    }
+    const unsigned gx = a2.xcd_map == 1 ? (unsigned)(mt * ceil_div(nt, 8) * 8) : (unsigned)(mt * nt);
     const dim3 grid(gx, (unsigned)(a.splits > 1 ? a.splits : 1), 1);
     KernelFn fn = can_vec(a, epi == EPI_STORE_NT) ? e.vec : e.scalar;
     const int pcls = epi;                                              // profiler class (0 store, 1 LSTM, 2 pick, 3 = TN kernel, 4 store with W^T)

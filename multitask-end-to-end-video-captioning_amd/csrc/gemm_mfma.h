@@ -60,7 +60,8 @@ struct GemmArgs {
     float* C;
     int ldc;
     int act;             // 0 none, 1 tanh
-    int xcd_map;         // 1: XCD-aware tile order (set by the launcher for skinny-M shapes)
+    int xcd_map;         // 1: XCD-aware tile order (set by the launcher for skinny-M shapes); 2: L2-sized supertiles (many-tile shapes)
+    int sup_gm, sup_gn;  //    xcd_map == 2: row tiles x column tiles of a supertile (~ the workgroups one XCD runs at a time)
     int splits;          // >1: order-free split-K over blockIdx.y (backward data path only, nseg == 1)
     int kper;            //     K range per split (multiple of BK)
     size_t slab_stride;  //     floats between the partial-sum slabs of consecutive splits
@@ -238,7 +239,24 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
     const int ntile_n = (g.N + CG - 1) / CG;
     const int ntile_m = (g.M + BM - 1) / BM;
     int tile_m, tile_n;
-    if (g.xcd_map) {
+    if (g.xcd_map == 2) {
+        // Many-tile shapes.  The tile grid is walked supertile by supertile (sup_gm row tiles x sup_gn column tiles, row
+        // tiles fastest inside one); XCD b % 8 takes a contiguous, equally long stretch of that walk, so the ~64-96
+        // workgroups an XCD runs at a time form one supertile: they walk K together, every A chunk is fetched into that
+        // XCD's L2 once for sup_gn column tiles and every W chunk once for sup_gm row tiles (the previous order ran ONE row
+        // tile x 64 column tiles at a time: the whole weight matrix re-streamed per row tile -- 2.5 GB of fetches for the
+        // 0.38 GB logits product).  Bijective for any tile count; edge supertiles are simply smaller.
+        const int nwg = ntile_m * ntile_n, q = nwg >> 3, r = nwg & 7;
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int p = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+        const int rowblk = g.sup_gm * ntile_n;
+        const int sm = p / rowblk, p1 = p - sm * rowblk;
+        const int hm = min(g.sup_gm, ntile_m - sm * g.sup_gm);
+        const int colblk = hm * g.sup_gn;
+        const int sn = p1 / colblk, within = p1 - sn * colblk;
+        tile_m = sm * g.sup_gm + within % hm;
+        tile_n = sn * g.sup_gn + within / hm;
+    } else if (g.xcd_map) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         tile_m = slot % ntile_m;
         tile_n = (slot / ntile_m) * 8 + xcd;
