@@ -218,6 +218,7 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
     """Synthetic inputs, resident in HBM, and the step closure of the workload."""
     import numpy as np
     import torch
+    from s2vt_amd import ops
     if workload.startswith("e2e"):
         return make_e2e_step(workload, mdl, dev, rank, B, K, info if info is not None else {})
     g = torch.Generator().manual_seed(1234 + rank)                                        # per-rank data shard
@@ -232,7 +233,7 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
     if workload == "rl":
         def step(i):
             s, _greedy = mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
-            return mdl.reinforce_update(video, s, pg_mask(s), rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,
+            return mdl.reinforce_update(video, s, None, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,      # mask None: PG mask from the ids, in the library
                                         reuse_sampler_state=True)    # LSTM1 trajectory of the sampler pass (same videos, same weights)
         return step
     # ground-truth captions: length 1 + min(Poisson(6), Tc - 2) words (MSVD mean 7.03), tokens U{2..V-1}, then <eos> = 0
@@ -251,7 +252,7 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
 
     def step(i):
         s, _greedy = mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
-        return mdl.mixed_update(video, s, pg_mask(s), rewards, baseline, gt, gt_mask, lr=1e-6, lambda_loss=0.5, clip_norm=5.0,
+        return mdl.mixed_update(video, s, ops.caption_mask(s, want_target=False)[0], rewards, baseline, gt, gt_mask, lr=1e-6, lambda_loss=0.5, clip_norm=5.0,
                                 video_base=rank * B, true_labels=labels)
     return step
 

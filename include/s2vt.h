@@ -236,6 +236,19 @@ int s2vt_bptt_dvideo(const s2vt_dims* d, const s2vt_params* p, int32_t B, int32_
 int s2vt_embed_scatter_add(const float* dE, int32_t ld, const int32_t* idx, int32_t R, int32_t E, float* dWemb,
                            s2vt_stream stream);
 
+/* ---- host glue of the REINFORCE step, on the device (decode_captions_masks, cider_evaluation.py:145-172; the objective's
+ * coefficients, reinforcement_multisampling_tf_s2vt.py:641-646).
+ * s2vt_caption_mask: ids [N, Tc] -> mask [N, Tc] (1 up to and including the first <eos> = 0; may be NULL), target_tm [Tc*N]
+ *   (the ids time-major, what s2vt_softmax_nll_fwd_bwd takes; may be NULL), *mask_sum = *mask_sum_copy = sum(mask) (each may be NULL).
+ * s2vt_pg_coef: coef_tm[t*N + n] = mask[n][t] * (rewards[n] - baseline[n]) * scale  (rewards NULL = 1, baseline NULL = 0).
+ * s2vt_step_scalars: *loss = sum(coef * nll) / *mask_sum_local, *gscale = 1 / *mask_sum_global (the bucket's tail slot after the
+ *   all-reduce), *sumsq = 0 -- every output optional; one launch. */
+int s2vt_caption_mask(const int32_t* ids, int32_t N, int32_t Tc, float* mask, int32_t* target_tm, float* mask_sum, float* mask_sum_copy, s2vt_stream stream);
+int s2vt_pg_coef(const float* mask, const float* rewards, const float* baseline, float scale, int32_t N, int32_t Tc, float* coef_tm,
+                 s2vt_stream stream);
+int s2vt_step_scalars(const float* coef, const float* nll, int64_t R, const float* mask_sum_local, const float* mask_sum_global, float* loss,
+                      float* gscale, float* sumsq, s2vt_stream stream);
+
 /* ---- gradient finalisation + tf.clip_by_global_norm + tf.train.AdamOptimizer ------------------
  * (reinforcement_multisampling_tf_s2vt.py:638-652; tf_s2vt.py:163-166,445-448).
  * s2vt_grad_finalize: g <- g * (*gscale) + weight_decay * theta over one flat range, and

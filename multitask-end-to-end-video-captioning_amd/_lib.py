@@ -77,6 +77,9 @@ SIGNATURES = {
     "s2vt_bptt_bwd_phase": (C.c_int, [_DP, _PP, _PP, _vp, _i32, _i32, _vp, _f32, _u64, _vp, _vp, _vp, _sz, _i32, _vp]),
     "s2vt_bptt_dvideo": (C.c_int, [_DP, _PP, _i32, _i32, _vp, _vp, _sz, _vp]),
     "s2vt_embed_scatter_add": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "s2vt_caption_mask": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "s2vt_pg_coef": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp]),
+    "s2vt_step_scalars": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_grad_finalize": (C.c_int, [_vp, _vp, _i64, _vp, _f32, _vp, _vp]),
     "s2vt_adam_tf": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _i64, _f32, _f32, _f32, _vp]),
     "s2vt_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

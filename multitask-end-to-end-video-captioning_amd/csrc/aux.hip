@@ -62,6 +62,87 @@ hipError_t launch_prep_caption(const int32_t* cap, int32_t* prev, int32_t* tgt, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Host glue of the REINFORCE step on the device (decode_captions_masks, cider_evaluation.py:145-172, and the objective's
+// coefficients, reinforcement_multisampling_tf_s2vt.py:641-646): what used to be ~20 tiny tensor-library launches per step.
+//   caption_mask: mask[n][t] = 1 up to and including the first <eos> = 0 of row n; target_tm[t*N + n] = ids[n][t];
+//                 *mask_sum = sum(mask) (ONE workgroup: no zeroing, no atomics, deterministic)
+//   pg_coef:      coef_tm[t*N + n] = mask[n][t] * (rewards[n] - baseline[n]) * scale
+//   step_scalars: *loss = sum(coef * nll) / *msum_local;  *gscale = 1 / *gsum_global;  *sumsq = 0
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void caption_mask_kernel(const int32_t* ids, int N, int Tc, float* mask, int32_t* target_tm, float* mask_sum, float* mask_sum_copy)
+{
+    __shared__ float sh[4];
+    float local = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        bool alive = true;
+        for (int t = 0; t < Tc; ++t) {
+            const int32_t w = ids[(size_t)n * Tc + t];
+            const float mk = alive ? 1.0f : 0.0f;
+            if (mask) mask[(size_t)n * Tc + t] = mk;
+            if (target_tm) target_tm[(size_t)t * N + n] = w;
+            local += mk;
+            if (w == 0) alive = false;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (mask_sum) *mask_sum = total;
+        if (mask_sum_copy) *mask_sum_copy = total;          // (the gradient bucket's tail slot: sum(mask) rides through the all-reduce there)
+    }
+}
+
+hipError_t launch_caption_mask(const int32_t* ids, int N, int Tc, float* mask, int32_t* target_tm, float* mask_sum, float* mask_sum_copy, hipStream_t st)
+{
+    hipLaunchKernelGGL(caption_mask_kernel, dim3(1), dim3(256), 0, st, ids, N, Tc, mask, target_tm, mask_sum, mask_sum_copy);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void pg_coef_kernel(const float* mask, const float* rewards, const float* baseline, float scale, int N,
+                                                      int Tc, float* coef_tm)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * Tc) return;
+    const int t = i / N, n = i % N;
+    const float adv = (rewards ? rewards[n] : 1.0f) - (baseline ? baseline[n] : 0.0f);
+    coef_tm[i] = mask[(size_t)n * Tc + t] * (adv * scale);
+}
+
+hipError_t launch_pg_coef(const float* mask, const float* rewards, const float* baseline, float scale, int N, int Tc, float* coef_tm,
+                          hipStream_t st)
+{
+    if (N * Tc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pg_coef_kernel, dim3((N * Tc + 255) / 256), dim3(256), 0, st, mask, rewards, baseline, scale, N, Tc, coef_tm);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void step_scalars_kernel(const float* coef, const float* nll, int64_t R, const float* msum_local,
+                                                           const float* gsum_global, float* loss, float* gscale, float* sumsq)
+{
+    __shared__ float sh[4];
+    float local = 0.f;
+    if (coef && nll)
+        for (int64_t i = threadIdx.x; i < R; i += 256) local += coef[i] * nll[i];
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (loss) *loss = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (msum_local ? *msum_local : 1.0f);
+        if (gscale) *gscale = 1.0f / (gsum_global ? *gsum_global : 1.0f);
+        if (sumsq) *sumsq = 0.0f;
+    }
+}
+
+hipError_t launch_step_scalars(const float* coef, const float* nll, int64_t R, const float* msum_local, const float* gsum_global, float* loss,
+                               float* gscale, float* sumsq, hipStream_t st)
+{
+    hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(256), 0, st, coef, nll, R, msum_local, gsum_global, loss, gscale, sumsq);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // softmax / NLL rows, forward + backward in one pass over the logits.
 //   lse = max + log(sum exp(l - max)); q = onehot*(1-s) + s/V; nll = -sum q*(l - lse)
 //   dlogits = coef[row] * (softmax - q)      (written in place over the logits)

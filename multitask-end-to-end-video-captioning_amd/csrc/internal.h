@@ -39,6 +39,11 @@ struct TnArgs {
 hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st);
 
 hipError_t launch_prep_caption(const int32_t* cap, int32_t* prev, int32_t* tgt, int N, int Tc, hipStream_t st);
+hipError_t launch_caption_mask(const int32_t* ids, int N, int Tc, float* mask, int32_t* target_tm, float* mask_sum, float* mask_sum_copy, hipStream_t st);
+hipError_t launch_pg_coef(const float* mask, const float* rewards, const float* baseline, float scale, int N, int Tc, float* coef_tm,
+                          hipStream_t st);
+hipError_t launch_step_scalars(const float* coef, const float* nll, int64_t R, const float* msum_local, const float* gsum_global, float* loss,
+                               float* gscale, float* sumsq, hipStream_t st);
 hipError_t launch_softmax_nll(float* logits, int ld, int R, int V, const int32_t* target, const float* coef,
                               float smoothing, float* nll, float* lp_t, hipStream_t st, const float* smooth_rows = nullptr);
 hipError_t launch_softmax_unshifted_argmax(const float* logits, int ld, int R, int V, int32_t* ids, float* probs, hipStream_t st);

@@ -310,6 +310,29 @@ int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, cons
     return S2VT_OK;
 }
 
+int s2vt_caption_mask(const int32_t* ids, int32_t N, int32_t Tc, float* mask, int32_t* target_tm, float* mask_sum, float* mask_sum_copy, s2vt_stream stream)
+{
+    if (!ids || N <= 0 || Tc <= 0) return S2VT_E_BADARG;
+    HIP_TRY(launch_caption_mask(ids, N, Tc, mask, target_tm, mask_sum, mask_sum_copy, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_pg_coef(const float* mask, const float* rewards, const float* baseline, float scale, int32_t N, int32_t Tc, float* coef_tm,
+                 s2vt_stream stream)
+{
+    if (!mask || !coef_tm || N <= 0 || Tc <= 0) return S2VT_E_BADARG;
+    HIP_TRY(launch_pg_coef(mask, rewards, baseline, scale, N, Tc, coef_tm, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_step_scalars(const float* coef, const float* nll, int64_t R, const float* mask_sum_local, const float* mask_sum_global, float* loss,
+                      float* gscale, float* sumsq, s2vt_stream stream)
+{
+    if (R < 0 || ((coef == nullptr) != (nll == nullptr))) return S2VT_E_BADARG;
+    HIP_TRY(launch_step_scalars(coef, nll, R, mask_sum_local, mask_sum_global, loss, gscale, sumsq, S(stream)));
+    return S2VT_OK;
+}
+
 int s2vt_softmax_nll_fwd_bwd(float* logits, int32_t ld, int32_t R, int32_t V, const int32_t* target, const float* coef,
                              float smoothing, float* nll, float* lp_target, s2vt_stream stream)
 {

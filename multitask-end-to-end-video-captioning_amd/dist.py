@@ -71,8 +71,9 @@ def _all_reduce_sum(t: torch.Tensor, group=None):
 
 def allreduce_bucket(grad_flat: torch.Tensor, n_params: int, local_mask_sum, group=None):
     """In place: grad_flat[:n_params] <- sum over ranks, returns the GLOBAL sum(mask) as a 1-element
-    view of the bucket's tail slot (so one collective carries both)."""
-    grad_flat[n_params] = local_mask_sum
+    view of the bucket's tail slot (so one collective carries both).  local_mask_sum None: the slot already holds it."""
+    if local_mask_sum is not None:
+        grad_flat[n_params] = local_mask_sum
     if active(group):
         _all_reduce_sum(grad_flat, group)
     return grad_flat[n_params:n_params + 1]

@@ -119,12 +119,10 @@ class EndToEnd:
         samples, _ = m.sample(video_s, K, False, seed=sample_seed, video_base=video_base)
         video_g, _ = self.extract(frames, dropout=False)
         _, greedy = m.sample(video_g, 0, True, video_base=video_base)
-        is_eos = samples == 0
-        mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()
         r, b = reward_fn(samples, greedy)
         r = torch.as_tensor(r, dtype=torch.float32)
         b = torch.as_tensor(b, dtype=torch.float32).repeat(K)
-        st = m.reinforce_update(video_u, samples, mask, r, b, lr, clip_norm=clip_norm, video_base=video_base,
+        st = m.reinforce_update(video_u, samples, None, r, b, lr, clip_norm=clip_norm, video_base=video_base,
                                 true_labels=true_labels, extra_sumsq=self._cnn_grads(h, 0.0, true_labels is not None))
         self._cnn_apply(lr, clip_norm)
         st.samples, st.greedy = samples, greedy

@@ -251,6 +251,7 @@ class Video_Caption_Generator:
         self.dp_overlap = os.environ.get("S2VT_DP_OVERLAP", "0") == "1"
         self._debug_checks = os.environ.get("S2VT_DEBUG_CHECKS", "0") == "1"
         self._applied = torch.zeros(1, dtype=torch.int32, device=self.device)   # step number of the last Adam update the device APPLIED
+        self._row_id_cache = {}
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._gscale = torch.ones(1, dtype=torch.float32, device=self.device)
         self._ascale = torch.ones(1, dtype=torch.float32, device=self.device)
@@ -262,9 +263,15 @@ class Video_Caption_Generator:
         return torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
 
     def _row_ids(self, B, rep, video_base):
-        vid = (torch.arange(B, dtype=torch.int32, device=self.device) + video_base).repeat(rep)
-        sid = torch.arange(rep, dtype=torch.int32, device=self.device).repeat_interleave(B)
-        return vid.contiguous(), sid.contiguous()
+        key = (B, rep, int(video_base))
+        hit = self._row_id_cache.get(key)
+        if hit is None:
+            vid = (torch.arange(B, dtype=torch.int32, device=self.device) + video_base).repeat(rep)
+            sid = torch.arange(rep, dtype=torch.int32, device=self.device).repeat_interleave(B)
+            if len(self._row_id_cache) > 64:
+                self._row_id_cache.clear()
+            hit = self._row_id_cache[key] = (vid.contiguous(), sid.contiguous())
+        return hit
 
     def _untile(self, v, N):
         """The reference feeds build_loss the feature block tiled K times, rows k*B+j = video j
@@ -339,7 +346,7 @@ class Video_Caption_Generator:
         return video, sentence, []
 
     # -------------------------------------------------------------------------------- training graphs
-    def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep, reuse_sampler_state=False):
+    def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep, reuse_sampler_state=False, target_tm=None):
         """Teacher-forced forward + softmax-NLL fwd/bwd.  caption [N,Tc] int32 device, coef_tm
         time-major [Tc*N].  Leaves dlogits + activations ready for backward()."""
         B = video.shape[0]
@@ -362,12 +369,12 @@ class Video_Caption_Generator:
                                             sampler_state=state)
         if callable(coef_tm):            # host work (the reward) runs here, beside the forward just queued on the GPU
             coef_tm = coef_tm()
-        target = caption.t().contiguous().view(-1)
+        target = caption.t().contiguous().view(-1) if target_tm is None else target_tm
         nll, lp = ops.softmax_nll_fwd_bwd(logits, target, coef_tm, smoothing)
         self._ctx = (video, N, logits, ws, keep, seed, vid, sid)
         return nll, lp
 
-    def backward(self, accumulate=False, overlap=None):
+    def backward(self, accumulate=False, overlap=None, keep_tail=False):
         """BPTT into the flat gradient bucket (accumulate=True: on top of what a previous pass left there).  Data parallel,
         overlap=True: the bucket is laid out [... lstm1_W | lstm2_W | embed_word_W | embed_word_b | ...]; the
         vocab-projection gradients are final after phase 1 and LSTM2's after phase 3, so their all-reduces are started
@@ -380,7 +387,7 @@ class Video_Caption_Generator:
         video, N, dlogits, ws, keep, seed, vid, sid = self._ctx
         st = self.store
         if not accumulate:
-            st.grad.zero_()
+            (st.grad[:st.numel] if keep_tail else st.grad).zero_()     # keep_tail: sum(mask) already sits in the tail slot (ops.caption_mask)
         self._pending = []
         self._early = None
         if dp.active() and overlap:
@@ -406,7 +413,7 @@ class Video_Caption_Generator:
         video, N, _, ws, *_ = self._ctx
         return ops.bptt_dvideo(self.dims, self.store.params, video.shape[0], N, ws)
 
-    def apply_gradients(self, mask_sum, lr, clip_norm, weight_decay=0.0, attr_scale=None, extra_sumsq=None, decay_all=False):
+    def apply_gradients(self, mask_sum, lr, clip_norm, weight_decay=0.0, attr_scale=None, extra_sumsq=None, decay_all=False, loss_terms=None):
         """All-reduce (RCCL, one flat bucket + sum(mask) in its tail), 1/sum(mask), weight decay,
         tf.clip_by_global_norm, TF-form Adam (reinforcement_multisampling_tf_s2vt.py:643-652).
         attr_scale: constant normaliser of the attribute-head gradients (their range of the bucket is
@@ -419,7 +426,8 @@ class Video_Caption_Generator:
         early = getattr(self, "_early", None)
         if early is not None and dp.active():
             lo, hi = early
-            st.grad[st.numel] = mask_sum
+            if mask_sum is not None:
+                st.grad[st.numel] = mask_sum
             pend = getattr(self, "_pending", [])
             pend.append(dp.allreduce_async(st.grad[:lo]))
             pend.append(dp.allreduce_async(st.grad[hi:]))            # includes the tail slot carrying sum(mask)
@@ -427,9 +435,13 @@ class Video_Caption_Generator:
             self._pending, self._early = [], None
             gsum = st.grad[st.numel:st.numel + 1]
         else:
-            gsum = dp.allreduce_bucket(st.grad, st.numel, mask_sum)
-        torch.reciprocal(gsum, out=self._gscale)
-        self._sumsq.zero_()
+            gsum = dp.allreduce_bucket(st.grad, st.numel, mask_sum)      # mask_sum None: the tail slot already holds the local sum(mask)
+        # one launch: 1 / global sum(mask), a fresh zeroed ||g||^2 accumulator, and the step's loss (loss_terms = (coef, nll,
+        # local sum(mask)): sum(coef * nll) / sum(mask) of THIS rank's rows)
+        self._sumsq = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._loss = torch.empty(1, dtype=torch.float32, device=self.device) if loss_terms is not None else None
+        coef_, nll_, msum_ = loss_terms if loss_terms is not None else (None, None, None)
+        ops.step_scalars(coef_, nll_, msum_, gsum, self._loss, self._gscale, self._sumsq)
         nd = st.n_decayed
         a0 = st.offsets.get("attr_W", nd)
         ops.grad_finalize(st.grad[:a0], st.theta[:a0], self._gscale, weight_decay, self._sumsq)
@@ -483,8 +495,9 @@ class Video_Caption_Generator:
     def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
                          true_labels=None, reuse_sampler_state=False, extra_sumsq=None, reward_fn=None):
         """build_loss + the REINFORCE objective and train_op of train()
-        (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc],
-        rewards / baseline [N], rows sample-major over the B videos.
+        (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc] (None: derived from the
+        ids on the device -- 1 up to and including the first <eos> -- with the coefficients, sum(mask) and the loss in three
+        small library launches instead of ~20 tensor-library ones), rewards / baseline [N], rows sample-major over the B videos.
         reuse_sampler_state: the sample() call that produced `sampled` ran just before on this same video tensor
         with the current weights -- its LSTM1 trajectory is reused (the reference recomputes the whole unroll in
         build_loss).  With true_labels [B, label_dim] the multitask objective of
@@ -495,7 +508,14 @@ class Video_Caption_Generator:
         `baseline` are ignored then."""
         video = self._dev(video, torch.float32)
         cap = self._dev(sampled, torch.int32)
-        mask = self._dev(mask, torch.float32)
+        st_ = self.store
+        fused = mask is None        # the library derives the mask from the ids (1 up to and incl. the first <eos>, cider_evaluation.py:145-172)
+        if fused:
+            msum = torch.empty(1, dtype=torch.float32, device=self.device)
+            mask, target_tm, _ = ops.caption_mask(cap, mask_sum=msum, mask_sum_copy=st_.grad[st_.numel:st_.numel + 1])
+        else:
+            mask = self._dev(mask, torch.float32)
+            target_tm = None
         rep = cap.shape[0] // video.shape[0]
         multitask = true_labels is not None and self.label_dim > 0
         pg_w = (1.0 - self.alpha) if multitask else 1.0
@@ -503,15 +523,18 @@ class Video_Caption_Generator:
 
         def make_coef():
             r, b = reward_fn() if reward_fn is not None else (rewards, baseline)
-            adv = self._dev(r, torch.float32) - self._dev(b, torch.float32)
-            made["coef"] = (mask * (adv * pg_w)[:, None]).t().contiguous().view(-1)
+            r, b = self._dev(r, torch.float32), self._dev(b, torch.float32)
+            if fused:
+                made["coef"] = ops.pg_coef(mask, r, b, pg_w)
+            else:
+                made["coef"] = (mask * ((r - b) * pg_w)[:, None]).t().contiguous().view(-1)
             return made["coef"]
         keep = self.dropout_rate if keep is None else keep
-        nll, _ = self._forward_loss(video, cap, make_coef, 0.0, rep, video_base, keep, reuse_sampler_state)
+        nll, _ = self._forward_loss(video, cap, make_coef, 0.0, rep, video_base, keep, reuse_sampler_state, target_tm=target_tm)
         coef = made["coef"]
-        msum = mask.sum()
-        loss_local = torch.dot(coef, nll)
-        self.backward()
+        if not fused:
+            msum = mask.sum().reshape(1)
+        self.backward(keep_tail=fused)
         attr_scale = None
         attr_loss = None
         if multitask:
@@ -522,9 +545,10 @@ class Video_Caption_Generator:
             attr_scale = self.alpha / float(self.label_dim * Bg)
             self._attr_ctx = (dz, attr_scale)                   # for callers that differentiate through `video` (e2e.py)
             attr_loss = bce.sum() * attr_scale
-        self.apply_gradients(msum, lr, clip_norm, attr_scale=attr_scale, extra_sumsq=extra_sumsq)
-        st = StepStats(loss_local / msum, self._sumsq.clone(), msum)
+        self.apply_gradients(None if fused else msum, lr, clip_norm, attr_scale=attr_scale, extra_sumsq=extra_sumsq, loss_terms=(coef, nll, msum))
+        st = StepStats(self._loss[0], self._sumsq, msum[0])
         st.attr_loss = attr_loss
+        st.mask = mask
         return st
 
     def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, q1=True, smoothing=0.05, video_base=0, keep=None,
@@ -545,11 +569,11 @@ class Video_Caption_Generator:
         coef = coef.contiguous().view(-1)
         keep = self.dropout_rate if keep is None else keep
         nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep)
-        msum = mask.sum()
-        loss_local = torch.dot(coef, nll)
+        msum = mask.sum().reshape(1)
         self.backward()
-        self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value, extra_sumsq=extra_sumsq, decay_all=decay_all)
-        return StepStats(loss_local / msum, self._sumsq.clone(), msum)
+        self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value, extra_sumsq=extra_sumsq, decay_all=decay_all,
+                             loss_terms=(coef, nll, msum))
+        return StepStats(self._loss[0], self._sumsq, msum[0])
 
     def mixed_update(self, video, sampled, mask, rewards, baseline, gt_caption, gt_mask, lr, lambda_loss=0.5, clip_norm=5.0,
                      video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None):
@@ -604,7 +628,7 @@ class Video_Caption_Generator:
             attr_loss = bce.sum() * attr_scale
         one = torch.full((), 1.0 / self.world_size, device=self.device)   # the bucket is already normalised: global "sum(mask)" = 1
         self.apply_gradients(one, lr, clip_norm, weight_decay=lam * self.decay_value, attr_scale=attr_scale)
-        st = StepStats(loss_pg + loss_xe, self._sumsq.clone(), sums[0])
+        st = StepStats(loss_pg + loss_xe, self._sumsq, sums[0])
         st.attr_loss = attr_loss
         return st
 

@@ -292,6 +292,34 @@ def bptt_dvideo(dims: Dims, params: Params, B: int, N: int, ws):
     return out
 
 
+def caption_mask(ids, mask_sum=None, want_mask=True, want_target=True, mask_sum_copy=None):
+    """ids [N, Tc] int32 -> (mask [N, Tc] fp32 | None, target_tm [Tc*N] int32 | None, mask_sum [1] fp32): one launch.
+    mask_sum_copy: a second place that receives sum(mask) (the gradient bucket's tail slot)."""
+    assert ids.is_cuda and ids.dtype == torch.int32 and ids.is_contiguous()
+    N, Tc = ids.shape
+    mask = torch.empty((N, Tc), dtype=torch.float32, device=ids.device) if want_mask else None
+    tgt = torch.empty(N * Tc, dtype=torch.int32, device=ids.device) if want_target else None
+    if mask_sum is None:
+        mask_sum = torch.empty(1, dtype=torch.float32, device=ids.device)
+    check(lib().s2vt_caption_mask(_ptr(ids), N, Tc, _ptr(mask), _ptr(tgt), _ptr(mask_sum), _ptr(mask_sum_copy), _stream()), "s2vt_caption_mask")
+    return mask, tgt, mask_sum
+
+
+def pg_coef(mask, rewards, baseline, scale=1.0):
+    _chk_f32(mask, rewards, baseline)
+    N, Tc = mask.shape
+    coef = torch.empty(N * Tc, dtype=torch.float32, device=mask.device)
+    check(lib().s2vt_pg_coef(_ptr(mask), _ptr(rewards), _ptr(baseline), float(scale), N, Tc, _ptr(coef), _stream()), "s2vt_pg_coef")
+    return coef
+
+
+def step_scalars(coef, nll, msum_local, gsum_global, loss=None, gscale=None, sumsq=None):
+    _chk_f32(coef, nll, msum_local, gsum_global, loss, gscale, sumsq)
+    R = 0 if coef is None else coef.numel()
+    check(lib().s2vt_step_scalars(_ptr(coef), _ptr(nll), R, _ptr(msum_local), _ptr(gsum_global), _ptr(loss), _ptr(gscale), _ptr(sumsq), _stream()),
+          "s2vt_step_scalars")
+
+
 def grad_finalize(g, theta, gscale, weight_decay, sumsq):
     _chk_f32(g, theta, gscale, sumsq)
     check(lib().s2vt_grad_finalize(_ptr(g), _ptr(theta), g.numel(), _ptr(gscale), float(weight_decay), _ptr(sumsq), _stream()),

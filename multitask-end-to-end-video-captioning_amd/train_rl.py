@@ -5,7 +5,7 @@ Step of the reference                                   | here
 --------------------------------------------------------+---------------------------------------------------
 9 sess.run of the sampler graphs (:743-753), each       | model.sample(video, K, with_greedy=True): ONE call,
   re-encoding the batch, vstack on the host (:757-764)  |   one encode, rows already sample-major
-decode_captions_masks: ids -> strings + mask (:783-784) | mask on the device (cumsum of <eos>), no strings
+decode_captions_masks: ids -> strings + mask (:783-784) | mask on the device (s2vt_caption_mask), no strings
 get_captions scan + evaluate_captions_cider x2 (:787-803| reward.CiderD.score_ids on the int32 ids (C++ inverted index, ~3 ms,
   pyciderevalcap on strings)                            |   under the GPU's teacher-forced forward); references indexed once
 features tiled x8 on the host (:779-782)                | never tiled: rows address video n % B
@@ -79,8 +79,6 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
 
             def step():
                 samples, greedy_words = model.sample(video, K, True, seed=cfg.seed + 7919 * (model.global_step + 1), video_base=lo)
-                is_eos = samples == 0
-                mask = ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()    # 1 up to and incl. the first <eos>
                 s_host, g_host = samples.cpu().numpy(), greedy_words.cpu().numpy()
                 model.check_health()            # the ids just came to the host: a starved sampler recurrence is caught before it is scored
 
@@ -88,7 +86,7 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
                     rb["r"] = scorer.score_ids(s_host, np.tile(rows, K))                 # [K*B], sample-major like the ids
                     rb["b"] = scorer.score_ids(g_host, rows)                            # [B]
                     return rb["r"], hostglue.tile_baseline(rb["b"], K)
-                return model.reinforce_update(video, samples, mask, None, None, lr=learning_rate(cfg, model.global_step),
+                return model.reinforce_update(video, samples, None, None, None, lr=learning_rate(cfg, model.global_step),
                                               clip_norm=cfg.clip_norm, video_base=lo, reuse_sampler_state=True, reward_fn=rewards)
             st, loss = run_step(model, step, log)
             r, b = rb["r"], rb["b"]

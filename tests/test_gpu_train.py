@@ -240,3 +240,41 @@ def test_backward_phases_sum_to_the_whole_pass(gpu, oracle):
     assert touched3 == {"embed_word_W", "embed_word_b", "lstm2_W", "lstm2_b"}
     for k in ("lstm2_W", "lstm2_b", "embed_word_W"):
         assert torch.equal(snaps[1][k], parts[k])                 # final when their phase returns
+
+
+def test_device_glue_matches_host_helpers(gpu):
+    """s2vt_caption_mask / s2vt_pg_coef / s2vt_step_scalars against the host helpers pinned to the reference
+    (hostglue.masks_from_ids <-> decode_captions_masks, tests/golden/hostglue.json) and plain numpy; and reinforce_update with
+    mask=None (library glue) lands where the explicit-mask form does."""
+    import torch
+    from s2vt_amd import hostglue, model as M
+    rng = np.random.default_rng(5)
+    N, Tc = 37, 9
+    ids = rng.integers(0, 6, (N, Tc)).astype(np.int32); ids[3] = 5; ids[4, 0] = 0          # a row without <eos>, a row that starts with it
+    tail = torch.zeros(1, device="cuda")
+    mask, tgt, msum = gpu.caption_mask(torch.as_tensor(ids).cuda(), mask_sum_copy=tail)
+    ref = hostglue.masks_from_ids(ids)
+    assert np.array_equal(mask.cpu().numpy(), ref) and np.array_equal(tgt.cpu().numpy(), ids.T.reshape(-1))
+    assert float(msum) == float(ref.sum()) == float(tail)
+    r = rng.random(N).astype(np.float32); b = rng.random(N).astype(np.float32)
+    coef = gpu.pg_coef(mask, torch.as_tensor(r).cuda(), torch.as_tensor(b).cuda(), 0.75)
+    assert np.array_equal(coef.cpu().numpy(), (ref * ((r - b) * np.float32(0.75))[:, None]).T.reshape(-1))
+    nll = torch.as_tensor(rng.random(N * Tc).astype(np.float32)).cuda()
+    loss = torch.empty(1, device="cuda"); gs = torch.empty(1, device="cuda"); sq = torch.ones(1, device="cuda")
+    g = torch.full((1,), 8.0, device="cuda")
+    gpu.step_scalars(coef, nll, msum, g, loss, gs, sq)
+    want = float((coef.double() * nll.double()).sum() / float(ref.sum()))
+    assert abs(float(loss) - want) <= 1e-5 * max(1.0, abs(want)) and float(gs) == 0.125 and float(sq) == 0.0
+    # the fused form of the update == the explicit-mask form
+    video = torch.as_tensor(np.abs(rng.standard_normal((4, 5, 128)) * 0.5).astype(np.float32)).cuda()
+    outs = []
+    for fused in (False, True):
+        mdl = M.Video_Caption_Generator(128, 260, 32, 64, 4, 0, 5, 8, seed=5, dropout_rate=0.9)
+        s, _ = mdl.sample(video, 3, True, seed=9)
+        mk = None if fused else torch.as_tensor(hostglue.masks_from_ids(s.cpu().numpy())).cuda()
+        rr = (rng.random(12) * 0 + np.linspace(0.1, 2, 12)).astype(np.float32); bb = np.tile(np.float32([0.5, 1.0, 0.2, 0.9]), 3)
+        st = mdl.reinforce_update(video, s, mk, rr, bb, lr=1e-3, reuse_sampler_state=True)
+        outs.append((mdl.store.theta.cpu().numpy(), float(st.loss), float(st.grad_sumsq), float(st.mask_sum)))
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= 2e-4
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * max(1.0, abs(outs[0][1])) and outs[0][3] == outs[1][3]
+    assert abs(outs[0][2] - outs[1][2]) <= 1e-4 * outs[0][2]
