@@ -389,99 +389,115 @@ struct BwdChainArgs {
     float* ex;                                         // [unit groups][4 gates][row tiles][256] partial tiles
     unsigned* sync;                                    // grid counters (kChainSyncBytes) then one 128-byte line per unit group
     unsigned* status; unsigned* fault; unsigned spin_limit;
-    int ncg;                                           // unit groups = ceil(H / 16)
+    int ncg;                                           // unit groups = ceil(H / (16 NC))
+    int tpp, img_tiles;                                // row tiles of a row part; row tiles of one image (= parts * tpp)
 };
 
-template <int NG, int TMW>
+// NC = 16-unit column tiles per workgroup.  NC = 1: workgroup (j, g) takes every row tile (4 TMW of them).  NC = 2 (M > 256
+// rows): workgroup (j, g, part) owns 32 units (128 KB of Whh in LDS) and HALF the row tiles (g.tpp per part), so a CU
+// streams half of its gate's dz image per step for the same number of MFMAs -- the two-part form of the forward kernel.
+template <int NG, int TMW, int NC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_chain_kernel(const BwdChainArgs g)
 {
     constexpr int ZS = 20;
-    constexpr int NT = 4 * TMW;                                // row tiles of an image
+    constexpr int PS = NC * TMW;                               // (row tile, column tile) slots one workgroup finishes per step, at most
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wl = smem;                                          // [NG][64 lanes][4]: B fragments of this workgroup's slice
+    float* Wl = smem;                                          // [NG][NC][64 lanes][4]: B fragments of this workgroup's slice
     const int tid = threadIdx.x, lane = tid & 63;
     const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* zb = smem + NG * 256 + pwave * (16 * ZS);           // per-wave transpose tile
-    float* dzl = smem + NG * 256 + 4 * 16 * ZS;                // [4 gates][16 rows][17]: dz of one finished row tile, regrouped for the image stores
+    float* zb = smem + NG * NC * 256 + pwave * (16 * ZS);      // per-wave transpose tile
+    float* dzl = smem + NG * NC * 256 + 4 * 16 * ZS;           // [4 gates][16 rows][17]: dz of one finished tile, regrouped for the image stores
     const int l15 = lane & 15, lq = lane >> 4;
     const int H = g.H, M = g.M, T = g.T;
-    // workgroup id -> (unit group, gate): the four gates of a unit group share blockIdx % 8
+    // workgroup id -> (unit group, gate, row part): the four gates of a (unit group, part) share blockIdx % 8
     const int wg = (int)blockIdx.x;
-    const int jj = (wg >> 5) * 8 + (wg & 7), gate = (wg >> 3) & 3;
+    const int gate = (wg >> 3) & 3;
+    const int part = NC == 2 ? (wg >> 5) & 1 : 0;
+    const int jj = (wg >> (NC == 2 ? 6 : 5)) * 8 + (wg & 7);
     if (jj >= g.ncg) return;                                   // (grid padded to whole groups of 8: these never take part)
-    const int u0 = jj * 16;
+    const int u0 = jj * 16 * NC;
+    const int tpp = g.tpp;                                     // row tiles of a part
+    const int NT = g.img_tiles;                                // row tiles of an image (= parts * tpp)
     const size_t img_floats = (size_t)NT * NG * 256;           // one gate image
 
-    // ---- this workgroup's slice of Whh -> LDS, once.  B[k][n] = Whh[u0 + n][gate * H + k]; element (k, n) goes to group
-    // k / 16, lane (k % 4) * 16 + n, component (k % 16) / 4.
-    for (int idx = tid; idx < 16 * NG * 4; idx += 256) {
+    // ---- this workgroup's slice of Whh -> LDS, once.  B[k][n] = Whh[u0 + n][gate * H + k]; element (k, n) of column tile
+    // c = n / 16 goes to group k / 16, tile c, lane (k % 4) * 16 + n % 16, component (k % 16) / 4.
+    for (int idx = tid; idx < 16 * NC * NG * 4; idx += 256) {
         const int k4 = idx % (NG * 4), n = idx / (NG * 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (u0 + n < H && 4 * k4 < H) v = *reinterpret_cast<const f32x4*>(g.W + (size_t)(g.kw0 + u0 + n) * g.ldw + (size_t)gate * H + 4 * k4);
-        const int grp = k4 >> 2, e = k4 & 3;
+        const int grp = k4 >> 2, e = k4 & 3, c = n >> 4, nn = n & 15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Wl[((grp * 64 + i * 16 + n) << 2) + e] = v[i];
+        for (int i = 0; i < 4; ++i) Wl[(((grp * NC + c) * 64 + i * 16 + nn) << 2) + e] = v[i];
     }
 
-    // ---- the (row, unit) this thread finishes at every step, per row tile gate * TMW + i
-    const int pr = tid >> 4, pn = tid & 15;                    // row within the tile, unit within the group
-    const int pu = u0 + pn;
-    float dc_reg[TMW], cnew[TMW];
-    uint32_t vid[TMW], sid[TMW];
-    bool pok[TMW];
+    // ---- the (row, unit) this thread finishes at every step, per slot s = gate * PSr + i of the part's tpp * NC (row tile,
+    // column tile) pairs (PSr = slots per workgroup, the four gate workgroups share them)
+    const int pr = tid >> 4, pn = tid & 15;                    // row within the tile, unit within the column tile
+    const int nslots = tpp * NC, psr = (nslots + 3) >> 2;
+    float dc_reg[PS], cnew[PS];
+    uint32_t vid[PS], sid[PS];
+    bool pok[PS];
+    int pm[PS], pu[PS], ptile[PS], pc[PS];
 #pragma unroll
-    for (int i = 0; i < TMW; ++i) {
-        const int m = (gate * TMW + i) * 16 + pr;
-        pok[i] = m < M && pu < H;
+    for (int i = 0; i < PS; ++i) {
+        const int slot = gate * psr + i;
+        ptile[i] = slot / NC; pc[i] = slot % NC;              // row tile within the part, column tile
+        pm[i] = (part * tpp + ptile[i]) * 16 + pr;
+        pu[i] = u0 + pc[i] * 16 + pn;
+        pok[i] = i < psr && slot < nslots && pm[i] < M && pu[i] < H;
         dc_reg[i] = 0.0f;
-        cnew[i] = pok[i] ? g.C[(size_t)T * g.state_tstride + (size_t)m * H + pu] : 0.0f;      // c_{T-1}
-        vid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.video_id[m] : 0u;
-        sid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.sample_id[m] : 0u;
+        cnew[i] = pok[i] ? g.C[(size_t)T * g.state_tstride + (size_t)pm[i] * H + pu[i]] : 0.0f;      // c_{T-1}
+        vid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.video_id[pm[i]] : 0u;
+        sid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.sample_id[pm[i]] : 0u;
     }
-    gu32* const ccount = (gu32*)g.sync + (kChainSyncBytes / 4) + jj * 32;
-    const __amdgpu_buffer_rsrc_t rsEx = __builtin_amdgcn_make_buffer_rsrc(g.ex, 0, g.ncg * 4 * NT * 1024, 0x00020000);
+    const int cluster = jj * NC + part;
+    gu32* const ccount = (gu32*)g.sync + (kChainSyncBytes / 4) + cluster * 32;
+    const __amdgpu_buffer_rsrc_t rsEx = __builtin_amdgcn_make_buffer_rsrc(g.ex, 0, g.ncg * NC * 4 * tpp * NC * 1024, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(g.img, 0, (int)(8 * img_floats * 4), 0x00020000);
-    GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, g.ncg, false, 4u};
-    bool wok[TMW];                                             // MFMA side: row tile pwave * TMW + i holds rows of the problem
+    GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, g.ncg, false, 4u * NC};
+    bool wok[TMW];                                             // MFMA side: row tile pwave * TMW + i of the part holds rows of the problem
     int voff[TMW];
+    const int tb = part * tpp + pwave * TMW;                   // first row tile of this wave
 #pragma unroll
     for (int i = 0; i < TMW; ++i) {
-        wok[i] = (pwave * TMW + i) * 16 < M;
+        wok[i] = pwave * TMW + i < tpp && (tb + i) * 16 < M;
         voff[i] = wok[i] ? lane * 16 : (int)0x80000000u;
     }
     __syncthreads();
 
-    float sg[TMW][4], cprev[TMW], dx[TMW];
+    float sg[PS][4], cprev[PS], dx[PS];
     auto load_step = [&](int t) __attribute__((always_inline)) {                // operands of step t's pointwise part (independent of the recurrence)
 #pragma unroll
-        for (int i = 0; i < TMW; ++i) {
-            const int m = (gate * TMW + i) * 16 + pr;
-            const float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)m * 4 * H + pu;
+        for (int i = 0; i < PS; ++i) {
+            const float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)pm[i] * 4 * H + pu[i];
 #pragma unroll
             for (int q = 0; q < 4; ++q) sg[i][q] = pok[i] ? gp[(size_t)q * H] : 0.0f;
-            cprev[i] = pok[i] ? g.C[(size_t)t * g.state_tstride + (size_t)m * H + pu] : 0.0f;
-            dx[i] = (pok[i] && g.dext && t >= g.dext_t0) ? g.dext[(size_t)(t - g.dext_t0) * g.dext_tstride + (size_t)m * g.ld_ext + pu] : 0.0f;
+            cprev[i] = pok[i] ? g.C[(size_t)t * g.state_tstride + (size_t)pm[i] * H + pu[i]] : 0.0f;
+            dx[i] = (pok[i] && g.dext && t >= g.dext_t0) ? g.dext[(size_t)(t - g.dext_t0) * g.dext_tstride + (size_t)pm[i] * g.ld_ext + pu[i]] : 0.0f;
         }
     };
     load_step(T - 1);
 
     unsigned arrival = 0;
     for (int t = T - 1; t >= 0; --t) {
-        float dh[TMW];
+        float dh[PS];
 #pragma unroll
-        for (int i = 0; i < TMW; ++i) dh[i] = 0.0f;
+        for (int i = 0; i < PS; ++i) dh[i] = 0.0f;
         if (t < T - 1) {
             // ---- dz_{t+1}[:, gate block] @ slice^T for this wave's row tiles: A fragments straight into registers
             gs.wait_all(arrival, pwave, lane);
             const float* acur = g.img + (size_t)((t + 1) & 1) * 4 * img_floats + (size_t)gate * img_floats;
             const __amdgpu_buffer_rsrc_t rsA =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)pwave * TMW * NG * 256), 0, TMW * NG * 1024, 0x00020000);
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)tb * NG * 256), 0, TMW * NG * 1024, 0x00020000);
             constexpr int RING0 = TMW == 1 ? 32 : 40 / TMW;
             constexpr int RING = NG < RING0 ? NG : RING0;
             f32x4 a[RING][TMW];
-            f32x4 acc[2][TMW];
+            f32x4 acc[2][NC][TMW];
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) { acc[0][i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) { acc[0][c][i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][c][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             static_for<0, RING>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
                 static_for<0, TMW>([&](auto i_) { constexpr int i = decltype(i_)::value; a[j][i] = bload16_sc1(rsA, voff[i], (i * NG + j) * 1024); });
@@ -489,18 +505,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
             const f32x4* bl = reinterpret_cast<const f32x4*>(Wl) + lane;
             constexpr int PB = NG < 4 ? NG : 4;
-            f32x4 b[PB];
-            static_for<0, PB>([&](auto j_) { constexpr int j = decltype(j_)::value; b[j] = bl[j * 64]; });
+            f32x4 b[PB][NC];
+            static_for<0, PB>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) b[j][c] = bl[(j * NC + c) * 64];
+            });
             static_for<0, NG>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
-                const f32x4 bj4 = b[j % PB];
-                if constexpr (j + PB < NG) b[j % PB] = bl[(j + PB) * 64];
+                f32x4 bj4[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bj4[c] = b[j % PB][c];
+                if constexpr (j + PB < NG) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) b[j % PB][c] = bl[((j + PB) * NC + c) * 64];
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, 4>([&](auto e_) {
                     constexpr int e = decltype(e_)::value;
-                    static_for<0, TMW>([&](auto i_) {
-                        constexpr int i = decltype(i_)::value;
-                        acc[e & 1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][i][e], bj4[e], acc[e & 1][i], 0, 0, 0);
+                    static_for<0, NC>([&](auto c_) {
+                        constexpr int c = decltype(c_)::value;
+                        static_for<0, TMW>([&](auto i_) {
+                            constexpr int i = decltype(i_)::value;
+                            acc[e & 1][c][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][i][e], bj4[c][e], acc[e & 1][c][i], 0, 0, 0);
+                        });
                     });
                 });
                 if constexpr (j + RING < NG) {
@@ -509,38 +537,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
-            // ---- partial tiles -> the unit group's exchange (row-major 16 x 16, one write-through 16-byte store per lane)
-            float* exw = g.ex + ((size_t)(jj * 4 + gate) * NT + (size_t)pwave * TMW) * 256;
+            // ---- partial tiles -> the cluster's exchange [gate][row tile of the part][column tile] (row-major 16 x 16, one
+            // write-through 16-byte store per lane)
+            const size_t exc = (size_t)cluster * 4 * nslots;          // tiles of this cluster's exchange before its own
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) {
+            for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[0][i][r] + acc[1][i][r];
-                __builtin_amdgcn_wave_barrier();
-                const f32x4 row = *reinterpret_cast<const f32x4*>(zb + (lane >> 2) * ZS + (lane & 3) * 4);
-                __builtin_amdgcn_wave_barrier();
-                const u32x4v bits = __builtin_bit_cast(u32x4v, row);
-                bstore16_sc1(rsEx, bits, (int)(((size_t)(exw - g.ex) + (size_t)i * 256 + lane * 4) * 4), 0);
-            }
+                for (int c = 0; c < NC; ++c) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[0][c][i][r] + acc[1][c][i][r];
+                    __builtin_amdgcn_wave_barrier();
+                    const f32x4 row = *reinterpret_cast<const f32x4*>(zb + (lane >> 2) * ZS + (lane & 3) * 4);
+                    __builtin_amdgcn_wave_barrier();
+                    const int tl = pwave * TMW + i;                    // row tile within the part
+                    if (tl < tpp)
+                        bstore16_sc1(rsEx, __builtin_bit_cast(u32x4v, row), (int)(((exc + (size_t)gate * nslots + (size_t)tl * NC + c) * 256 + lane * 4) * 4), 0);
+                }
             gs.arrive_one(ccount, tid);
             gs.wait_one(ccount, 4u * (arrival + 1u), pwave, lane);
             ++arrival;
-            const float* exr = g.ex + ((size_t)jj * 4 * NT + (size_t)gate * TMW) * 256;
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) {
-                float s = 0.0f;
+            for (int i = 0; i < PS; ++i) {
+                const int slot = gate * psr + i;
+                float s_ = 0.0f;
+                if (i < psr && slot < nslots) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    s += __uint_as_float(__hip_atomic_load((const gu32*)(exr + ((size_t)q * NT + i) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                dh[i] = s;
+                    for (int q = 0; q < 4; ++q)
+                        s_ += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * nslots + slot) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                dh[i] = s_;
             }
         }
-        // ---- BasicLSTMCell backward pointwise (the expressions of lstm_bwd_pointwise_kernel), one (row, unit) per thread
-        float dzv[TMW][4];
+        // ---- BasicLSTMCell backward pointwise (the expressions of lstm_bwd_pointwise_kernel), one (row, unit) per thread and slot
+        float dzv[PS][4];
 #pragma unroll
-        for (int i = 0; i < TMW; ++i) {
+        for (int i = 0; i < PS; ++i) {
             float d = dx[i];
             if (g.keep < 1.0f && g.dext && t >= g.dext_t0)
-                d = (d / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)pu, g.keep);
+                d = (d / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)pu[i], g.keep);
             const float dht = dh[i] + d;
             const float si = sg[i][0], tj = sg[i][1], sf = sg[i][2], so = sg[i][3];
             const float tc = dm_tanhf(cnew[i]);
@@ -555,9 +589,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (t > 0) {
             // ---- dz_t -> the four gate images of the other parity, regrouped through LDS so that every thread writes ONE
             // 16-byte fragment slot: thread (gate q = tid / 64, slot L = tid % 64) takes row L % 16, units L / 16 + 4e
-            float* inext = g.img + (size_t)(t & 1) * 4 * img_floats;
+            const size_t inext = (size_t)(t & 1) * 4 * img_floats;
 #pragma unroll
-            for (int i = 0; i < TMW; ++i) {
+            for (int i = 0; i < PS; ++i) {
+                const int slot = gate * psr + i;
+                if (!(i < psr && slot < nslots)) continue;       // (uniform over the workgroup)
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dzl[(q * 16 + pr) * 17 + pn] = pok[i] ? dzv[i][q] : 0.0f;
@@ -566,17 +602,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 u32x4v w;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(dzl[(q * 16 + r) * 17 + kq + 4 * e]);
-                float* dst = inext + (size_t)q * img_floats + ((size_t)((gate * TMW + i) * NG + jj) * 64 + L) * 4;
-                bstore16_sc1(rsImg, w, (int)((size_t)(dst - g.img) * 4), 0);
+                const size_t dst = inext + (size_t)q * img_floats + ((size_t)((part * tpp + ptile[i]) * NG + jj * NC + pc[i]) * 64 + L) * 4;
+                bstore16_sc1(rsImg, w, (int)(dst * 4), 0);
             }
             gs.arrive(tid);
         }
         // ---- history: dZ[t] (read by the weight-gradient contractions after the launch), then the next step's operands
 #pragma unroll
-        for (int i = 0; i < TMW; ++i) {
+        for (int i = 0; i < PS; ++i) {
             if (!pok[i]) continue;
-            const int m = (gate * TMW + i) * 16 + pr;
-            float* zp = g.dZ + (size_t)t * g.dz_tstride + (size_t)m * 4 * H + pu;
+            float* zp = g.dZ + (size_t)t * g.dz_tstride + (size_t)pm[i] * 4 * H + pu[i];
 #pragma unroll
             for (int q = 0; q < 4; ++q) zp[(size_t)q * H] = dzv[i][q];
         }
@@ -680,20 +715,24 @@ DevState* dev_state()
 
 // ---- backward recurrence: configurations, eligibility, launcher
 typedef void (*BwdFn)(const BwdChainArgs);
-struct BwdCfg { int ng, tmw; BwdFn fn; const char* name; };
+struct BwdCfg { int ng, tmw, nc; BwdFn fn; const char* name; };
 const BwdCfg kBwd[] = {
-    {8, 1, lstm_bwd_chain_kernel<8, 1>, "bchain(ng8,m64)"},    {8, 2, lstm_bwd_chain_kernel<8, 2>, "bchain(ng8,m128)"},
-    {8, 4, lstm_bwd_chain_kernel<8, 4>, "bchain(ng8,m256)"},   {64, 1, lstm_bwd_chain_kernel<64, 1>, "bchain(ng64,m64)"},
-    {64, 2, lstm_bwd_chain_kernel<64, 2>, "bchain(ng64,m128)"}, {64, 4, lstm_bwd_chain_kernel<64, 4>, "bchain(ng64,m256)"},
+    {8, 1, 1, lstm_bwd_chain_kernel<8, 1, 1>, "bchain(ng8,m64)"},     {8, 2, 1, lstm_bwd_chain_kernel<8, 2, 1>, "bchain(ng8,m128)"},
+    {8, 4, 1, lstm_bwd_chain_kernel<8, 4, 1>, "bchain(ng8,m256)"},    {64, 1, 1, lstm_bwd_chain_kernel<64, 1, 1>, "bchain(ng64,m64)"},
+    {64, 2, 1, lstm_bwd_chain_kernel<64, 2, 1>, "bchain(ng64,m128)"}, {64, 4, 1, lstm_bwd_chain_kernel<64, 4, 1>, "bchain(ng64,m256)"},
+    // 32 units x half the row tiles per workgroup (tmw = row tiles per wave of a part): 257 .. 384 rows
+    {64, 3, 2, lstm_bwd_chain_kernel<64, 3, 2>, "bchain2(ng64,m384)"},
 };
 constexpr int kNumBwd = (int)(sizeof(kBwd) / sizeof(kBwd[0]));
-int bwd_lds_bytes(const BwdCfg& c) { return (c.ng * 256 + 4 * 16 * 20 + 4 * 16 * 17) * 4; }
+int bwd_lds_bytes(const BwdCfg& c) { return (c.ng * c.nc * 256 + 4 * 16 * 20 + 4 * 16 * 17) * 4; }
+bool bwd_two_parts(int M, int H) { return M > 256 && (H + 15) / 16 > 8; }
 int bwd_cfg(int M, int H)
 {
     const int ng = (H + 15) / 16 <= 8 ? 8 : 64;
-    const int tmw = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
+    const bool two = bwd_two_parts(M, H);
+    const int tmw = two ? 3 : (M <= 64 ? 1 : (M <= 128 ? 2 : 4)), nc = two ? 2 : 1;
     for (int i = 0; i < kNumBwd; ++i)
-        if (kBwd[i].ng == ng && kBwd[i].tmw == tmw) return i;
+        if (kBwd[i].ng == ng && kBwd[i].tmw == tmw && kBwd[i].nc == nc) return i;
     return -1;
 }
 struct BwdDev { std::once_flag once; bool ok = false; int per_cu[kNumBwd] = {}; };
@@ -815,7 +854,7 @@ bool chain_operands_ok(const float* W, int ldw, const float* abuf)
 }
 
 
-constexpr int kBwdMaxRows = 256;
+constexpr int kBwdMaxRows = 384;
 
 bool bwd_chain_eligible(int M, int H)
 {
@@ -827,24 +866,36 @@ bool bwd_chain_eligible(int M, int H)
     if (!(M >= 1 && M <= kBwdMaxRows && H >= 4 && (H & 3) == 0 && H <= 1024)) return false;
     const int ci = bwd_cfg(M, H);
     if (ci < 0) return false;
-    const int ncg = (H + 15) / 16;
-    return (long)b->per_cu[ci] * d->num_cus >= 4L * ncg;        // every ACTIVE workgroup fits on the chip at once
+    const int nc = kBwd[ci].nc, ncg = (H + 16 * nc - 1) / (16 * nc);
+    return (long)b->per_cu[ci] * d->num_cus >= 4L * nc * ncg;   // every ACTIVE workgroup fits on the chip at once
 }
 
 bool bwd_chain_auto(int M, int H)
 {
-    static const int maxm = [] { const char* e = getenv("S2VT_BCHAIN_MAXM"); return e ? atoi(e) : 128; }();  // rows up to which the persistent form is chosen unasked
-    return M <= maxm && bwd_chain_eligible(M, H);
+    static const int maxm = [] { const char* e = getenv("S2VT_BCHAIN_MAXM"); return e ? atoi(e) : 128; }();  // rows up to which the one-part form is chosen unasked
+    static const bool two = [] { const char* e = getenv("S2VT_BCHAIN2"); return !(e && e[0] == '0'); }();      // the two-part form (257 .. 384 rows)
+    return (M <= maxm || (two && bwd_two_parts(M, H))) && bwd_chain_eligible(M, H);
+}
+
+// geometry of a launch: column tiles per workgroup, row tiles per part, unit groups
+static void bwd_geometry(int M, int H, int* nc, int* tmw, int* tpp, int* ncg)
+{
+    const bool two = bwd_two_parts(M, H);
+    const int tiles = (M + 15) / 16;
+    *nc = two ? 2 : 1;
+    *tmw = two ? 3 : (M <= 64 ? 1 : (M <= 128 ? 2 : 4));
+    *tpp = two ? (tiles + 1) / 2 : 4 * *tmw;
+    *ncg = (H + 16 * *nc - 1) / (16 * *nc);
 }
 
 void bwd_chain_scratch(int H, int M, size_t* img_floats, size_t* ex_floats, size_t* sync_bytes)
 {
     const int ng = (H + 15) / 16 <= 8 ? 8 : 64;
-    const int tmw = M <= 64 ? 1 : (M <= 128 ? 2 : 4);
-    const int ncg = (H + 15) / 16;
-    *img_floats = (size_t)8 * 4 * tmw * ng * 256;
-    *ex_floats = (size_t)ncg * 4 * 4 * tmw * 256;
-    *sync_bytes = kChainSyncBytes + (size_t)ncg * 128;
+    int nc, tmw, tpp, ncg;
+    bwd_geometry(M, H, &nc, &tmw, &tpp, &ncg);
+    *img_floats = (size_t)8 * nc * tpp * ng * 256;                             // 2 parities x 4 gates x (parts * tpp) row tiles
+    *ex_floats = (size_t)ncg * nc * 4 * tpp * nc * 256;                        // clusters x 4 gates x (row tile, column tile) slots
+    *sync_bytes = kChainSyncBytes + (size_t)ncg * nc * 128;
 }
 
 hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
@@ -868,7 +919,9 @@ hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
     k.video_id = a.video_id; k.sample_id = a.sample_id;
     k.img = a.img; k.ex = a.ex; k.sync = a.sync;
     k.status = g_status_dev; k.fault = d->fault; k.spin_limit = spin_limit();
-    k.ncg = (a.H + 15) / 16;
+    int nc_, tmw_, tpp_, ncg_;
+    bwd_geometry(a.M, a.H, &nc_, &tmw_, &tpp_, &ncg_);
+    k.ncg = ncg_; k.tpp = tpp_; k.img_tiles = nc_ * tpp_;
     size_t imgf, exf, syncb;
     bwd_chain_scratch(a.H, a.M, &imgf, &exf, &syncb);
     std::lock_guard<std::mutex> lk(g_launch_mu);
@@ -880,7 +933,7 @@ hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.img, 0, imgf * 4, st);                // rows >= M and k >= H of the images must read as zeros
     if (e != hipSuccess) return e;
-    const dim3 grid((unsigned)((k.ncg + 7) / 8 * 32));
+    const dim3 grid((unsigned)((k.ncg + 7) / 8 * 32 * nc_));
     const double flops = 2.0 * a.M * (double)a.H * 4.0 * a.H * (a.T - 1);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = prof_wants(6, ci);

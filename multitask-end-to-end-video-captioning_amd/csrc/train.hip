@@ -57,6 +57,19 @@ SlabPlan slab_plan(int M, int H)
     return p;
 }
 
+// scratch of the persistent backward recurrence for any row count up to Mmax (the one- and two-part forms lay it out differently)
+void bwd_scratch_max(int H, int Mmax, size_t* imgf, size_t* exf, size_t* syncb)
+{
+    *imgf = *exf = *syncb = 0;
+    for (int m : {64, 128, 256, 384}) {
+        size_t a, b, s;
+        bwd_chain_scratch(H, Mmax < m ? Mmax : m, &a, &b, &s);
+        if (a > *imgf) *imgf = a;
+        if (b > *exf) *exf = b;
+        if (s > *syncb) *syncb = s;
+    }
+}
+
 size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
 {
     const size_t H = d->lstm_dim, E = d->word_dim, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
@@ -78,7 +91,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
     {
         size_t imgf, exf, syncb;
-        bwd_chain_scratch((int)H, N < 256 ? N : 256, &imgf, &exf, &syncb);       // (sized for the larger of the two recurrences: N >= B rows)
+        bwd_scratch_max((int)H, N, &imgf, &exf, &syncb);       // (sized for the larger of the two recurrences: N >= B rows)
         w.bimg = c.take<float>(imgf); w.bex = c.take<float>(exf); w.bsync = c.take<unsigned>(syncb / 4);
     }
     if (out) *out = w;
@@ -189,7 +202,7 @@ size_t s2vt_lstm_recurrence_bwd_scratch_bytes(int32_t M, int32_t H)
     if (M <= 0 || H <= 0) return 0;
     Carver c(nullptr, 0);
     size_t imgf, exf, syncb;
-    bwd_chain_scratch(H, M < 256 ? M : 256, &imgf, &exf, &syncb);
+    bwd_scratch_max(H, M, &imgf, &exf, &syncb);
     c.take<float>((size_t)kMaxSlabs * M * H); c.take<float>((size_t)M * H);
     c.take<float>(imgf); c.take<float>(exf); c.take<unsigned>(syncb / 4);
     return c.off;
@@ -207,7 +220,7 @@ int s2vt_lstm_recurrence_bwd(const float* W, int32_t kw0, const float* gates, co
     if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     Carver c(scratch, scratch_bytes);
     size_t imgf, exf, syncb;
-    bwd_chain_scratch(H, M < 256 ? M : 256, &imgf, &exf, &syncb);
+    bwd_scratch_max(H, M, &imgf, &exf, &syncb);
     BwdScratch sc;
     sc.slab = c.take<float>((size_t)kMaxSlabs * M * H); sc.dc = c.take<float>((size_t)M * H);
     sc.bimg = c.take<float>(imgf); sc.bex = c.take<float>(exf); sc.bsync = c.take<unsigned>(syncb / 4);

@@ -227,6 +227,9 @@ BWD_SHAPES = [  # M, E, H, T, first step with an upstream gradient
     (100, 8, 64, 4, 0), (128, 500, 1000, 6, 2),          # two row tiles per wave
     (200, 16, 136, 3, 0), (256, 500, 1000, 3, 1),        # four row tiles per wave (persistent = 1 only: auto stops at 128 rows)
     (64, 8, 1024, 3, 0),                                  # H = 1024: 64 unit groups x 4 gates = every CU
+    # above 256 rows: the two-part form (32 units x half the row tiles per workgroup)
+    (320, 500, 1000, 25, 5),                              # LSTM2 of build_loss at K * B = 320 rows: parts of 10 row tiles
+    (384, 8, 1000, 3, 0), (260, 16, 136, 4, 1), (300, 8, 1024, 3, 1),
 ]
 
 
@@ -249,7 +252,7 @@ def test_persistent_backward_recurrence(gpu, M, E, H, T, t0, keep):
         assert gpu.chain_timeouts() == 0
         scale = ref.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
         assert float(((got - ref).abs() / scale).max()) <= 2e-5, rep
-    if M <= 128:
+    if M <= 128 or (M > 256 and H > 128):
         auto = gpu.lstm_recurrence_bwd(Wd, E, gates, C, persistent=-1, **args)
         assert torch.equal(auto, got)                       # auto takes the persistent form here (deterministic: no atomics)
     # float64 restatement
