@@ -349,7 +349,7 @@ def main():
             ach = dom["total_flops"] / (dom["total_ms"] * 1e-3) / 1e12
             cls = {0: "contraction+store", 1: "fused LSTM cell (4-gate GEMM + pointwise epilogue)", 2: "vocab logits + Gumbel-max pick",
                    3: "weight-gradient TN contraction", 4: "contraction+store, W^T operand (backward data gradients)",
-                   5: "persistent LSTM recurrence"}.get(dom["kernel_class"], "?")
+                   5: "persistent LSTM recurrence", 6: "persistent LSTM backward recurrence"}.get(dom["kernel_class"], "?")
             traffic, traffic_src = stored_traffic(dom["kernel_class"], dom["name"])
             # flops the contraction kernels actually executed per step (hoisting, LSTM1 once per video and sampler-state
             # reuse execute fewer than the algorithmic count), from the warm-up table

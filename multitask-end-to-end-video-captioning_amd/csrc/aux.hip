@@ -661,7 +661,8 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
                      (a.ldb & 3) == 0 && (a.Kout & 3) == 0 && (a.N & 3) == 0 &&
                      // the vector path addresses a chunk (32 rows) of each operand by 32-bit byte offsets from a base it
                      // re-computes per chunk; a gathered A must fit a 2 GiB window (its extent is the caller's table)
-                     (size_t)32 * a.lda * 4 < (1ull << 31) && (size_t)32 * a.ldb * 4 < (1ull << 31);
+                     (size_t)32 * a.lda * 4 < (1ull << 31) && (size_t)32 * a.ldb * 4 < (1ull << 31) &&
+                     !(a.rowidx && a.gather_rows > 0 && (size_t)a.gather_rows * a.lda * 4 >= (1ull << 31));
     // the 128x128 vector path stages by LDS-DMA (rows must be 16-byte aligned, which `vec` already says)
     static const int use_dma = [] { const char* e = getenv("S2VT_TN_DMA"); return e ? atoi(e) : 1; }();       // dev knob
     const bool dma_on = vec && use_dma >= 1 && use_dma <= (int)(sizeof(kTnDma) / sizeof(kTnDma[0]));

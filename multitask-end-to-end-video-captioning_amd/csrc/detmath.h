@@ -167,6 +167,14 @@ __device__ __forceinline__ uint32_t quad_word_from(const u32x4& mine, uint32_t e
     return e == 0 ? x : e == 1 ? y : e == 2 ? z : w;
 }
 __device__ __forceinline__ float gumbel_from_word(uint32_t word) { return -dm_logf(-dm_logf(u01(word))); }
+// The same value to ~1e-5 absolute from two v_log_f32 (1 ulp log2): only ever used to SCREEN candidates for the exact
+// expression above (gemm_mfma.h, PICK epilogue) -- never decides a token.  u in [2^-24, 1 - 2^-24] keeps both logs normal.
+constexpr float kGumbelScreenMargin = 1.0e-3f;       // >= 50 x the worst |fast - exact| + the rounding of logit + noise
+__device__ __forceinline__ float gumbel_fast_from_word(uint32_t word)
+{
+    const float l = -0.693147180559945f * __builtin_amdgcn_logf(u01(word));
+    return -0.693147180559945f * __builtin_amdgcn_logf(l);
+}
 
 // DropoutWrapper keep decision (reference tf_s2vt.py:75,77: floor(keep + U[0,1)) ) from the dropout
 // stream: key (seed_lo, seed_hi ^ 'DROP'), counter (unit>>2, video, sample, code), code =

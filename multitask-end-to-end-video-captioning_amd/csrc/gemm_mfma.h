@@ -959,6 +959,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
             }
             const int sid_own = e4 == 0 ? sid[0] : e4 == 1 ? sid[1] : e4 == 2 ? sid[2] : sid[3];
             const int vid_own = e4 == 0 ? vid[0] : e4 == 1 ? vid[1] : e4 == 2 ? vid[2] : vid[3];
+#ifdef S2VT_PICK_EXACT_ALL     // dev A/B: the exact noise for every element (the form before the two-tier screen)
             float best[4];
             uint32_t bidx[4];
             bool have[4];
@@ -988,6 +989,95 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     }
                 }
             }
+#else
+            float best[4];
+            uint32_t bidx[4];
+            bool have[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { best[r] = 0.0f; bidx[r] = 0xFFFFFFFFu; have[r] = false; }
+            // Two-tier Gumbel-max (exact result, ~1/3 of the noise arithmetic).  The exact key of an element is
+            //     v = (acc + bias) + gumbel_from_word(word);  v = v + 0.0f
+            // -- two Cephes logs per element, 8 us of VALU per launch when done for all 24 elements of a lane.  Tier 1 keys
+            // every element with a FAST Gumbel value (two v_log_f32, |fast - exact| << kGumbelScreenMargin) and takes the
+            // row maximum over the workgroup tile's columns this wave holds.  An element whose fast key is more than
+            // 2 x margin below that maximum cannot be the exact maximum of the row (the fast key of the exact winner is
+            // within the margin of its exact key, and the fast maximum is at least that).  Tier 2 evaluates the EXACT
+            // expression -- the same instruction sequence as before -- only for the survivors: per row typically ONE
+            // element of the lane's TN (its fast-best), any other survivor in a guarded rare path.  Ties and order:
+            // (v > best) or (v == best and col < bidx), i.e. the lowest column among equal keys, as the ascending scan gave.
+            float v0[TN][4], ka[TN][4];
+            uint32_t wd[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 16 + l15;
+                u32x4 blk = {0u, 0u, 0u, 0u};
+#ifndef S2VT_PICK_NONOISE
+                if (sid_own >= 0)
+                    blk = philox4x32_10((uint32_t)col >> 2, (uint32_t)vid_own, (uint32_t)sid_own, (uint32_t)g.step, g.seed_lo,
+                                        g.seed_hi);
+#endif
+                wd[j][0] = quad_word_from<0>(blk, e4);
+                wd[j][1] = quad_word_from<1>(blk, e4);
+                wd[j][2] = quad_word_from<2>(blk, e4);
+                wd[j][3] = quad_word_from<3>(blk, e4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow + r;
+                    const bool ok = m < g.M && col < g.N;
+                    const float v = acc[i][j][r] + ep_bias[j];
+                    v0[j][r] = v;
+                    if (ok && g.logits_out) g.logits_out[(size_t)m * g.ldc + col] = v;
+                    float k = v;
+#ifndef S2VT_PICK_NONOISE       // (dev ablation)
+                    if (sid[r] >= 0) k = v + gumbel_fast_from_word(wd[j][r]);
+#endif
+                    ka[j][r] = ok ? k : -__builtin_inff();
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // fast row maximum: this lane's TN columns, then the 16 lanes that hold the row
+                float mx = ka[0][r];
+                int js = 0;
+#pragma unroll
+                for (int j = 1; j < TN; ++j)
+                    if (ka[j][r] > mx) { mx = ka[j][r]; js = j; }
+                float rmx = mx;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, off, 64));
+                const float thr = rmx - 2.0f * kGumbelScreenMargin;
+                // the lane's fast-best element of this row
+                float vs = v0[0][r];
+                uint32_t ws = wd[0][r];
+#pragma unroll
+                for (int j = 1; j < TN; ++j)
+                    if (js == j) { vs = v0[j][r]; ws = wd[j][r]; }
+                const int cols = n0 + (wn * TN + js) * 16 + l15;
+                const bool okr = mrow + r < g.M;
+                if (okr && cols < g.N && !(mx < thr)) {
+                    float v = vs;
+#ifndef S2VT_PICK_NONOISE
+                    if (sid[r] >= 0) v = v + gumbel_from_word(ws);
+#endif
+                    v = v + 0.0f;  // -0 -> +0 so that the integer order equals the float order
+                    best[r] = v; bidx[r] = (uint32_t)cols; have[r] = true;
+                }
+                // rare: a second element of this lane's row within the margin
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + (wn * TN + j) * 16 + l15;
+                    const bool extra = okr && col < g.N && j != js && !(ka[j][r] < thr);
+                    if (__any(extra)) {
+                        if (extra) {
+                            float v = v0[j][r];
+                            if (sid[r] >= 0) v = v + gumbel_from_word(wd[j][r]);
+                            v = v + 0.0f;
+                            if (!have[r] || v > best[r] || (v == best[r] && (uint32_t)col < bidx[r])) { best[r] = v; bidx[r] = (uint32_t)col; have[r] = true; }
+                        }
+                    }
+                }
+            }
+#endif
             S2VT_STAMP_AT(10);                     // (dev build) noise + per-lane argmax
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -999,7 +1089,11 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     const unsigned long long o = __shfl_xor(key, off, 64);
                     key = o > key ? o : key;
                 }
+#ifndef S2VT_PICK_NOATOMIC      // (dev ablation)
                 if (l15 == 0 && m < g.M && key != 0ull) atomicMax(&g.pick[(size_t)m * (g.pick_stride > 0 ? g.pick_stride : 1)], key);
+#else
+                if (l15 == 0 && m < g.M && key == 1ull) g.pick[(size_t)m * (g.pick_stride > 0 ? g.pick_stride : 1)] = key;
+#endif
             }
             S2VT_STAMP_AT(11);                     // (dev build) lane reduction + atomics
         }

@@ -33,6 +33,8 @@ struct TnArgs {
     int Mred, Kout, N;
     int accumulate;                                    // 1: C += result (fp32 atomics when split)
     float* colsum;                                     // optional [N]: += column sums of B (bias gradient), see launch_gemm_tn
+    int gather_rows;                                   // rows of the table `rowidx` indexes (0 = not stated by the caller): the vector paths form
+                                                       // rowidx * lda * 4 in 32 bits, so a table known to reach 2 GiB takes the scalar (64-bit) path
 };
 // colsum: when given, the column sums of B are ADDED to it -- inside the contraction on the vector path, by a colsum launch
 // otherwise (so callers never launch one themselves).

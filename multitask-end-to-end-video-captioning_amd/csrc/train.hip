@@ -426,6 +426,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         HIP_TRY(launch_gemm_tn(a, sd));
         TnArgs b{p->Wemb, w.prev, E, w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, grads->lstm2_W + (size_t)H * 4 * H, 4 * H, Tc * N, E,
                  4 * H, 1};
+        b.gather_rows = V;                                  // Wemb [V, E]
         HIP_TRY(launch_gemm_tn(b, sd));
         TnArgs e{w.H2, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, T * N, H, 4 * H, 1};
         e.colsum = grads->lstm2_b;
@@ -448,6 +449,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
     // ---- remaining weight gradients: one contraction over all unrolled steps per weight block
     {
         TnArgs f{w.emb, w.encidx, E, w.dZ1, 4 * H, grads->lstm1_W, 4 * H, Tv * B, E, 4 * H, 1};
+        f.gather_rows = Tv * B;
         HIP_TRY(launch_gemm_tn(f, st));
         TnArgs g{w.H1, nullptr, H, w.dZ1, 4 * H, grads->lstm1_W + (size_t)E * 4 * H, 4 * H, T * B, H, 4 * H, 1};
         g.colsum = grads->lstm1_b;
@@ -456,6 +458,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         HIP_TRY(launch_scatter_add_rows(w.dX2 + (size_t)Tv * N * (H + E) + H, H + E, w.prev, Tc * N, E, grads->Wemb, E, st));
         // frame embedding
         TnArgs h{video, w.encidx, D, w.dX1, E, grads->encode_image_W, E, Tv * B, D, E, 1};
+        h.gather_rows = Tv * B;
         h.colsum = grads->encode_image_b;
         HIP_TRY(launch_gemm_tn(h, st));
     }
