@@ -33,6 +33,8 @@ SHAPES = [  # M, E, H, T, steps with a carried partial
     (320, 500, 1000, 25, 25),                     # LSTM2 of build_loss at K * B = 320 rows: parts of 10 row tiles, 3 / 3 / 3 / 1 per wave
     (384, 500, 1000, 4, 2), (200, 500, 1000, 3, 3),   # 12 tiles per part (3 per wave); 13 row tiles: parts of 7 and 6
     (128, 500, 1000, 3, 3), (96, 16, 136, 3, 1),      # one row tile per wave; a part whose last waves are idle (3 tiles)
+    # above 256 rows: the register-weights form (chain4: 16 units x a quarter of the row tiles per workgroup, A through LDS)
+    (257, 16, 136, 3, 1), (300, 8, 1000, 3, 2), (336, 8, 1024, 3, 0), (384, 500, 1000, 25, 25), (321, 8, 264, 4, 4),
     (100, 8, 132, 3, 1),                              # H % 8 != 0: the one-part form at two row tiles per wave, 64 k groups
 ]
 
@@ -282,3 +284,42 @@ def gpu_mask(gpu, seed, video, sample, code, keep, H):
     import torch
     ones = torch.ones((len(video), H), dtype=torch.float32, device="cuda")
     return (gpu.dropout_bwd(ones, keep, seed, code, _dev(video), _dev(sample)) > 0).double().cpu().numpy()
+
+
+CHILD_FORMS = r"""
+import os, sys
+sys.path.insert(0, os.environ["S2VT_ROOT"]); sys.path.insert(0, os.path.join(os.environ["S2VT_ROOT"], "tests"))
+import numpy as np, torch
+import s2vt_amd
+from s2vt_amd import ops
+from test_gpu_chain import _case, _dev
+for (M, E, H, T, cs) in ((320, 500, 1000, 6, 6), (384, 8, 1000, 3, 1), (260, 16, 136, 3, 0)):
+    W, b, h0, c0, cinit, vid, sid = _case(M, E, H, T, cs, seed=M)
+    args = dict(T=T, cinit=_dev(cinit) if cs else None, cinit_steps=cs, keep=0.9, seed=3, video_id=_dev(vid), sample_id=_dev(sid), drop_code0=512,
+                want_gates=True, want_out=True)
+    ref = ops.lstm_recurrence_fwd(_dev(W), E, _dev(b), _dev(h0), _dev(c0), persistent=0, **args)
+    got = ops.lstm_recurrence_fwd(_dev(W), E, _dev(b), _dev(h0), _dev(c0), persistent=1, **args)
+    assert ops.chain_timeouts() == 0
+    for r, g in zip(ref, got):
+        assert torch.equal(r, g), (M, H)
+    # an unaligned weight matrix (persistent = -1): per-step launches, same bits
+    Wu = torch.empty(W.size + 1, dtype=torch.float32, device="cuda")[1:].view(W.shape); Wu.copy_(_dev(W))
+    assert Wu.data_ptr() % 16 != 0
+    auto = ops.lstm_recurrence_fwd(Wu, E, _dev(b), _dev(h0), _dev(c0), persistent=-1, **args)
+    for r, g in zip(ref, auto):
+        assert torch.equal(r, g), ("unaligned", M, H)
+print("child ok")
+"""
+
+
+def test_two_part_form_above_256_rows_and_unaligned_weights(gpu):
+    """With the register-weights form switched off (S2VT_CHAIN4=0) the two-part form serves 257-384 rows: still bit-identical
+    to per-step launches.  And persistent = -1 with a weight matrix that is not 16-byte aligned falls back to per-step
+    launches instead of failing."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", CHILD_FORMS], env=dict(os.environ, S2VT_ROOT=root, S2VT_CHAIN4="0"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "child ok" in r.stdout, f"rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
