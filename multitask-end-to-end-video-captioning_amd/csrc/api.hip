@@ -228,6 +228,14 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
     t.vid = c.take<int32_t>(R); t.sid = c.take<int32_t>(R); t.bos = c.take<int32_t>(R);
     t.chain_sync = c.take<unsigned>(kChainSyncBytes / 4);
     t.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
+    t.wemb_p = t.w2_p = t.himg[0] = t.himg[1] = nullptr;
+    if (R > 256 && R <= 384 && (size_t)d->n_words * ((E + 15) / 16 * 16) * 4 < (1ull << 31)) {      // (sized by shape alone: the same carve whatever the device says)
+        Dec4Geom q;
+        decode4_geometry(R, (int)H, (int)E, &q);
+        t.wemb_p = c.take<float>((size_t)d->n_words * q.erow);
+        t.w2_p = c.take<float>((size_t)q.ncg * 4 * q.ngt * 256);
+        for (int i = 0; i < 2; ++i) t.himg[i] = c.take<float>((size_t)q.img_tiles * q.hgp * 256);
+    }
     if (w) *w = t;
     return c.off;
 }
@@ -320,8 +328,33 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
     NoiseIds ids{w.vid, w.sid, seed};
     const size_t enc = (size_t)Tv * B * H;   // where sample_encode left the encoder state: slot Tv of the history
     int cur2 = 0;
+    // 257-384 rows: the LSTM2 step runs on fragment-order operands packed once per call (decode4.hip); same chain, same bits
+    const bool dec4 = w.wemb_p && decode4_eligible(R, H, E);
+    Dec4Geom q4;
+    if (dec4) {
+        decode4_geometry(R, H, E, &q4);
+        HIP_TRY(decode4_pack(p->Wemb, p->lstm2_W, V, H, E, q4, w.wemb_p, w.w2_p, st));
+        HIP_TRY(decode4_state_to_image(w.h2e + enc, B, R, H, q4, w.himg[0], st));
+        HIP_TRY(hipMemsetAsync(w.himg[1], 0, (size_t)q4.img_tiles * q4.hgp * 1024, st));
+    }
     for (int t = 0; t < Tc; ++t) {
         const int nxt2 = cur2 ^ 1;
+        if (dec4) {
+            Dec4Launch a;
+            std::memset(&a, 0, sizeof(a));
+            a.wemb_p = w.wemb_p; a.w2_p = w.w2_p; a.bias = p->lstm2_b;
+            a.cinit = w.P2 + (size_t)(Tv + t) * 4 * BH; a.ldcinit = 4 * H; a.cinit_rowmod = B;
+            a.tok = t == 0 ? nullptr : w.packed + (size_t)(t - 1) * R * kPickStride; a.tok_stride = kPickStride; a.tok_const = 1;     // <bos> = 1
+            a.himg_in = w.himg[t & 1]; a.himg_out = w.himg[(t + 1) & 1];
+            a.c_prev = t == 0 ? w.c2e + enc : w.c2[cur2]; a.cprev_rowmod = t == 0 ? B : 0;
+            a.c_new = w.c2[nxt2]; a.h_new = w.h2[nxt2];
+            a.R = R; a.H = H; a.E = E; a.V = V;
+            HIP_TRY(launch_decode_lstm4(a, q4, st));
+            HIP_TRY(pick_call(w.h2[nxt2], H, p->embed_word_W, p->embed_word_b, R, H, V, ids, t, w.packed + (size_t)t * R * kPickStride,
+                              nullptr, -1, st, kPickStride));
+            cur2 = nxt2;
+            continue;
+        }
         const float* h2p = t == 0 ? w.h2e + enc : w.h2[cur2];
         const float* c2p = t == 0 ? w.c2e + enc : w.c2[cur2];
         const int smod = t == 0 ? B : 0;

@@ -126,6 +126,7 @@ struct SampleWs {
     int32_t *vid, *sid, *bos;
     float* chain_abuf;       // persistent-recurrence scratch (chain.hip): fragment images of h + arrival counters
     unsigned* chain_sync;
+    float *wemb_p, *w2_p, *himg[2];   // fragment-order operands of the decode loop's LSTM2 step (decode4.hip); NULL when R is outside its range
 };
 
 // One LSTM recurrence of T steps on M rows: ONE persistent launch when the shape fits (chain_eligible), else T

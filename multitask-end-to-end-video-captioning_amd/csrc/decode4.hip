@@ -1,0 +1,442 @@
+// decode4.hip -- the sampler's LSTM2 step at 257-384 rows (the K multinomial + 1 greedy decodes of
+// reinforcement_multisampling_tf_s2vt.py:318-337 advance together: R = (K + 1) B rows) on operands that are ALREADY in MFMA
+// fragment order, so that the main loop is the one of the register-weights recurrence (chain.hip, lstm_chain4_kernel): no
+// register staging, no ds_write pass, no address arithmetic between the MFMAs.
+//
+//   z[R, 4H] = P2_t[row % B]  (+)  embed(word_{t-1}) @ W2[H : H+E]  (+)  h2_{t-1} @ W2[H+E : ]      (tf_s2vt.py:143; one
+//   ascending-k chain per output: carried partial, then the embedding rows, then the recurrent rows -- the order of the
+//   generic step kernel, bit for bit)
+//
+// * workgroup (j, part): 16 hidden units x a quarter of the row tiles; wave w owns column tile w = units 16j + 4w .. +3 of all
+//   four gates (the gates of a unit meet inside the wave, as in chain.hip); TPP row tiles per wave.
+// * operands, packed once per sampler call (the weights change every training step, the decode loop runs 20 steps on them):
+//     Wemb'  [V][EG x 16]     embedding rows with k permuted inside each group of 16 (position lq*4 + e holds k = 16g + 4e + lq),
+//                             so the A fragment of (row, k-group) is 16 contiguous bytes of the row: the gather of
+//                             tf.nn.embedding_lookup becomes a per-lane source offset of an LDS-DMA load;
+//     W2'    [j][w][G][64][4]  B fragments of every (unit group, wave, k-group): 1 KB lane-linear blocks;
+//     h2 image [tile][g][64][4] the state in A-fragment order, written by the previous step's epilogue (ping-pong).
+// * every k-group of a chunk goes global -> LDS by `buffer_load_dwordx4 ... lds` (TPP A pieces + the four waves' B pieces,
+//   1 KB each, every wave issues a quarter), a ring of chunk buffers, one barrier per chunk, counted vmcnt; chunks past the
+//   end are issued out of range (zeros, still counted) so the loop has one steady state.
+// * epilogue: BasicLSTMCell pointwise (the expression sequence of EPI_LSTM / chain.hip), c_t row-major, h_t BOTH as the next
+//   image block (one 1-KB fragment block per row tile: this workgroup's 16 units are one k-group) and row-major for the vocab
+//   kernel, staged through LDS so that every store is 16 bytes per lane.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "detmath.h"
+#include "internal.h"
+
+namespace s2vt {
+
+namespace {
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+struct Dec4Args {
+    const float* wemb_p; int erow;                 // Wemb' and its row length in floats (EG * 16)
+    const float* w2_p;                             // W2' [ncg][4][NGt][256]
+    const float* bias;                             // [4H]
+    const float* cinit; int ldcinit; int cinit_rowmod;   // carried partial P2_t [B, 4H] (row % rowmod)
+    const unsigned long long* tok; int tok_stride; // packed pick words of the previous step (token = ~low32), NULL: every row takes tok_const
+    int tok_const;
+    const float* himg_in; float* himg_out;         // state images [tiles][HGp][64][4]
+    const float* c_prev; int cprev_rowmod;         // [*, H]
+    float* c_new; float* h_new;                    // [R, H] row-major
+    int R, H, V;
+    int eg, hg, hgp;                               // k-groups: embedding, recurrent, recurrent padded to the image's group count
+    int ncg;                                       // unit groups = ceil(H / 16)
+};
+
+#define S2VT_D4_CG 8
+#ifndef S2VT_D4_NBUF
+#define S2VT_D4_NBUF 3
+#endif
+constexpr int kCG = S2VT_D4_CG, kNBUF = S2VT_D4_NBUF;   // k-groups per chunk, LDS chunk buffers (NBUF - 1 chunks in flight)
+
+#ifdef S2VT_D4_STAMP
+__device__ unsigned long long d4_stamp_acc[8];
+#define D4_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x == 40 && threadIdx.x == 0) atomicAdd(&d4_stamp_acc[i], n_ - st_prev); st_prev = n_; } while (0)
+#else
+#define D4_STAMP(i) do { } while (0)
+#endif
+template <int TPP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void decode_lstm4_kernel(const Dec4Args g)
+{
+#ifdef S2VT_D4_STAMP
+    unsigned long long st_prev = __builtin_readcyclecounter();
+#endif
+    constexpr int ZS = 20;
+    constexpr int CG = kCG, NBUF = kNBUF;
+    constexpr int PPG = TPP;                                   // LDS pieces (1 KB) per k-group: the TPP row tiles of A (B goes global -> registers)
+    constexpr int CHF = CG * PPG * 256;                        // floats per chunk buffer
+    constexpr int GPW = CG / 4;                                // A groups a wave moves per chunk
+    constexpr int YOUNGER = (NBUF - 2) * GPW * TPP + (NBUF - 1) * CG;   // vector-memory instructions a wave has issued after the A loads of the chunk it is about to use
+    static_assert(YOUNGER <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ab = smem;                                          // [NBUF][CG][PPG][64][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* zb = smem + NBUF * CHF + wave * (16 * ZS);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int H = g.H, R = g.R;
+    // workgroup id -> (unit group, row part): the four parts of a unit group share blockIdx % 8 -- one XCD under round-robin
+    // placement (speed only): they stream the same W2' slice in the same order, so it is fetched into that L2 once
+    const int cg = ((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7), rp = ((int)blockIdx.x >> 3) & 3;
+    if (cg >= g.ncg) return;
+    const int u0 = cg * 16 + wave * 4;
+    const bool wact = u0 < H;
+    const int tb = rp * TPP;
+    const int ech = (g.eg + CG - 1) / CG, hch = (g.hg + CG - 1) / CG, nch = ech + hch;
+    const int ngt = (ech + hch) * CG;                          // k-groups of a W2' stream (both parts padded to whole chunks)
+
+    // ---- per-lane source offsets of the embedding rows: DMA lane L takes row L % 16 of a tile, k-quarter L / 16
+    int tokoff[TPP];
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) {
+        const int m = (tb + i) * 16 + l15;
+        int tk = g.tok_const;
+        if (g.tok && m < R) tk = (int)(~(uint32_t)g.tok[(size_t)m * g.tok_stride]);
+        if (m >= R || tk < 0 || tk >= g.V) tk = 0;             // rows beyond the problem compute on any valid row (never stored)
+        tokoff[i] = tk * g.erow * 4 + lq * 16;
+    }
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wemb_p), 0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsH =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.himg_in + (size_t)tb * g.hgp * 256), 0, TPP * g.hgp * 1024, 0x00020000);
+
+    // chunk c = k-groups c*CG .. c*CG + 3.  Wave w moves the A pieces of group w (all TPP row tiles) and its OWN B fragments
+    // of the four groups: TPP + 4 loads per wave and chunk, every index below either a compile-time constant or `wave`
+    // (a piece list decoded from a running index cost ~30 scalar / vector instructions per piece in front of every
+    // chunk's MFMAs: 82 us per launch against 55 for the kernel this replaces).  A chunk past the end is issued out of
+    // range: zeros, still counted by vmcnt.
+    static_assert(CG % 4 == 0, "whole A groups per wave");
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w2_p + ((size_t)cg * 4 + wave) * ngt * 256), 0, ngt * 1024, 0x00020000);
+    // chunk c = k-groups c*CG .. c*CG + CG - 1, moved as NP pieces per wave: the A pieces of groups w, w + 4, .. (all TPP row
+    // tiles, global -> LDS) and the wave's OWN B fragments of the CG groups (global -> registers: nobody else wants them,
+    // through LDS they were 40 % of the ring's bytes).  Piece j of a chunk is issued BETWEEN the MFMAs of the chunk in
+    // flight (one piece per k-step): issued as a burst at the head of a chunk, 20 loads per wave x 4 waves queue up in front
+    // of the CU's one address unit and no wave starts its MFMAs for ~1800 cycles (40+ cycles per MFMA over the loop).
+    // Every index is a compile-time constant or `wave`; the embedding / state sources differ in operands only, not in
+    // control flow.  A chunk past the end is issued out of range: zeros, still counted by vmcnt.
+    constexpr int NPA = GPW * TPP, NP = NPA + CG;              // pieces per wave and chunk: A first, then B (the vmcnt bookkeeping below)
+    auto issue_piece = [&](auto j_, int c, float* dstb, f32x4* bdst) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_)::value;
+        const int oob = c >= nch ? (int)0x80000000u : 0;           // (uniform)
+        if constexpr (j < NPA) {
+            constexpr int gl = j / TPP, i = j % TPP;
+            const int gq = wave + 4 * gl;                          // group of the chunk
+            const int Ga = c * CG + gq;
+            const bool emb = c < ech;
+            const int Gh = Ga - ech * CG;
+            const bool inr = emb ? Ga < g.eg : Gh < g.hgp;
+            const int vo = (inr ? (emb ? tokoff[i] + Ga * 64 : lane * 16) : (int)0x80000000u) | oob;
+            const int so = (emb || !inr) ? 0 : (Gh + i * g.hgp) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(emb ? rsE : rsH, (lds_ptr)(dstb + (gq * PPG + i) * 256), 16, vo, so, 0, 0);
+        } else {
+            constexpr int gq = j - NPA;
+            const int sb = (oob ? 0 : c * CG) * 1024;
+            bdst[gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (lane * 16) | oob, sb + gq * 1024, 0));
+        }
+    };
+    auto issue_chunk = [&](int c, float* dstb, f32x4* bdst) __attribute__((always_inline)) {
+        static_for<0, NP>([&](auto j_) { issue_piece(j_, c, dstb, bdst); });
+    };
+
+    // ---- carried partial (accumulator layout: lane (column l15, row group lq) holds rows lq*4 + r of a tile), branch-free
+    const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);
+    f32x4 acc[TPP];
+    {
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.cinit), 0, g.cinit ? (int)0x80000000u : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TPP; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (tb + i) * 16 + lq * 4 + r;
+                // (row % B: a wave-uniform remainder per row tile when B is a multiple of 16 -- a per-element integer
+                //  division is ~40 instructions, 24 of them were 4 us in front of every launch)
+                const int mm = g.cinit_rowmod <= 0 ? m
+                               : (g.cinit_rowmod & 15) == 0 ? __builtin_amdgcn_readfirstlane(((tb + i) * 16) % g.cinit_rowmod) + lq * 4 + r
+                                                            : m % g.cinit_rowmod;
+                const int off = (wact && m < R) ? (mm * g.ldcinit + ccol) * 4 : (int)0x80000000u;
+                acc[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, off, 0, 0));
+            }
+    }
+    // c_{t-1} of the (row, unit) pairs this lane finishes (row tile i: row lane / 4, unit lane % 4 of the wave's four)
+    float cpv[TPP];
+    {
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.c_prev), 0, g.c_prev ? (int)0x80000000u : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TPP; ++i) {
+            const int row = (tb + i) * 16 + (lane >> 2);
+            const int prow = g.cprev_rowmod <= 0 ? row
+                             : (g.cprev_rowmod & 15) == 0 ? __builtin_amdgcn_readfirstlane(((tb + i) * 16) % g.cprev_rowmod) + (lane >> 2)
+                                                          : row % g.cprev_rowmod;
+            const int off = (wact && row < R) ? (prow * H + u0 + (lane & 3)) * 4 : (int)0x80000000u;
+            cpv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsP, off, 0, 0));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) { asm volatile("" : "+v"(acc[i])); asm volatile("" : "+v"(cpv[i])); }   // in registers before the DMA ring starts (vmcnt bookkeeping)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    D4_STAMP(0);                                                  // prologue: tokens, carried partial, c_{t-1}
+
+    f32x4 breg[NBUF][CG];                                         // B fragments of the chunks in flight (ring slot = chunk % NBUF, static)
+    static_for<0, NBUF - 1>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        issue_chunk(c, Ab + c * CHF, breg[c]);
+    });
+    for (int c0 = 0; c0 < nch; c0 += NBUF) {
+        static_for<0, NBUF>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            const int c = c0 + k;                                  // (chunks beyond nch: zeros x zeros into the accumulators' +0 -- harmless, and they keep one steady state)
+            // this wave's A loads of chunk c have landed once at most YOUNGER younger instructions are outstanding; then everybody's
+            // have, and everybody is done reading chunk c - 1, whose LDS buffer and register slot chunk c + NBUF - 1 now takes
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+            __syncthreads();
+            if (c == 0) D4_STAMP(1);                               // first chunk in LDS
+            float* const nbuf = Ab + ((k + NBUF - 1) % NBUF) * CHF;
+            f32x4* const nreg = breg[(k + NBUF - 1) % NBUF];
+            static_assert(NP <= CG * 4, "one piece per k-step");
+            const f32x4* ab = reinterpret_cast<const f32x4*>(Ab + k * CHF) + lane;
+            f32x4 a[2][TPP];
+#pragma unroll
+            for (int i = 0; i < TPP; ++i) a[0][i] = ab[i * 64];
+            static_for<0, CG>([&](auto q_) {
+                constexpr int gq = decltype(q_)::value;
+                if constexpr (gq + 1 < CG) {
+#pragma unroll
+                    for (int i = 0; i < TPP; ++i) a[(gq + 1) & 1][i] = ab[((gq + 1) * PPG + i) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    static_for<0, TPP>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gq & 1][i][e], breg[k][gq][e], acc[i], 0, 0, 0);
+                    });
+                    // one piece of chunk c + NBUF - 1 behind this k-step's MFMAs
+                    if constexpr (gq * 4 + e < NP) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(std::integral_constant<int, gq * 4 + e>{}, c + NBUF - 1, nbuf, nreg);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    }
+    D4_STAMP(2);                                                  // chunk loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the out-of-range tail
+    __syncthreads();
+
+    // ---- BasicLSTMCell pointwise (gate order i, j, f, o; forget_bias 1.0 added at run time) -- the EPI_LSTM expressions
+    const int rt = lane >> 2, uu = lane & 3;
+    const int u = u0 + uu;
+    float bi = 0.f, bj = 0.f, bf = 0.f, bo = 0.f;
+    if (wact) { bi = g.bias[u]; bj = g.bias[H + u]; bf = g.bias[2 * H + u]; bo = g.bias[3 * H + u]; }
+    float* const stg = Ab;                                         // [2 arrays (c, h)][TPP][16 rows][16 units]
+    constexpr int ST = TPP * 256;
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 z = *reinterpret_cast<const f32x4*>(zb + rt * ZS + uu * 4);
+        __builtin_amdgcn_wave_barrier();
+        const float cp = cpv[i];
+        const float zi = z[0] + bi, zj = z[1] + bj, zf = z[2] + bf, zo = z[3] + bo;
+        const float si = dm_sigmoidf(zi);
+        const float tj = dm_tanhf(zj);
+        const float sf = dm_sigmoidf(zf + 1.0f);
+        const float so = dm_sigmoidf(zo);
+        const float t1 = cp * sf;
+        const float t2 = si * tj;
+        const float cc = t1 + t2;
+        const float hv = dm_tanhf(cc) * so;
+        float* sp = stg + (i * 16 + rt) * 16 + wave * 4 + uu;
+        sp[0] = cc; sp[ST] = (wact ? hv : 0.0f);                  // (units beyond H: zeros into the image, they multiply zero weights anyway)
+    }
+    D4_STAMP(3);                                                  // pointwise
+    __syncthreads();
+    {
+        // the next image: block (tile, group cg), lane L = kq * 16 + r takes row r, units kq + 4e
+        const __amdgpu_buffer_rsrc_t rsN =
+            __builtin_amdgcn_make_buffer_rsrc(g.himg_out + ((size_t)tb * g.hgp + cg) * 256, 0, TPP * g.hgp * 1024, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < (TPP + 3) / 4; ++q) {
+            const int i = wave + 4 * q;
+            if (i < TPP) {
+                const int r = lane & 15, kq = lane >> 4;
+                u32x4v w4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w4[e] = __float_as_uint(stg[ST + (i * 16 + r) * 16 + kq + 4 * e]);
+                __builtin_amdgcn_raw_buffer_store_b128(w4, rsN, (i * g.hgp * 256 + lane * 4) * 4, 0, 0);
+            }
+        }
+        // row-major c_t, h_t: block (array, tile) = [16 rows][16 units]; lane = (row, quarter) writes 16 bytes
+        const int srow = lane >> 2, sq = lane & 3;
+        const int uq = cg * 16 + sq * 4;
+        const __amdgpu_buffer_rsrc_t rsC2 = __builtin_amdgcn_make_buffer_rsrc(g.c_new, 0, (int)0x80000000u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsH2 = __builtin_amdgcn_make_buffer_rsrc(g.h_new, 0, (int)0x80000000u, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < (2 * TPP + 3) / 4; ++q) {
+            const int bidx = wave + 4 * q;
+            if (bidx < 2 * TPP) {
+                const int arr = bidx / TPP, i = bidx % TPP;
+                const int row = (tb + i) * 16 + srow;
+                const bool ok = row < R && uq < H;
+                const u32x4v v = __builtin_bit_cast(u32x4v, *reinterpret_cast<const f32x4*>(stg + arr * ST + (i * 16 + srow) * 16 + sq * 4));
+                const int ho = ok ? (row * H + uq) * 4 : (int)0x80000000u;
+                if (arr == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rsC2, ho, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(v, rsH2, ho, 0, 0);
+            }
+        }
+    }
+    D4_STAMP(4);                                                  // stores issued
+}
+
+// ---- operand packers (once per sampler call)
+__global__ void pack_wemb_kernel(const float* Wemb, int V, int E, int erow, float* out)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)V * erow) return;
+    const int v = (int)(idx / erow), p = (int)(idx % erow);
+    const int grp = p >> 4, q = p & 15, lq = q >> 2, e = q & 3;
+    const int k = 16 * grp + 4 * e + lq;
+    out[idx] = k < E ? Wemb[(size_t)v * E + k] : 0.0f;
+}
+
+// W2' [ncg][4 waves][ngt groups][64 lanes][4]: groups [0, ech*CG) take the embedding rows W2[H + k], the rest the recurrent rows
+__global__ void pack_w2_kernel(const float* W2, int H, int E, int ncg, int ech_groups, int ngt, float* out)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)ncg * 4 * ngt * 256;
+    if (idx >= total) return;
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const size_t blk = idx >> 8;
+    const int G = (int)(blk % ngt), w = (int)((blk / ngt) & 3), j = (int)(blk / ((size_t)ngt * 4));
+    const int lq = lane >> 4, l15 = lane & 15, uu = l15 >> 2, gate = l15 & 3;
+    const int unit = 16 * j + 4 * w + uu;
+    float v = 0.0f;
+    if (unit < H) {
+        if (G < ech_groups) {
+            const int kl = 16 * G + 4 * e + lq;
+            if (kl < E) v = W2[(size_t)(H + kl) * 4 * H + (size_t)gate * H + unit];
+        } else {
+            const int kl = 16 * (G - ech_groups) + 4 * e + lq;
+            if (kl < H) v = W2[(size_t)(H + E + kl) * 4 * H + (size_t)gate * H + unit];
+        }
+    }
+    out[idx] = v;
+}
+
+// h [B, H] (row % B) -> image [tiles][hgp][64][4]; rows >= R and k >= H are zero
+__global__ void state_to_image_kernel(const float* h, int B, int R, int H, int tiles, int hgp, float* img)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)tiles * hgp * 256) return;
+    const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const size_t blk = idx >> 8;
+    const int grp = (int)(blk % hgp), tile = (int)(blk / hgp);
+    const int m = tile * 16 + (lane & 15), k = 16 * grp + 4 * e + (lane >> 4);
+    img[idx] = (m < R && k < H) ? h[(size_t)(m % B) * H + k] : 0.0f;
+}
+
+typedef void (*Dec4Fn)(const Dec4Args);
+struct Dec4Cfg { int tpp; Dec4Fn fn; const char* name; };
+const Dec4Cfg kDec4[] = {{5, decode_lstm4_kernel<5>, "dec4(m320)"}, {6, decode_lstm4_kernel<6>, "dec4(m384)"}};
+int dec4_lds_bytes(int tpp) { return (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4; }
+std::once_flag g_dec4_once;
+bool g_dec4_ok = false;
+
+}  // namespace
+
+bool decode4_eligible(int R, int H, int E)
+{
+    // OPT-IN (S2VT_DEC4=1).  Measured on MI355X at R = 384, H = 1000, E = 500 (profiles/r03_dec4_probe.jsonl): 55.2 us per
+    // launch against 55.4 for the gate-per-wave tile it would replace -- no gain.  In-kernel stamps: prologue (token, partial
+    // and c_{t-1} loads, cold instruction cache) 6 us, first chunk 3.4 us, chunk loop 37.6 us = 39 cycles per MFMA (32 is the
+    // pipe's rate; the register-weights recurrence, same inner loop without the B stream, runs 36.5), pointwise 2.6 us.
+    static const bool on = [] { const char* e = getenv("S2VT_DEC4"); return e && e[0] == '1'; }();
+    if (!on || R <= 256 || R > 384 || (H & 3) || H < 132 || E < 1) return false;
+    std::call_once(g_dec4_once, [] {
+        bool ok = true;
+        for (const Dec4Cfg& c : kDec4)
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, dec4_lds_bytes(c.tpp)) == hipSuccess;
+        g_dec4_ok = ok;
+    });
+    return g_dec4_ok;
+}
+
+void decode4_geometry(int R, int H, int E, Dec4Geom* o)
+{
+    o->eg = (E + 15) / 16; o->hg = (H + 15) / 16;
+    o->ech = (o->eg + kCG - 1) / kCG; o->hch = (o->hg + kCG - 1) / kCG;
+    o->erow = o->eg * 16;
+    o->hgp = o->hch * kCG;
+    o->ngt = (o->ech + o->hch) * kCG;
+    o->ncg = (H + 15) / 16;
+    const int tiles = (R + 15) / 16;
+    o->tpp = (tiles + 3) / 4 <= 5 ? 5 : 6;
+    o->img_tiles = 4 * o->tpp;
+}
+
+hipError_t decode4_pack(const float* Wemb, const float* W2, int V, int H, int E, const Dec4Geom& q, float* wemb_p, float* w2_p, hipStream_t st)
+{
+    const size_t ne = (size_t)V * q.erow, nw = (size_t)q.ncg * 4 * q.ngt * 256;
+    hipLaunchKernelGGL(pack_wemb_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, Wemb, V, E, q.erow, wemb_p);
+    hipLaunchKernelGGL(pack_w2_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W2, H, E, q.ncg, q.ech * kCG, q.ngt, w2_p);
+    return hipGetLastError();
+}
+
+hipError_t decode4_state_to_image(const float* h, int B, int R, int H, const Dec4Geom& q, float* img, hipStream_t st)
+{
+    const size_t n = (size_t)q.img_tiles * q.hgp * 256;
+    hipLaunchKernelGGL(state_to_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h, B, R, H, q.img_tiles, q.hgp, img);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_lstm4(const Dec4Launch& a, const Dec4Geom& q, hipStream_t st)
+{
+    Dec4Args k;
+    std::memset(&k, 0, sizeof(k));
+    k.wemb_p = a.wemb_p; k.erow = q.erow; k.w2_p = a.w2_p; k.bias = a.bias;
+    k.cinit = a.cinit; k.ldcinit = a.ldcinit; k.cinit_rowmod = a.cinit_rowmod;
+    k.tok = a.tok; k.tok_stride = a.tok_stride; k.tok_const = a.tok_const;
+    k.himg_in = a.himg_in; k.himg_out = a.himg_out; k.c_prev = a.c_prev; k.cprev_rowmod = a.cprev_rowmod;
+    k.c_new = a.c_new; k.h_new = a.h_new; k.R = a.R; k.H = a.H; k.V = a.V;
+    k.eg = q.eg; k.hg = q.hg; k.hgp = q.hgp; k.ncg = q.ncg;
+    const Dec4Cfg& c = kDec4[q.tpp == 5 ? 0 : 1];
+    const dim3 grid((unsigned)((q.ncg + 7) / 8 * 32));
+    const double flops = 2.0 * a.R * (double)(a.E + a.H) * 4.0 * a.H;
+    const int ci = 12 + (q.tpp == 5 ? 0 : 1);                   // profiler slot: class 1 (fused LSTM cell), beyond the gemm_kernel table
+    if (!prof_wants(1, ci)) {
+        hipLaunchKernelGGL(c.fn, grid, dim3(256), dec4_lds_bytes(c.tpp), st, k);
+        return hipGetLastError();
+    }
+    hipEvent_t e0, e1;
+    hipError_t pe = prof_events(&e0, &e1);
+    if (pe != hipSuccess) return pe;
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(c.fn, grid, dim3(256), dec4_lds_bytes(c.tpp), st, k);
+    (void)hipEventRecord(e1, st);
+    prof_record(1, ci, c.name, flops, e0, e1);
+    return hipGetLastError();
+}
+
+}  // namespace s2vt
+
+#ifdef S2VT_D4_STAMP
+extern "C" int s2vt_d4_stamp_read(unsigned long long* out8)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(s2vt::d4_stamp_acc), 8 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(s2vt::d4_stamp_acc), z, sizeof(z)) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -119,6 +119,23 @@ bool bwd_chain_auto(int M, int H);                   // ... and it is the faster
 void bwd_chain_scratch(int H, int M, size_t* img_floats, size_t* ex_floats, size_t* sync_bytes);
 hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st);
 
+// ---- the sampler's LSTM2 step at 257-384 rows on fragment-order operands (decode4.hip)
+struct Dec4Geom { int eg, hg, ech, hch, erow, hgp, ngt, ncg, tpp, img_tiles; };
+struct Dec4Launch {
+    const float* wemb_p; const float* w2_p; const float* bias;
+    const float* cinit; int ldcinit; int cinit_rowmod;
+    const unsigned long long* tok; int tok_stride; int tok_const;
+    const float* himg_in; float* himg_out;
+    const float* c_prev; int cprev_rowmod;
+    float* c_new; float* h_new;
+    int R, H, E, V;
+};
+bool decode4_eligible(int R, int H, int E);
+void decode4_geometry(int R, int H, int E, Dec4Geom* out);
+hipError_t decode4_pack(const float* Wemb, const float* W2, int V, int H, int E, const Dec4Geom& q, float* wemb_p, float* w2_p, hipStream_t st);
+hipError_t decode4_state_to_image(const float* h, int B, int R, int H, const Dec4Geom& q, float* img, hipStream_t st);
+hipError_t launch_decode_lstm4(const Dec4Launch& a, const Dec4Geom& q, hipStream_t st);
+
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.
 struct NnBwdArgs {

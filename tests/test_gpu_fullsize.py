@@ -62,3 +62,41 @@ def test_update_linearity_and_mask_normalisation(full):
     assert abs(float(st2.grad_sumsq) - 4 * float(st1.grad_sumsq)) < 1e-2 * float(st1.grad_sumsq)
     assert float(st1.mask_sum) == float(mask.sum()) and float(mask[:, 0].min()) == 1.0
     mdl.global_step = step0
+
+
+def test_fragment_order_decode_step_opt_in_bit_exact(gpu):
+    """decode4.hip (opt-in, S2VT_DEC4=1: the sampler's LSTM2 step at 257-384 rows on fragment-order operands) draws the token
+    ids of the default path, bit for bit, at the bench dimensions (B = 64, K = 5: R = 384) and at R = 272."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["S2VT_ROOT"])
+import numpy as np, torch
+import s2vt_amd
+from s2vt_amd import ops
+from oracle import s2vt_oracle as orc
+out = {}
+for (B, K) in ((64, 5), (34, 7)):
+    d = orc.Dims(1536, 12000, 500, 1000, 5, 6, 0)
+    dims = ops.make_dims(1536, 12000, 500, 1000, 5, 6)
+    p = {k: torch.as_tensor(v).cuda() for k, v in orc.init_params(d, 3).items()}
+    video = torch.as_tensor(np.abs(np.random.default_rng(B).standard_normal((B, 5, 1536)) * 0.5).astype(np.float32)).cuda()
+    s, g = ops.sample(dims, ops.make_params(p), video, K, seed=11)
+    out[f"s{B}"] = s.cpu().numpy(); out[f"g{B}"] = g.cpu().numpy()
+np.savez(sys.argv[1], **out)
+print("child ok")
+'''
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            f = os.path.join(td, f"ids{flag}.npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, S2VT_ROOT=root, S2VT_DEC4=flag), capture_output=True, text=True,
+                               timeout=900)
+            assert r.returncode == 0 and "child ok" in r.stdout, r.stderr[-3000:]
+            res[flag] = dict(np.load(f))
+    for k in res["0"]:
+        assert np.array_equal(res["0"][k], res["1"][k]), k
