@@ -62,6 +62,8 @@ __device__ __forceinline__ void bstore16_sc1(__amdgpu_buffer_rsrc_t rsrc, u32x4v
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, 16);                    // aux 16 = sc1
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr4;
+
 constexpr int kShards = 8;             // counter shards, one 128-byte line each; word kShards * 32 = timeout flag
 constexpr unsigned kSpinLimitDefault = 1u << 21;   // polls (each >= ~0.3 us: s_sleep + an L2 round trip) before a wait gives up: ~1-2 s
 
@@ -931,6 +933,229 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// The backward recurrence above 256 rows in the register-weights form (the construction of lstm_chain4_kernel): workgroup
+// (j, gate, part) = 64 output units x one gate's quarter of the reduction x a QUARTER of the row tiles (grid 16 x 4 x 4 = 256
+// at H = 1000); wave w keeps the B fragments of column tile w (units 64j + 16w .. +15, all H of the gate's k) in registers
+// for the whole launch; the part's slice of the gate's dz image goes global -> LDS once per CU (LDS-DMA ring) and every
+// wave reads the same A fragments from it: TPP row tiles x 1 column tile per wave (balanced), a quarter of the image per CU.
+// Exchange, pointwise part and hand-off are those of the kernel above with 4 column tiles per workgroup.
+template <int NG, int TPP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_chain4_kernel(const BwdChainArgs g)
+{
+    constexpr int NC = 4;                                      // (name of the kernel above: column tiles per workgroup)
+    constexpr int CG = 8, NCH = NG / CG, NBUF = 3;             // k-groups per chunk, chunks per step, LDS chunk buffers
+    constexpr int CHF = TPP * CG * 256;                        // floats per chunk buffer
+    constexpr int DPW = TPP * CG / 4;                          // DMA instructions per wave per chunk
+    static_assert(NG % CG == 0 && NCH >= NBUF && (TPP * CG) % 4 == 0, "chunking");
+    constexpr int ZS = 20;
+    constexpr int PS = TPP;                                    // (row tile, column tile) slots one workgroup finishes per step: tpp * 4 / 4 gates
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ab = smem;                                          // [NBUF][CG][TPP][64 lanes][4]: the A ring
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* zb = smem + NBUF * CHF + pwave * (16 * ZS);         // per-wave transpose tile
+    float* dzl = smem + NBUF * CHF + 4 * 16 * ZS;              // [4 gates][16 rows][17]: dz of one finished tile, regrouped for the image stores
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int H = g.H, M = g.M, T = g.T;
+    // workgroup id -> (unit group, gate, row part): the four gates of a (unit group, part) share blockIdx % 8
+    const int wg = (int)blockIdx.x;
+    const int gate = (wg >> 3) & 3;
+    const int part = (wg >> 5) & 3;
+    const int jj = (wg >> 7) * 8 + (wg & 7);
+    if (jj >= g.ncg) return;                                   // (grid padded to whole groups of 8: these never take part)
+    const int u0 = jj * 16 * NC;
+    const int tpp = g.tpp;                                     // row tiles of a part
+    const int NT = g.img_tiles;                                // row tiles of an image (= parts * tpp)
+    const size_t img_floats = (size_t)NT * NG * 256;           // one gate image
+
+    // ---- this wave's column tile of the slice -> registers, once: k-step s holds B[k = 4s + lq][n = l15] = Whh[u0 + 16 w + l15][gate H + k]
+    float breg[4 * NG];
+    {
+        const int un = u0 + 16 * pwave + l15;
+#pragma unroll
+        for (int s_ = 0; s_ < 4 * NG; ++s_) {
+            const int kk = 4 * s_ + lq;
+            breg[s_] = (un < H && kk < H) ? g.W[(size_t)(g.kw0 + un) * g.ldw + (size_t)gate * H + kk] : 0.0f;
+        }
+    }
+
+    // ---- the (row, unit) this thread finishes at every step, per slot s = gate * PSr + i of the part's tpp * NC (row tile,
+    // column tile) pairs (PSr = slots per workgroup, the four gate workgroups share them)
+    const int pr = tid >> 4, pn = tid & 15;                    // row within the tile, unit within the column tile
+    const int nslots = tpp * NC, psr = (nslots + 3) >> 2;
+    float dc_reg[PS], cnew[PS];
+    uint32_t vid[PS], sid[PS];
+    bool pok[PS];
+    int pm[PS], pu[PS], ptile[PS], pc[PS];
+#pragma unroll
+    for (int i = 0; i < PS; ++i) {
+        const int slot = gate * psr + i;
+        ptile[i] = slot / NC; pc[i] = slot % NC;              // row tile within the part, column tile
+        pm[i] = (part * tpp + ptile[i]) * 16 + pr;
+        pu[i] = u0 + pc[i] * 16 + pn;
+        pok[i] = i < psr && slot < nslots && pm[i] < M && pu[i] < H;
+        dc_reg[i] = 0.0f;
+        cnew[i] = pok[i] ? g.C[(size_t)T * g.state_tstride + (size_t)pm[i] * H + pu[i]] : 0.0f;      // c_{T-1}
+        vid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.video_id[pm[i]] : 0u;
+        sid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.sample_id[pm[i]] : 0u;
+    }
+    const int cluster = jj * NC + part;
+    gu32* const ccount = (gu32*)g.sync + (kChainSyncBytes / 4) + cluster * 32;
+    const __amdgpu_buffer_rsrc_t rsEx = __builtin_amdgcn_make_buffer_rsrc(g.ex, 0, g.ncg * NC * 4 * tpp * NC * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(g.img, 0, (int)(8 * img_floats * 4), 0x00020000);
+    GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, g.ncg, false, 4u * NC};
+    const int tb = part * tpp;                                 // first row tile of this workgroup (every wave multiplies all tpp of them)
+    __syncthreads();
+
+    float sg[PS][4], cprev[PS], dx[PS];
+    auto load_step = [&](int t) __attribute__((always_inline)) {                // operands of step t's pointwise part (independent of the recurrence)
+#pragma unroll
+        for (int i = 0; i < PS; ++i) {
+            const float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)pm[i] * 4 * H + pu[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sg[i][q] = pok[i] ? gp[(size_t)q * H] : 0.0f;
+            cprev[i] = pok[i] ? g.C[(size_t)t * g.state_tstride + (size_t)pm[i] * H + pu[i]] : 0.0f;
+            dx[i] = (pok[i] && g.dext && t >= g.dext_t0) ? g.dext[(size_t)(t - g.dext_t0) * g.dext_tstride + (size_t)pm[i] * g.ld_ext + pu[i]] : 0.0f;
+        }
+    };
+    load_step(T - 1);
+
+    unsigned arrival = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        float dh[PS];
+#pragma unroll
+        for (int i = 0; i < PS; ++i) dh[i] = 0.0f;
+        if (t < T - 1) {
+            // ---- dz_{t+1}[:, gate block] @ slice^T for this wave's row tiles: A fragments straight into registers
+            gs.wait_all(arrival, pwave, lane);
+            const float* acur = g.img + (size_t)((t + 1) & 1) * 4 * img_floats + (size_t)gate * img_floats;
+            const __amdgpu_buffer_rsrc_t rsA =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)tb * NG * 256), 0, TPP * NG * 1024, 0x00020000);
+            // chunk c = groups c*CG ..; piece p = gq * TPP + i; wave w issues pieces w, w + 4, .. (static: CG * TPP / 4 each)
+            auto issue_chunk = [&](auto c_) __attribute__((always_inline)) {
+                constexpr int c = decltype(c_)::value;
+                float* dstb = Ab + (c % NBUF) * CHF;
+                static_for<0, DPW>([&](auto q_) {
+                    constexpr int q = decltype(q_)::value;
+                    const int p = pwave + 4 * q;
+                    const int gq = p / TPP, i = p % TPP;
+                    const int vo = (tb + i) * 16 < M ? lane * 16 : (int)0x80000000u;          // row tiles beyond the problem: zeros
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr4)(dstb + p * 256), 16, vo, (i * NG + c * CG + gq) * 1024, 0, 16);   // aux 16 = sc1
+                });
+            };
+            f32x4 acc[TPP];
+#pragma unroll
+            for (int i = 0; i < TPP; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            static_for<0, NBUF - 1>([&](auto c_) { issue_chunk(c_); });
+            static_for<0, NCH>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                constexpr int issued = c + NBUF - 1 < NCH ? c + NBUF - 1 : NCH;
+                constexpr int later = issued - (c + 1);
+                static_assert(later * DPW <= 63, "vmcnt range");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(later * DPW) : "memory");
+                __syncthreads();
+                if constexpr (c + NBUF - 1 < NCH) issue_chunk(std::integral_constant<int, c + NBUF - 1>{});
+                const f32x4* ab = reinterpret_cast<const f32x4*>(Ab + (c % NBUF) * CHF) + lane;
+                f32x4 a[2][TPP];
+#pragma unroll
+                for (int i = 0; i < TPP; ++i) a[0][i] = ab[i * 64];
+                static_for<0, CG>([&](auto q_) {
+                    constexpr int gq = decltype(q_)::value;
+                    if constexpr (gq + 1 < CG) {
+#pragma unroll
+                        for (int i = 0; i < TPP; ++i) a[(gq + 1) & 1][i] = ab[((gq + 1) * TPP + i) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, 4>([&](auto e_) {
+                        constexpr int e = decltype(e_)::value;
+                        static_for<0, TPP>([&](auto i_) {
+                            constexpr int i = decltype(i_)::value;
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gq & 1][i][e], breg[(c * CG + gq) * 4 + e], acc[i], 0, 0, 0);
+                        });
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            __syncthreads();                                          // (everybody is done with the ring before the exchange tiles reuse zb / the next step's DMA)
+            // ---- partial tiles -> the cluster's exchange [gate][row tile of the part][column tile] (row-major 16 x 16, one
+            // write-through 16-byte store per lane)
+            const size_t exc = (size_t)cluster * 4 * nslots;          // tiles of this cluster's exchange before its own
+#pragma unroll
+            for (int i = 0; i < TPP; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 row = *reinterpret_cast<const f32x4*>(zb + (lane >> 2) * ZS + (lane & 3) * 4);
+                __builtin_amdgcn_wave_barrier();
+                if (i < tpp)
+                    bstore16_sc1(rsEx, __builtin_bit_cast(u32x4v, row), (int)(((exc + (size_t)gate * nslots + (size_t)i * NC + pwave) * 256 + lane * 4) * 4), 0);
+            }
+            gs.arrive_one(ccount, tid);
+            gs.wait_one(ccount, 4u * (arrival + 1u), pwave, lane);
+            ++arrival;
+#pragma unroll
+            for (int i = 0; i < PS; ++i) {
+                const int slot = gate * psr + i;
+                float s_ = 0.0f;
+                if (i < psr && slot < nslots) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        s_ += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * nslots + slot) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                dh[i] = s_;
+            }
+        }
+        // ---- BasicLSTMCell backward pointwise (the expressions of lstm_bwd_pointwise_kernel), one (row, unit) per thread and slot
+        float dzv[PS][4];
+#pragma unroll
+        for (int i = 0; i < PS; ++i) {
+            float d = dx[i];
+            if (g.keep < 1.0f && g.dext && t >= g.dext_t0)
+                d = (d / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)pu[i], g.keep);
+            const float dht = dh[i] + d;
+            const float si = sg[i][0], tj = sg[i][1], sf = sg[i][2], so = sg[i][3];
+            const float tc = dm_tanhf(cnew[i]);
+            const float dc = dht * so * (1.f - tc * tc) + dc_reg[i];
+            dzv[i][0] = dc * tj * si * (1.f - si);
+            dzv[i][1] = dc * si * (1.f - tj * tj);
+            dzv[i][2] = dc * cprev[i] * sf * (1.f - sf);
+            dzv[i][3] = dht * tc * so * (1.f - so);
+            dc_reg[i] = dc * sf;
+            cnew[i] = cprev[i];                                  // c_{t-1} is the next step's c_t
+        }
+        if (t > 0) {
+            // ---- dz_t -> the four gate images of the other parity, regrouped through LDS so that every thread writes ONE
+            // 16-byte fragment slot: thread (gate q = tid / 64, slot L = tid % 64) takes row L % 16, units L / 16 + 4e
+            const size_t inext = (size_t)(t & 1) * 4 * img_floats;
+#pragma unroll
+            for (int i = 0; i < PS; ++i) {
+                const int slot = gate * psr + i;
+                if (!(i < psr && slot < nslots)) continue;       // (uniform over the workgroup)
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dzl[(q * 16 + pr) * 17 + pn] = pok[i] ? dzv[i][q] : 0.0f;
+                __syncthreads();
+                const int q = tid >> 6, L = tid & 63, r = L & 15, kq = L >> 4;
+                u32x4v w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(dzl[(q * 16 + r) * 17 + kq + 4 * e]);
+                const size_t dst = inext + (size_t)q * img_floats + ((size_t)((part * tpp + ptile[i]) * NG + jj * NC + pc[i]) * 64 + L) * 4;
+                bstore16_sc1(rsImg, w, (int)(dst * 4), 0);
+            }
+            gs.arrive(tid);
+        }
+        // ---- history: dZ[t] (read by the weight-gradient contractions after the launch), then the next step's operands
+#pragma unroll
+        for (int i = 0; i < PS; ++i) {
+            if (!pok[i]) continue;
+            float* zp = g.dZ + (size_t)t * g.dz_tstride + (size_t)pm[i] * 4 * H + pu[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zp[(size_t)q * H] = dzv[i][q];
+        }
+        if (t > 0) load_step(t - 1);
+    }
+}
+
 typedef void (*ChainFn)(const ChainArgs);
 struct ChainCfg { int ng, tmw, nc; ChainFn fn; const char* name; };     // nc == 4: the register-weights form (tmw = row tiles per part)
 constexpr int kMaxTmw = 6;                                     // 6 row tiles per wave x 4 waves x 16 rows = 384 rows
@@ -1051,13 +1276,30 @@ const BwdCfg kBwd[] = {
     {64, 2, 1, lstm_bwd_chain_kernel<64, 2, 1>, "bchain(ng64,m128)"}, {64, 4, 1, lstm_bwd_chain_kernel<64, 4, 1>, "bchain(ng64,m256)"},
     // 32 units x half the row tiles per workgroup (tmw = row tiles per wave of a part): 257 .. 384 rows
     {64, 3, 2, lstm_bwd_chain_kernel<64, 3, 2>, "bchain2(ng64,m384)"},
+    // weights in registers, 64 units x a gate x a quarter of the row tiles per workgroup (tmw = row tiles per part)
+    {64, 5, 4, lstm_bwd_chain4_kernel<64, 5>, "bchain4(ng64,m320)"}, {64, 6, 4, lstm_bwd_chain4_kernel<64, 6>, "bchain4(ng64,m384)"},
 };
 constexpr int kNumBwd = (int)(sizeof(kBwd) / sizeof(kBwd[0]));
-int bwd_lds_bytes(const BwdCfg& c) { return (c.ng * c.nc * 256 + 4 * 16 * 20 + 4 * 16 * 17) * 4; }
+int bwd_lds_bytes(const BwdCfg& c)
+{
+    if (c.nc == 4) return (3 * c.tmw * 8 * 256 + 4 * 16 * 20 + 4 * 16 * 17) * 4;      // the A ring (3 chunks of 8 groups x tmw tiles) instead of a W slice
+    return (c.ng * c.nc * 256 + 4 * 16 * 20 + 4 * 16 * 17) * 4;
+}
 bool bwd_two_parts(int M, int H) { return M > 256 && (H + 15) / 16 > 8; }
+bool bwd_four_parts(int M, int H)
+{
+    static const bool on = [] { const char* e = getenv("S2VT_BCHAIN4"); return !(e && e[0] == '0'); }();      // dev knob
+    return on && bwd_two_parts(M, H);
+}
 int bwd_cfg(int M, int H)
 {
     const int ng = (H + 15) / 16 <= 8 ? 8 : 64;
+    if (bwd_four_parts(M, H)) {
+        const int tpp = ((M + 15) / 16 + 3) / 4;
+        for (int i = 0; i < kNumBwd; ++i)
+            if (kBwd[i].nc == 4 && kBwd[i].ng == ng && kBwd[i].tmw == (tpp <= 5 ? 5 : 6)) return i;
+        return -1;
+    }
     const bool two = bwd_two_parts(M, H);
     const int tmw = two ? 3 : (M <= 64 ? 1 : (M <= 128 ? 2 : 4)), nc = two ? 2 : 1;
     for (int i = 0; i < kNumBwd; ++i)
@@ -1217,6 +1459,13 @@ static void bwd_geometry(int M, int H, int* nc, int* tmw, int* tpp, int* ncg)
 {
     const bool two = bwd_two_parts(M, H);
     const int tiles = (M + 15) / 16;
+    if (bwd_four_parts(M, H)) {
+        *nc = 4;
+        *tpp = (tiles + 3) / 4 <= 5 ? 5 : 6;
+        *tmw = *tpp;
+        *ncg = (H + 63) / 64;
+        return;
+    }
     *nc = two ? 2 : 1;
     *tmw = two ? 3 : (M <= 64 ? 1 : (M <= 128 ? 2 : 4));
     *tpp = two ? (tiles + 1) / 2 : 4 * *tmw;

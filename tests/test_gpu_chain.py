@@ -308,18 +308,27 @@ for (M, E, H, T, cs) in ((320, 500, 1000, 6, 6), (384, 8, 1000, 3, 1), (260, 16,
     auto = ops.lstm_recurrence_fwd(Wu, E, _dev(b), _dev(h0), _dev(c0), persistent=-1, **args)
     for r, g in zip(ref, auto):
         assert torch.equal(r, g), ("unaligned", M, H)
+    # the backward recurrence in its two-part form (S2VT_BCHAIN4=0) against per-step launches
+    C, Hh, gates, _ = ref
+    dext = torch.as_tensor((np.random.default_rng(M).standard_normal((T, M, H)) * 0.1).astype(np.float32)).cuda()
+    bargs = dict(dext=dext, dext_t0=0, keep=0.9, seed=5, video_id=_dev(vid), sample_id=_dev(sid), drop_code0=512)
+    b0 = ops.lstm_recurrence_bwd(_dev(W), E, gates, C, persistent=0, **bargs)
+    b1 = ops.lstm_recurrence_bwd(_dev(W), E, gates, C, persistent=1, **bargs)
+    scale = b0.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
+    assert float(((b1 - b0).abs() / scale).max()) <= 2e-5, ("bwd two-part", M, H)
+    assert ops.chain_timeouts() == 0
 print("child ok")
 """
 
 
 def test_two_part_form_above_256_rows_and_unaligned_weights(gpu):
-    """With the register-weights form switched off (S2VT_CHAIN4=0) the two-part form serves 257-384 rows: still bit-identical
-    to per-step launches.  And persistent = -1 with a weight matrix that is not 16-byte aligned falls back to per-step
+    """With the register-weights forms switched off (S2VT_CHAIN4=0, S2VT_BCHAIN4=0) the two-part forms serve 257-384 rows:
+    forward still bit-identical to per-step launches, backward equal to reduction order.  And persistent = -1 with a weight matrix that is not 16-byte aligned falls back to per-step
     launches instead of failing."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", CHILD_FORMS], env=dict(os.environ, S2VT_ROOT=root, S2VT_CHAIN4="0"), capture_output=True, text=True,
-                       timeout=600)
+    r = subprocess.run([sys.executable, "-c", CHILD_FORMS], env=dict(os.environ, S2VT_ROOT=root, S2VT_CHAIN4="0", S2VT_BCHAIN4="0"),
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, f"rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"

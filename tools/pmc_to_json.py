@@ -37,6 +37,10 @@ def prof_key(kname):
     if m:
         ng, tpp = [int(x) for x in m.groups()]
         return f"5:chain4(ng{ng},m{tpp * 64})"
+    m = re.search(r"lstm_bwd_chain4_kernel<(\d+), (\d+)>", kname)
+    if m:
+        ng, tpp = [int(x) for x in m.groups()]
+        return f"6:bchain4(ng{ng},m{tpp * 64})"
     m = re.search(r"lstm_bwd_chain_kernel<(\d+), (\d+), (\d+)>", kname)
     if m:
         ng, tmw, nc = [int(x) for x in m.groups()]
