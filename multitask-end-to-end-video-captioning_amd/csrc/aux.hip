@@ -502,6 +502,30 @@ hipError_t launch_colsum(const float* X, int ld, int M, int N, float* out, hipSt
 }
 
 // ---------------------------------------------------------------------------------------------
+// dst[i] = sum_s slabs[s * stride + i]   (split-K partial products of an order-free contraction; dst may be slab 0)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_slabs_kernel(float* dst, const float* slabs, int nslab, size_t stride, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = reinterpret_cast<const f32x4*>(slabs)[i];
+    for (int s = 1; s < nslab; ++s) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride)[i];
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    reinterpret_cast<f32x4*>(dst)[i] = acc;
+}
+
+hipError_t launch_sum_slabs(float* dst, const float* slabs, int nslab, size_t stride, size_t n, hipStream_t st)
+{
+    if (n == 0 || nslab <= 0) return hipSuccess;
+    if ((n & 3) || (stride & 3)) return hipErrorInvalidValue;
+    const size_t n4 = n >> 2;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dst, slabs, nslab, stride, n4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // dWemb[idx[r], :] += dE[r, :]   (gradient of tf.nn.embedding_lookup; one wave per row,
 // 256 contiguous bytes per atomic wave-instruction).
 // ---------------------------------------------------------------------------------------------

@@ -62,6 +62,7 @@ hipError_t launch_reduce_dropout(const float* dout, int ld_out, float* dh, int T
                                  uint64_t seed, uint32_t code_base, const int32_t* video_id, const int32_t* sample_id,
                                  hipStream_t st);
 hipError_t launch_colsum(const float* X, int ld, int M, int N, float* out, hipStream_t st);
+hipError_t launch_sum_slabs(float* dst, const float* slabs, int nslab, size_t stride, size_t n, hipStream_t st);
 hipError_t launch_scatter_add_rows(const float* dE, int ld, const int32_t* idx, int R, int E, float* dW, int ldw,
                                    hipStream_t st);
 hipError_t launch_transpose(const float* in, int ldi, float* out, int ldo, int R, int Cc, hipStream_t st);

@@ -34,12 +34,31 @@ struct TrainWs {
     unsigned* chain_sync;
     float *bimg, *bex;   // persistent BACKWARD recurrence scratch (chain.hip): dz images, partial-tile exchange
     unsigned* bsync;
+    float* dO2s;         // split-K slabs of dO2 = dlogits @ Wout^T when it has few rows (NULL otherwise)
+    float* dXs;          // split-K slabs of dX2 / dX1 when they are short of tiles (NULL otherwise)
 };
 
 // Split-K plan of the recurrent data-gradient product dz[M,4H] @ Whh^T[4H,H] (order-free): enough K slabs
 // that the launch has >= ~512 workgroups of the 64x32 tile; the slabs are summed by the next step's
 // pointwise kernel.
 constexpr int kMaxSlabs = 16;
+// dO2 = dlogits[Tc N, V] @ Wout^T -> [Tc N, H] has K = |V| = 12000 but, at N = 64, only 1280 x 1000 outputs: as 64x32 tiles with
+// the whole K each it ran 80 TFLOP/s (12 % of the XE step).  Order-free, so up to this many rows it is cut into K slabs on
+// 128x128 tiles and the slabs are summed (5 MB each).
+constexpr int kDo2SplitRows = 2048, kDo2Slabs = 6;
+// The same for the other two data-gradient products of the backward when they are short of tiles: dX2 = dZ2 @ W2[0:H+E]^T
+// ([T N, H+E], K = 4H) and dX1 = dZ1 @ W1[0:E]^T ([Tv B, E], K = 4H).  One slab buffer serves both (they run one after the other).
+constexpr int kDxSlabRows = 2048, kDxMaxSlabs = 12;
+int dx_splits(int M, int N, int K)
+{
+    static const bool off = [] { const char* e = getenv("S2VT_DX_SPLITS"); return e && e[0] == '0'; }();      // dev knob
+    if (off || M > kDxSlabRows || ((size_t)M * N & 3)) return 1;
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);            // 128x128 tiles; aim at ~480 workgroups
+    int s = (int)((480 + tiles - 1) / tiles);
+    if (s > kDxMaxSlabs) s = kDxMaxSlabs;
+    while (s > 1 && K / s < 256) --s;                                           // keep >= 8 chunks per slab
+    return s < 1 ? 1 : s;
+}
 struct SlabPlan { int splits, kper, nslab; };
 SlabPlan slab_plan(int M, int H)
 {
@@ -93,6 +112,13 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
         size_t imgf, exf, syncb;
         bwd_scratch_max((int)H, N, &imgf, &exf, &syncb);       // (sized for the larger of the two recurrences: N >= B rows)
         w.bimg = c.take<float>(imgf); w.bex = c.take<float>(exf); w.bsync = c.take<unsigned>(syncb / 4);
+    }
+    w.dO2s = (Tc * n <= kDo2SplitRows && (H & 3) == 0) ? c.take<float>((size_t)kDo2Slabs * Tc * n * H) : nullptr;
+    {
+        const int s2 = dx_splits((int)(T * n), (int)(H + E), (int)(4 * H)), s1 = dx_splits((int)(Tv * b), (int)E, (int)(4 * H));
+        const size_t need2 = s2 > 1 ? (size_t)s2 * T * n * (H + E) : 0, need1 = s1 > 1 ? (size_t)s1 * Tv * b * E : 0;
+        const size_t need = need2 > need1 ? need2 : need1;
+        w.dXs = need ? c.take<float>(need) : nullptr;
     }
     if (out) *out = w;
     return c.off;
@@ -191,6 +217,18 @@ hipError_t lstm_recurrence_bwd(const float* W, int kw0, const float* gates, cons
         }
     }
     return hipSuccess;
+}
+
+// C = A @ Wt^T with the reduction cut into slabs when the output is short of tiles (dx_splits), the slabs summed into C
+hipError_t nn_bwd_slabs(const float* A, int lda, const float* Wt, int ldw, float* C, int ldc, int M, int N, int K, float* slabs, hipStream_t st)
+{
+    const int s = slabs ? dx_splits(M, N, K) : 1;
+    if (s <= 1 || ldc != N) return nn_bwd(A, lda, Wt, ldw, C, ldc, M, N, K, 1, 0, st);
+    const size_t stride = (size_t)M * N;
+    hipError_t e = nn_bwd(A, lda, Wt, ldw, slabs, N, M, N, K, s, stride, st);
+    if (e != hipSuccess) return e;
+    const int kper = ((K + s - 1) / s + BK - 1) / BK * BK;                     // what nn_bwd made of `splits`
+    return launch_sum_slabs(C, slabs, (K + kper - 1) / kper, stride, stride, st);
 }
 
 }  // namespace
@@ -411,7 +449,15 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         TnArgs a{w.O2 + (size_t)Tv * NH, nullptr, H, dlogits, V, grads->embed_word_W, V, Tc * N, H, V, 1};
         a.colsum = grads->embed_word_b;                     // the bias gradient rides in the same pass over dlogits
         HIP_TRY(launch_gemm_tn(a, sv));
-        HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2, H, Tc * N, H, V, 1, 0, st));
+        static const int do2_splits = [] { const char* e = getenv("S2VT_DO2_SPLITS"); const int v = e ? atoi(e) : kDo2Slabs; return v < 1 ? 1 : (v > kDo2Slabs ? kDo2Slabs : v); }();   // dev knob
+        if (w.dO2s && do2_splits > 1) {
+            const size_t stride = (size_t)Tc * N * H;
+            HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2s, H, Tc * N, H, V, do2_splits, stride, st));
+            const int kper = ((V + do2_splits - 1) / do2_splits + BK - 1) / BK * BK;       // what nn_bwd made of `splits`
+            HIP_TRY(launch_sum_slabs(w.dO2, w.dO2s, (V + kper - 1) / kper, stride, stride, st));
+        } else {
+            HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2, H, Tc * N, H, V, 1, 0, st));
+        }
     }
     if (do_l2) {
     // ---- LSTM2 back through time (one persistent launch up to 128 rows: chain.hip)
@@ -435,7 +481,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
     }
     if (!do_rest) return S2VT_OK;
     // d[out1 ; embed] for every step at once
-    HIP_TRY(nn_bwd(w.dZ2, 4 * H, p->lstm2_W, 4 * H, w.dX2, H + E, T * N, H + E, 4 * H, 1, 0, st));
+    HIP_TRY(nn_bwd_slabs(w.dZ2, 4 * H, p->lstm2_W, 4 * H, w.dX2, H + E, T * N, H + E, 4 * H, w.dXs, st));
     // ---- LSTM1 back through time, on the B per-video rows: the gradient w.r.t. its dropped output is
     // first reduced over the rep sample rows of each video (with their dropout masks)
     const size_t BH = (size_t)B * H;
@@ -444,7 +490,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         BwdScratch sc{w.slab, w.dc, w.bimg, w.bex, w.bsync};
         HIP_TRY(lstm_recurrence_bwd(p->lstm1_W, E, w.G1, w.C1, w.dH1, BH, H, 0, w.dZ1, B, H, T, 1.0f, seed, 0u, nullptr, nullptr, sc, -1, st));
     }
-    HIP_TRY(nn_bwd(w.dZ1, 4 * H, p->lstm1_W, 4 * H, w.dX1, E, Tv * B, E, 4 * H, 1, 0, st));
+    HIP_TRY(nn_bwd_slabs(w.dZ1, 4 * H, p->lstm1_W, 4 * H, w.dX1, E, Tv * B, E, 4 * H, w.dXs, st));
 
     // ---- remaining weight gradients: one contraction over all unrolled steps per weight block
     {
