@@ -11,6 +11,6 @@ done
 wait
 for spec in "$@"; do
   name=${spec%%:*}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api.o train.o attn.o session.o chain.o /tmp/dvar_$name/decode4.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api.o train.o attn.o session.o chain.o chain_bwd.o /tmp/dvar_$name/decode4.o
 done
 ls ../../variants
