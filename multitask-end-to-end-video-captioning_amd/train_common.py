@@ -33,6 +33,7 @@ class Config:
     model_path: str = "./models"
     model_name: str = "s2vt_model"
     max_steps_per_epoch: int = 0       # 0 = the whole epoch (tests bound it)
+    checkpoint_format: str = "npz"     # "npz" (name -> array dump) or "tf" (a TensorFlow V2 checkpoint: <name>-<epoch>.index / .data-00000-of-00001)
     step_log: str = ""                 # path of a JSONL step log ("" = none)
 
 
@@ -176,18 +177,27 @@ def save_checkpoint(model, cfg: Config, epoch: int, step_name: str = "g_step"):
     the optimizer (reinforcement_multisampling_tf_s2vt.py:661): Adam slots, beta powers, the step counter -- a resumed
     run continues the moments, the bias correction, the learning-rate staircase and the noise streams."""
     os.makedirs(cfg.model_path, exist_ok=True)
+    sd = model.store.state_dict(global_step=model.global_step, adam_t=model.adam_t, step_name=step_name)
+    if cfg.checkpoint_format == "tf":                      # the files tf.train.Saver.save(sess, path, global_step=epoch) leaves (:661)
+        from . import tfckpt
+        path = os.path.join(cfg.model_path, f"{cfg.model_name}-{epoch}")
+        sd.pop("global_step", None)                        # (this repository's alias; the graph's counter is `step_name`)
+        tfckpt.write_checkpoint_v2(path, {k: np.asarray(v) for k, v in sd.items()})
+        return path
     path = os.path.join(cfg.model_path, f"{cfg.model_name}-{epoch}.npz")
-    np.savez(path, **model.store.state_dict(global_step=model.global_step, adam_t=model.adam_t, step_name=step_name))
+    np.savez(path, **sd)
     return path
 
 
 def optimistic_restore(model, path, restore_step: bool = True, step_names=("global_step", "g_step", "Variable")):
-    """Load every variable whose name and shape match (reinforcement_multisampling_tf_s2vt.py:47-61) -- Adam slots and
+    """Load every variable whose name and shape match (reinforcement_multisampling_tf_s2vt.py:47-61) from an .npz dump or a
+    TensorFlow checkpoint FILE (V2 `<prefix>.index` + data shards, or a V1 file: tfckpt.py) -- Adam slots and
     beta powers included, as there -- and position the model's counters: the step counter when the checkpoint holds one
     under a name this run's graph would have (`step_names`: a REINFORCE run started from an XE checkpoint passes
     ('g_step',) and so starts its staircase at 0, as the reference does), Adam's update count from beta1_power."""
-    with np.load(path) as z:
-        sd = {k: z[k] for k in z.files if k in step_names or k not in ("global_step", "g_step", "Variable")}
+    from . import tfckpt
+    raw = tfckpt.read_checkpoint(path)                     # .npz dump, TensorFlow V2 prefix (<path>.index) or V1 file
+    sd = {k: v for k, v in raw.items() if k in step_names or k not in ("global_step", "g_step", "Variable")}
     loaded = model.store.load_state_dict(sd)
     st = model.store
     if restore_step and (st.restored_step is not None or st.restored_adam_t is not None):

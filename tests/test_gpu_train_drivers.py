@@ -133,6 +133,14 @@ def test_checkpoint_resume_continues_adam_and_counters(tmp_path):
     e = make()
     tc.optimistic_restore(e, path, step_names=("g_step",))
     assert e.global_step == 0 and e.adam_t == 2
+    # the same through TensorFlow checkpoint FILES (V2 bundle written by save_checkpoint(checkpoint_format="tf"), tfckpt.py)
+    cfg_tf = tc.Config(model_path=str(tmp_path / "mtf"), model_name="ck", decay_steps=2, start_learning_rate=1e-2, checkpoint_format="tf")
+    prefix = tc.save_checkpoint(b, cfg_tf, 0, step_name="Variable")
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+    f = make()
+    tc.optimistic_restore(f, prefix)
+    assert f.global_step == 2 and f.adam_t == 2
+    assert torch.equal(f.store.theta, b.store.theta) and torch.equal(f.store.m, b.store.m) and torch.equal(f.store.v, b.store.v)
 
 
 CHILD_DP_TRAIN = r"""
