@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{src}/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        m = re.search(r"(gemm_kernel|gemm_tn_kernel|gemm_tn_dma_kernel|lstm_chain_kernel)<([^>]*)>", k)
+        m = re.search(r"(gemm_kernel|gemm_tn_kernel|gemm_tn_dma_kernel|lstm_chain_kernel|lstm_chain4_kernel|lstm_bwd_chain_kernel|lstm_bwd_chain4_kernel|decode_lstm4_kernel)<([^>]*)>", k)
         name = (m.group(1).replace("gemm_", "") + "<" + m.group(2).replace(" ", "") + ">") if m else k.split("(")[0][-40:]
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []
@@ -22,5 +22,5 @@ for name, c in agg.items():
                  a.get("SQ_INSTS_SALU", 0) / waves, a.get("SQ_INSTS_VMEM_RD", 0) / waves, a.get("SQ_LDS_BANK_CONFLICT", 0) / max(a.get("SQ_ACTIVE_INST_LDS", 1), 1),
                  a.get("GRBM_GUI_ACTIVE", 0) / 8))
 print(f"{'kernel':<46}{'n':>5}{'waves':>7}{'cyc/wave':>10}{'mfma%':>7}{'wait%':>7}{'istall%':>8}{'active%':>8}{'valu/w':>8}{'mfma/w':>8}{'lds/w':>7}{'salu/w':>8}{'vmem/w':>7}{'bankcf':>7}{'gpu_cyc':>9}")
-for r in sorted(rows, reverse=True)[:16]:
+for r in sorted(rows, reverse=True)[:20]:
     print(f"{r[1]:<46}{r[2]:>5}{r[3]:>7.0f}{r[4]:>10.0f}{100*r[5]:>7.1f}{100*r[6]:>7.1f}{100*r[7]:>8.1f}{100*r[8]:>8.1f}{r[9]:>8.0f}{r[10]:>8.0f}{r[11]:>7.0f}{r[12]:>8.0f}{r[13]:>7.0f}{r[14]:>7.2f}{r[15]:>9.0f}")
