@@ -505,7 +505,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float hvv = dm_tanhf(cc) * so;
             c_reg[i] = cc;
             hv[i] = hvv; siv[i] = si; tjv[i] = tj; sfv[i] = sf; sov[i] = so;
+#ifndef S2VT_C4_NOEPI
             stg[1 * ST + (i * 16 + rt) * 16 + wave * 4 + uu] = hvv;       // only what the hand-off needs is staged before it
+#endif
         }
         C4_STAMP(4);                                              // pointwise
         __syncthreads();
@@ -536,8 +538,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             float ov = hv[i];
             if (g.out && g.keep < 1.0f)
                 ov = (hv[i] / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)u, g.keep);
+#ifndef S2VT_C4_NOEPI
             float* sp = stg + (i * 16 + rt) * 16 + wave * 4 + uu;
             sp[0 * ST] = c_reg[i]; sp[2 * ST] = ov; sp[3 * ST] = siv[i]; sp[4 * ST] = tjv[i]; sp[5 * ST] = sfv[i]; sp[6 * ST] = sov[i];
+#else
+            asm volatile("" ::"v"(ov));
+#endif
         }
         __syncthreads();
         // ---- histories (nobody in this launch reads them): block (array, tile) = [16 rows][16 units]; lane = (row, quarter)
