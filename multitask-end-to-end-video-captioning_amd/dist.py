@@ -139,6 +139,7 @@ def init_from_env(device=None):
             # several ranks share a GPU (functional tests only): each rank's persistent recurrence needs ~every CU of the
             # chip, two of them in flight starve each other (csrc/chain.hip) -> per-step launches, same bits
             os.environ["S2VT_CHAIN"] = "0"
+            os.environ["S2VT_BCHAIN"] = "0"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("S2VT_DIST_BACKEND", "nccl")
