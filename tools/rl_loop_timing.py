@@ -21,7 +21,9 @@ corpus.features = data.FeatureStore(np.abs(rng.standard_normal((nvid, Tv, D)) * 
 corpus.vocabulary = vocab
 corpus.index = data.CaptionIndex(corpus.captions)
 cfg = train_rl.rl_config(n_caption_lstm_step=20, n_epochs=1, batch_size=64, multisample=5, max_steps_per_epoch=int(sys.argv[1]) if len(sys.argv) > 1 else 30,
-                         model_path="/tmp/rl_timing")
+                         model_path="/tmp/rl_timing", step_log="/tmp/rl_timing_steps.jsonl")
+if os.path.exists("/tmp/rl_timing_steps.jsonl"):
+    os.remove("/tmp/rl_timing_steps.jsonl")
 times = []
 
 
@@ -32,4 +34,7 @@ def log(msg):
 
 t0 = time.time()
 train_rl.train(cfg, corpus, None, log=log)
+import json
+secs = [json.loads(l)["seconds"] for l in open("/tmp/rl_timing_steps.jsonl") if '"kind": "step"' in l]
+print(f"step log: median {1e3 * np.median(secs[3:]):.3f} ms, p10 {1e3 * np.percentile(secs[3:], 10):.3f}, p90 {1e3 * np.percentile(secs[3:], 90):.3f}")
 print(f"{len(times)} steps; median wall per step {1e3 * np.median(times[3:]):.2f} ms (first {1e3 * times[0]:.0f} ms); loop total {time.time() - t0:.1f} s")
