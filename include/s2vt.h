@@ -389,7 +389,7 @@ int s2vt_lstm_recurrence_fwd(const float* W, int32_t kw0, const float* b, const 
  * operand order, the four gate partials of a unit group meet through a 4-workgroup exchange, the cell gradient stays in
  * registers (M <= 384, H % 4 == 0, H <= 1024, 4 * ceil(H / 16) <= the CU count; S2VT_E_BADARG otherwise; above 256 rows a
  * workgroup owns 32 units and half the row tiles); 0: per step one pointwise launch + split-K slabs of the product; -1:
- * persistent when the shape fits and it is the faster form (M <= 128 or 256 < M <= 384).  Results agree to
+ * persistent when the shape fits (M <= 384).  Results agree to
  * reduction order (gradients are order-free).  scratch: s2vt_lstm_recurrence_bwd_scratch_bytes(M, H)
  * bytes, 256-byte aligned. */
 size_t s2vt_lstm_recurrence_bwd_scratch_bytes(int32_t M, int32_t H);

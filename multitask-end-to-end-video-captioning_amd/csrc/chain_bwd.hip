@@ -579,7 +579,7 @@ bool bwd_chain_eligible(int M, int H)
 
 bool bwd_chain_auto(int M, int H)
 {
-    static const int maxm = [] { const char* e = getenv("S2VT_BCHAIN_MAXM"); return e ? atoi(e) : 128; }();  // rows up to which the one-part form is chosen unasked
+    static const int maxm = [] { const char* e = getenv("S2VT_BCHAIN_MAXM"); return e ? atoi(e) : 256; }();  // rows up to which the one-part form is chosen unasked (M = 256: 1.01 ms against 1.39 as launches)
     static const bool two = [] { const char* e = getenv("S2VT_BCHAIN2"); return !(e && e[0] == '0'); }();      // the two-part form (257 .. 384 rows)
     return (M <= maxm || (two && bwd_two_parts(M, H))) && bwd_chain_eligible(M, H);
 }
