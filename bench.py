@@ -245,8 +245,15 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
     gt = torch.as_tensor(cap).to(dev)
     gt_mask = pg_mask(gt)
     if workload == "xe":
+        # as train_xe does: the steps behind the longest caption of the GLOBAL batch (its <eos> included) are padding on
+        # every rank and are not unrolled (exact: they add zeros); every rank re-draws the other ranks' lengths
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        steps = min(TC, 1 + max(int((1 + np.minimum(np.random.default_rng(1234 + r).poisson(6, B), TC - 2)).max()) for r in range(world)))
+        if info is not None:
+            info["active_steps"] = steps
+
         def step(i):
-            return mdl.xe_update(video, gt, gt_mask, lr=1e-3, clip_norm=10.0, q1=True, video_base=rank * B)
+            return mdl.xe_update(video, gt, gt_mask, lr=1e-3, clip_norm=10.0, q1=True, video_base=rank * B, active_steps=steps)
         return step
     labels = (torch.rand(B, mdl.label_dim, generator=g) < 0.02).float().to(dev)           # bag-of-words attribute labels, ~8 of 400 set
 
@@ -386,6 +393,8 @@ def main():
             out["config"]["cnn_params"] = info["cnn_params"]
             out["config"]["note"] = ("CNN-bound step: the convolutions run on MIOpen through PyTorch (not a kernel of this library); "
                                      "the roofline object describes this library's dominant kernel only")
+        if "active_steps" in info:
+            out["config"]["unrolled_caption_steps"] = info["active_steps"]      # of TC: behind the longest caption all is padding
         if world == 1 and not args.no_cpu_baseline and args.workload == "rl":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -192,6 +192,18 @@ int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, cons
                                   const void* sampler_workspace, size_t sampler_workspace_bytes, int32_t sampler_rows,
                                   s2vt_stream stream);
 
+/* Same, unrolling only the first `caption_steps` (1 .. Tc) decode steps: when no row of the batch has an unmasked
+ * position at t >= caption_steps -- the padding behind the longest caption of the batch (tf_s2vt.py:371-401 pads every
+ * caption to Tc; cider_evaluation.py:145-172 masks a sample behind its first <eos>) -- those steps add exact zeros to the
+ * loss and to every gradient, so a caller that knows the masks on the host skips them.  `caption` keeps its [N, Tc] row
+ * stride; logits_out is [caption_steps * N, V]; the workspace is the one s2vt_train_workspace_bytes sizes (its layout does
+ * not depend on caption_steps).  Pair it with s2vt_bptt_bwd_steps at the SAME caption_steps. */
+int s2vt_teacher_forced_fwd_steps(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
+                                  const int32_t* caption, int32_t caption_steps, float keep, uint64_t seed,
+                                  const int32_t* video_id, const int32_t* sample_id, float* logits_out, void* workspace,
+                                  size_t workspace_bytes, const void* sampler_workspace, size_t sampler_workspace_bytes,
+                                  int32_t sampler_rows, s2vt_stream stream);
+
 /* ---- softmax / NLL rows, forward + backward ----------------------------------------------------
  * nll[r] = -sum_v q[v] * log_softmax(logits[r])[v],  q = onehot(target[r])*(1-s) + s/V
  * (tf.losses.softmax_cross_entropy(label_smoothing=s), tf_s2vt.py:155; s = 0 gives the
@@ -224,6 +236,13 @@ int s2vt_bptt_bwd(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* g
 int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
                         int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                         const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase, s2vt_stream stream);
+
+/* The backward of s2vt_teacher_forced_fwd_steps: dlogits is [caption_steps * N, V]; steps behind caption_steps carry no
+ * gradient (the recurrences start from zero at the last unrolled step).  phase as above. */
+int s2vt_bptt_bwd_steps(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
+                        int32_t N, const float* dlogits, int32_t caption_steps, float keep, uint64_t seed,
+                        const int32_t* video_id, const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase,
+                        s2vt_stream stream);
 
 /* Gradient w.r.t. the frame features, for the end-to-end scripts where they are the CNN's output
  * (e2e_tf_s2vt.py:106-121,163-166: the optimizer differentiates through `video` into Inception-ResNet-v2):

@@ -113,11 +113,22 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
         bwd_scratch_max((int)H, N, &imgf, &exf, &syncb);       // (sized for the larger of the two recurrences: N >= B rows)
         w.bimg = c.take<float>(imgf); w.bex = c.take<float>(exf); w.bsync = c.take<unsigned>(syncb / 4);
     }
-    w.dO2s = (Tc * n <= kDo2SplitRows && (H & 3) == 0) ? c.take<float>((size_t)kDo2Slabs * Tc * n * H) : nullptr;
+    // (a truncated unroll -- caption_steps < Tc, the *_steps entry points -- has fewer rows and may split where the full one
+    //  does not: both scratch blocks are sized for the worst of all step counts)
     {
-        const int s2 = dx_splits((int)(T * n), (int)(H + E), (int)(4 * H)), s1 = dx_splits((int)(Tv * b), (int)E, (int)(4 * H));
-        const size_t need2 = s2 > 1 ? (size_t)s2 * T * n * (H + E) : 0, need1 = s1 > 1 ? (size_t)s1 * Tv * b * E : 0;
-        const size_t need = need2 > need1 ? need2 : need1;
+        const size_t rows = Tc * n <= (size_t)kDo2SplitRows ? Tc * n : (n <= (size_t)kDo2SplitRows ? (size_t)kDo2SplitRows / n * n : 0);
+        w.dO2s = (rows && (H & 3) == 0) ? c.take<float>((size_t)kDo2Slabs * rows * H) : nullptr;
+    }
+    {
+        size_t need = 0;
+        for (size_t tc = 1; tc <= Tc; ++tc) {
+            const int s2 = dx_splits((int)((Tv + tc) * n), (int)(H + E), (int)(4 * H));
+            const size_t need2 = s2 > 1 ? (size_t)s2 * (Tv + tc) * n * (H + E) : 0;
+            if (need2 > need) need = need2;
+        }
+        const int s1 = dx_splits((int)(Tv * b), (int)E, (int)(4 * H));
+        const size_t need1 = s1 > 1 ? (size_t)s1 * Tv * b * E : 0;
+        if (need1 > need) need = need1;
         w.dXs = need ? c.take<float>(need) : nullptr;
     }
     if (out) *out = w;
@@ -291,12 +302,26 @@ int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, cons
                                   const void* sampler_workspace, size_t sampler_workspace_bytes, int32_t sampler_rows,
                                   s2vt_stream stream)
 {
+    return s2vt_teacher_forced_fwd_steps(d, p, video, B, N, caption, d ? d->n_caption_lstm_step : 0, keep, seed, video_id, sample_id,
+                                         logits, workspace, workspace_bytes, sampler_workspace, sampler_workspace_bytes, sampler_rows,
+                                         stream);
+}
+
+int s2vt_teacher_forced_fwd_steps(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
+                                  const int32_t* caption, int32_t caption_steps, float keep, uint64_t seed,
+                                  const int32_t* video_id, const int32_t* sample_id, float* logits, void* workspace,
+                                  size_t workspace_bytes, const void* sampler_workspace, size_t sampler_workspace_bytes,
+                                  int32_t sampler_rows, s2vt_stream stream)
+{
     if (!dims_ok(d) || !params_ok(p) || !video || !caption || !logits || !workspace || B <= 0 || N <= 0 || N % B)
         return S2VT_E_BADARG;
     if (!(keep > 0.0f) || (keep < 1.0f && (!video_id || !sample_id))) return S2VT_E_BADARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
     if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
-    const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
+    if (caption_steps < 1 || caption_steps > d->n_caption_lstm_step) return S2VT_E_BADARG;
+    // Tc / T below are the steps this call UNROLLS; every buffer is time-major, so a truncated unroll is the leading part
+    // of the full one's layout (the workspace is carved by the model's dimensions whatever caption_steps says)
+    const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = caption_steps;
     const int T = Tv + Tc;
     Carver c(workspace, workspace_bytes);
     TrainWs w;
@@ -304,7 +329,7 @@ int s2vt_teacher_forced_fwd_reuse(const s2vt_dims* d, const s2vt_params* p, cons
     if (!c.ok()) return S2VT_E_WORKSPACE;
     hipStream_t st = S(stream);
 
-    HIP_TRY(launch_prep_caption(caption, w.prev, w.tgt, N, Tc, st));
+    HIP_TRY(launch_prep_caption(caption, w.prev, w.tgt, N, d->n_caption_lstm_step, st));
     hipLaunchKernelGGL(enc_index_kernel, dim3((B * Tv + 255) / 256), dim3(256), 0, st, w.encidx, B, Tv);
     HIP_TRY(hipGetLastError());
     const size_t NH = (size_t)N * H, BH = (size_t)B * H;
@@ -420,13 +445,25 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                         int32_t N, const float* dlogits, float keep, uint64_t seed, const int32_t* video_id,
                         const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase, s2vt_stream stream)
 {
+    return s2vt_bptt_bwd_steps(d, p, grads, video, B, N, dlogits, d ? d->n_caption_lstm_step : 0, keep, seed, video_id, sample_id,
+                               workspace, workspace_bytes, phase, stream);
+}
+
+int s2vt_bptt_bwd_steps(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
+                        int32_t N, const float* dlogits, int32_t caption_steps, float keep, uint64_t seed,
+                        const int32_t* video_id, const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase,
+                        s2vt_stream stream)
+{
     if (phase < 0 || phase > 4) return S2VT_E_BADARG;
     if (!dims_ok(d) || !params_ok(p) || !params_ok(grads) || !video || !dlogits || !workspace || B <= 0 || N <= 0 || N % B)
         return S2VT_E_BADARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
     if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
+    if (caption_steps < 1 || caption_steps > d->n_caption_lstm_step) return S2VT_E_BADARG;
+    // the steps the forward call unrolled (s2vt_teacher_forced_fwd_steps): later steps carry no gradient, so the
+    // recurrences start from zero at step T - 1 and every contraction covers the leading T (Tc) steps only
     const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, D = d->dim_image, Tv = d->n_video_lstm_step,
-              Tc = d->n_caption_lstm_step;
+              Tc = caption_steps;
     const int T = Tv + Tc;
     Carver c(workspace, workspace_bytes);
     TrainWs w;
@@ -450,7 +487,7 @@ int s2vt_bptt_bwd_phase(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         a.colsum = grads->embed_word_b;                     // the bias gradient rides in the same pass over dlogits
         HIP_TRY(launch_gemm_tn(a, sv));
         static const int do2_splits = [] { const char* e = getenv("S2VT_DO2_SPLITS"); const int v = e ? atoi(e) : kDo2Slabs; return v < 1 ? 1 : (v > kDo2Slabs ? kDo2Slabs : v); }();   // dev knob
-        if (w.dO2s && do2_splits > 1) {
+        if (w.dO2s && do2_splits > 1 && Tc * N <= kDo2SplitRows) {
             const size_t stride = (size_t)Tc * N * H;
             HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2s, H, Tc * N, H, V, do2_splits, stride, st));
             const int kper = ((V + do2_splits - 1) / do2_splits + BK - 1) / BK * BK;       // what nn_bwd made of `splits`

@@ -346,11 +346,46 @@ class Video_Caption_Generator:
         return video, sentence, []
 
     # -------------------------------------------------------------------------------- training graphs
-    def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep, reuse_sampler_state=False, target_tm=None):
+    @staticmethod
+    def active_steps(mask):
+        """Number of leading decode steps at which ANY row of `mask` [N, Tc] is unmasked (>= 1), or None when the mask
+        does not live on the host (a device tensor would have to be synchronised for the answer).  Steps behind it add
+        exact zeros to the loss and to every gradient, so the update methods unroll only this many
+        (ops.teacher_forced_fwd(steps=)).  Data parallel with Q1's batch-mean cross entropy: pass the GLOBAL batch's mask
+        (a rank whose own captions are shorter still contributes to the mean at a step another rank keeps alive)."""
+        if isinstance(mask, torch.Tensor):
+            if mask.is_cuda:
+                return None
+            mask = mask.numpy()
+        m = np.asarray(mask)
+        if m.ndim != 2 or m.size == 0:
+            return None
+        live = np.flatnonzero(np.asarray(m != 0).any(axis=0))
+        return int(live[-1]) + 1 if live.size else 1
+
+    def _steps(self, active_steps, mask, local_ok=True):
+        """Resolve an update method's `active_steps` argument: an int (clamped to 1..Tc), None / 0 = the full unroll, "auto" =
+        from a host-resident mask when the local mask decides it (local_ok: single process, or rows that do not couple
+        across ranks)."""
+        Tc = self.n_caption_lstm_step
+        if active_steps is None or active_steps == 0:
+            return Tc
+        if isinstance(active_steps, str):
+            if active_steps != "auto":
+                raise ValueError("active_steps: an int, None or 'auto'")
+            s = self.active_steps(mask) if (local_ok or self.world_size == 1) else None
+            return Tc if s is None else max(1, min(Tc, s))
+        return max(1, min(Tc, int(active_steps)))
+
+    def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep, reuse_sampler_state=False, target_tm=None,
+                      steps=None):
         """Teacher-forced forward + softmax-NLL fwd/bwd.  caption [N,Tc] int32 device, coef_tm
-        time-major [Tc*N].  Leaves dlogits + activations ready for backward()."""
+        time-major [Tc*N].  Leaves dlogits + activations ready for backward().  steps < Tc: only the first `steps` decode
+        steps are unrolled (the caller vouches that coef_tm is zero behind them); nll / lp then have steps*N entries."""
         B = video.shape[0]
         N = caption.shape[0]
+        steps = self.n_caption_lstm_step if steps is None else int(steps)
+        R = steps * N
         vid, sid = self._row_ids(B, rep, video_base)
         seed = self.dropout_seed + 104729 * self.global_step
         state = None
@@ -366,12 +401,14 @@ class Video_Caption_Generator:
                                    "weights, as the last sampler call before the update")
             state = (ls[0], ls[1])
         logits, ws = ops.teacher_forced_fwd(self.dims, self.store.params, video, caption, N, keep, seed, vid, sid,
-                                            sampler_state=state)
+                                            sampler_state=state, steps=steps)
         if callable(coef_tm):            # host work (the reward) runs here, beside the forward just queued on the GPU
             coef_tm = coef_tm()
         target = caption.t().contiguous().view(-1) if target_tm is None else target_tm
-        nll, lp = ops.softmax_nll_fwd_bwd(logits, target, coef_tm, smoothing)
-        self._ctx = (video, N, logits, ws, keep, seed, vid, sid)
+        if isinstance(smoothing, torch.Tensor):
+            smoothing = smoothing[:R]
+        nll, lp = ops.softmax_nll_fwd_bwd(logits, target[:R], coef_tm[:R], smoothing)      # (time-major: a prefix)
+        self._ctx = (video, N, logits, ws, keep, seed, vid, sid, steps)
         return nll, lp
 
     def backward(self, accumulate=False, overlap=None, keep_tail=False):
@@ -384,7 +421,7 @@ class Video_Caption_Generator:
         rank under RCCL, tests/test_gpu_rccl.py -- no multi-GPU box was available to the build)."""
         if overlap is None:
             overlap = self.dp_overlap
-        video, N, dlogits, ws, keep, seed, vid, sid = self._ctx
+        video, N, dlogits, ws, keep, seed, vid, sid, steps = self._ctx
         st = self.store
         if not accumulate:
             (st.grad[:st.numel] if keep_tail else st.grad).zero_()     # keep_tail: sum(mask) already sits in the tail slot (ops.caption_mask)
@@ -394,17 +431,17 @@ class Video_Caption_Generator:
             def span(first, last):
                 return st.offsets[first], st.offsets[last] + (int(np.prod(st.shapes[last])) + 63) // 64 * 64
             args = (self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid)
-            ops.bptt_bwd(*args, phase=1)
+            ops.bptt_bwd(*args, phase=1, steps=steps)
             lo1, hi1 = span("embed_word_W", "embed_word_b")
             self._pending.append(dp.allreduce_async(st.grad[lo1:hi1]))
-            ops.bptt_bwd(*args, phase=3)
+            ops.bptt_bwd(*args, phase=3, steps=steps)
             lo2, hi2 = span("lstm2_W", "lstm2_W")
             assert hi2 == lo1, "bucket layout: lstm2_W sits right below embed_word_W"
             self._pending.append(dp.allreduce_async(st.grad[lo2:hi2]))
             self._early = (lo2, hi1)                       # [lo2, hi1) is already on its way
-            ops.bptt_bwd(*args, phase=4)
+            ops.bptt_bwd(*args, phase=4, steps=steps)
         else:
-            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid)
+            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, steps=steps)
 
     def video_grad(self):
         """d(loss * sum(mask)) / d(video) [B, Tv, dim_image] of the pass backward() just ran -- the gradient the
@@ -493,7 +530,7 @@ class Video_Caption_Generator:
         return self.global_step, lost
 
     def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
-                         true_labels=None, reuse_sampler_state=False, extra_sumsq=None, reward_fn=None):
+                         true_labels=None, reuse_sampler_state=False, extra_sumsq=None, reward_fn=None, active_steps="auto"):
         """build_loss + the REINFORCE objective and train_op of train()
         (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc] (None: derived from the
         ids on the device -- 1 up to and including the first <eos> -- with the coefficients, sum(mask) and the loss in three
@@ -505,7 +542,11 @@ class Video_Caption_Generator:
             -(1-alpha) * PG / sum(mask) + alpha * sum(bce) / (label_dim * B).
         reward_fn: callable() -> (rewards [N], baseline [N]) evaluated on the host AFTER the teacher-forced forward has
         been queued on the GPU (which does not need them), so a host-side scorer (CIDEr-D) runs under it; `rewards` /
-        `baseline` are ignored then."""
+        `baseline` are ignored then.
+        active_steps: decode steps to unroll -- "auto" (default): behind the longest sample of the batch every position is
+        masked, so when `mask` is host-resident (numpy / CPU tensor, as the reference's loop has it) only the steps up
+        to it run; an int: the caller's own count; None: all Tc.  Exact: the skipped steps add zeros."""
+        steps = self._steps(active_steps, mask)
         video = self._dev(video, torch.float32)
         cap = self._dev(sampled, torch.int32)
         st_ = self.store
@@ -530,8 +571,9 @@ class Video_Caption_Generator:
                 made["coef"] = (mask * ((r - b) * pg_w)[:, None]).t().contiguous().view(-1)
             return made["coef"]
         keep = self.dropout_rate if keep is None else keep
-        nll, _ = self._forward_loss(video, cap, make_coef, 0.0, rep, video_base, keep, reuse_sampler_state, target_tm=target_tm)
-        coef = made["coef"]
+        nll, _ = self._forward_loss(video, cap, make_coef, 0.0, rep, video_base, keep, reuse_sampler_state, target_tm=target_tm,
+                                    steps=steps)
+        coef = made["coef"][:nll.numel()]
         if not fused:
             msum = mask.sum().reshape(1)
         self.backward(keep_tail=fused)
@@ -552,9 +594,13 @@ class Video_Caption_Generator:
         return st
 
     def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, q1=True, smoothing=0.05, video_base=0, keep=None,
-                  extra_sumsq=None, decay_all=False):
+                  extra_sumsq=None, decay_all=False, active_steps="auto"):
         """build_model + train_op of tf_s2vt.py:90-167,445-448 (label smoothing 0.05, Q1 batch-mean
-        semantics, weight decay on the non-'bias' variables, clip 10)."""
+        semantics, weight decay on the non-'bias' variables, clip 10).
+        active_steps: as reinforce_update -- the padding behind the longest caption of the batch is not unrolled.  "auto"
+        reads a host-resident caption_mask; data parallel with q1 it needs the GLOBAL batch's longest caption, which only the
+        caller knows (train_xe passes it), so "auto" keeps the full unroll there."""
+        steps = self._steps(active_steps, caption_mask, local_ok=not q1)
         video = self._dev(video, torch.float32)
         cap = self._dev(caption, torch.int32)
         mask = self._dev(caption_mask, torch.float32)
@@ -568,7 +614,8 @@ class Video_Caption_Generator:
             coef = mask.t() * self.loss_weight
         coef = coef.contiguous().view(-1)
         keep = self.dropout_rate if keep is None else keep
-        nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep)
+        nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep, steps=steps)
+        coef = coef[:nll.numel()]
         msum = mask.sum().reshape(1)
         self.backward()
         self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value, extra_sumsq=extra_sumsq, decay_all=decay_all,
@@ -576,7 +623,7 @@ class Video_Caption_Generator:
         return StepStats(self._loss[0], self._sumsq, msum[0])
 
     def mixed_update(self, video, sampled, mask, rewards, baseline, gt_caption, gt_mask, lr, lambda_loss=0.5, clip_norm=5.0,
-                     video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None):
+                     video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None, active_steps="auto"):
         """The mixed objective of reinforce_multitask_e2e_attribute_s2vt.py:850 (BASELINE configs[3]):
             sum_loss = -(1 - lambda) * PG / sum(mask_pg)  +  lambda * model_loss
         with PG the reward-scaled log-likelihood of the SAMPLED captions (build_loss) and model_loss the
@@ -588,6 +635,10 @@ class Video_Caption_Generator:
         for the price of 32.  With true_labels [B, label_dim] (and a model built with label_dim > 0) the attribute head's
         term of reinforce_multitask_e2e_attribute_loss.py:957 is added: + alpha * sum(bce) / (label_dim * B_global) --
         the per-GPU shape of BASELINE configs[3] (attribute FC + XE mix + REINFORCE, K = 1)."""
+        if active_steps == "auto":          # both blocks decide: the longest sample and the longest ground-truth caption
+            sa, sb = self.active_steps(mask), self.active_steps(gt_mask)
+            active_steps = None if (sa is None or sb is None or (q1 and self.world_size > 1)) else max(sa, sb)
+        steps = self._steps(active_steps, None)
         video = self._dev(video, torch.float32)
         cap = self._dev(sampled, torch.int32)
         mask = self._dev(mask, torch.float32)
@@ -613,9 +664,10 @@ class Video_Caption_Generator:
         smooth = torch.zeros((rep + 1) * B, dtype=torch.float32, device=self.device)
         smooth[rep * B:] = float(smoothing)
         smooth_tm = smooth.repeat(self.n_caption_lstm_step).contiguous()
-        nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, rep + 1, video_base, keep)
+        nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, rep + 1, video_base, keep,
+                                    steps=steps)
         N = (rep + 1) * B
-        per_row = (coef * nll).view(-1, N)
+        per_row = (coef[:nll.numel()] * nll).view(-1, N)
         loss_pg, loss_xe = per_row[:, :rep * B].sum(), per_row[:, rep * B:].sum()
         self.backward(accumulate=False, overlap=False)
         attr_scale = attr_loss = None

@@ -86,8 +86,13 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
                     rb["r"] = scorer.score_ids(s_host, np.tile(rows, K))                 # [K*B], sample-major like the ids
                     rb["b"] = scorer.score_ids(g_host, rows)                            # [B]
                     return rb["r"], hostglue.tile_baseline(rb["b"], K)
+                # the ids are on the host anyway: behind the longest sample (its first <eos> included) every position of the
+                # batch is masked, and the update does not unroll those steps
+                eos = s_host == 0
+                steps = int(np.where(eos.any(1), eos.argmax(1) + 1, s_host.shape[1]).max())
                 return model.reinforce_update(video, samples, None, None, None, lr=learning_rate(cfg, model.global_step),
-                                              clip_norm=cfg.clip_norm, video_base=lo, reuse_sampler_state=True, reward_fn=rewards)
+                                              clip_norm=cfg.clip_norm, video_base=lo, reuse_sampler_state=True, reward_fn=rewards,
+                                              active_steps=steps)
             st, loss = run_step(model, step, log)
             r, b = rb["r"], rb["b"]
             losses.append(loss); adv.append(float(r.mean() - b.mean()))

@@ -46,12 +46,16 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
                 break
             t0 = time.time()
             idx, lo = par.shard(gidx)
-            vid, sentence = caps[idx, 0], caps[idx, 1].tolist()
-            captions_ind, captions_mask = hostglue.sentence_padding_toix(sentence, wordtoix, cfg.n_caption_lstm_step)
+            vid = caps[idx, 0]
+            # the GLOBAL batch is padded (64 short strings) so that every rank knows its longest caption: the steps behind
+            # it are all padding on every rank and are not unrolled (Q1's batch mean couples the ranks at a live step)
+            g_ind, g_mask = hostglue.sentence_padding_toix(caps[gidx, 1].tolist(), wordtoix, cfg.n_caption_lstm_step)
+            captions_ind, captions_mask = np.asarray(g_ind, np.int32)[lo:lo + len(idx)], np.asarray(g_mask, np.float32)[lo:lo + len(idx)]
+            steps = model.active_steps(np.asarray(g_mask))
             feats = train_corpus.features.batch(vid)
-            st, loss = run_step(model, lambda: model.xe_update(feats, np.asarray(captions_ind, np.int32), captions_mask,
+            st, loss = run_step(model, lambda: model.xe_update(feats, captions_ind, captions_mask,
                                                                lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm,
-                                                               video_base=lo), log)
+                                                               video_base=lo, active_steps=steps), log)
             losses.append(loss)
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
                 f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")

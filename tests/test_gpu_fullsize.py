@@ -100,3 +100,38 @@ print("child ok")
             res[flag] = dict(np.load(f))
     for k in res["0"]:
         assert np.array_equal(res["0"][k], res["1"][k]), k
+
+
+@pytest.mark.parametrize("mode", ["xe", "pg"])
+def test_padding_steps_are_skipped_exactly_at_the_timed_shapes(full, mode):
+    """active_steps at the bench shapes (persistent recurrences, split-K slabs, LDS-DMA weight gradients): the unroll
+    stops behind the longest caption -- 13 of 20 steps here -- and loss and gradients are those of the full unroll (the
+    skipped steps add zeros; gradients to the noise of the order-free reductions).  lr = 0 keeps the variables fixed."""
+    import torch
+    mdl, video = full
+    rng = np.random.default_rng(3)
+    rep = 1 if mode == "xe" else K
+    N = rep * B
+    longest = 13
+    cap = rng.integers(2, V, (N, TC)).astype(np.int32)
+    ln = rng.integers(1, longest, N); ln[5] = longest - 1
+    for n in range(N):
+        cap[n, ln[n]:] = 0
+    mask = (np.arange(TC)[None, :] <= ln[:, None]).astype(np.float32)          # words + the first <eos>
+    assert mdl.active_steps(mask) == longest
+    r = (rng.random(N) * 2).astype(np.float32); b = np.tile((rng.random(B) * 2).astype(np.float32), rep)
+    step0 = mdl.global_step
+    outs = []
+    for active in (None, "auto"):
+        mdl.global_step = step0                                                 # same dropout masks
+        if mode == "xe":
+            st = mdl.xe_update(video, cap, mask, lr=0.0, q1=True, active_steps=active)
+        else:
+            st = mdl.reinforce_update(video, cap, mask, r, b, lr=0.0, active_steps=active)
+        outs.append((float(st.loss), mdl.store.grad[:mdl.store.numel].clone(), float(st.grad_sumsq), mdl._ctx[-1]))
+    mdl.global_step = step0
+    assert outs[0][3] == TC and outs[1][3] == longest
+    assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * max(1.0, abs(outs[0][0]))
+    scale = float(outs[0][1].abs().max())
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-5 * scale
+    assert abs(outs[0][2] - outs[1][2]) <= 1e-4 * outs[0][2]

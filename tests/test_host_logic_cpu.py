@@ -129,3 +129,16 @@ def test_data_parallel_switches_without_a_process_group(monkeypatch):
     out = dp.allreduce_bucket(g, 4, 3.0)                                 # no group: the bucket is untouched, sum(mask) rides in the tail
     assert float(out) == 3.0 and dp.allreduce_async(t) is None and torch.equal(dp.allreduce_small(t), torch.arange(4.0))
     assert dp.shard_range(64, 3, 8) == (24, 32)
+
+
+def test_active_steps_counts_the_live_leading_steps():
+    """Video_Caption_Generator.active_steps: the steps behind the longest caption of a batch are not unrolled."""
+    from s2vt_amd import hostglue
+    from s2vt_amd.model import Video_Caption_Generator as G
+    ids = np.array([[3, 4, 0, 0, 3, 0], [3, 3, 3, 0, 9, 9], [0, 4, 4, 4, 4, 4]], np.int32)
+    mask = hostglue.masks_from_ids(ids)                                   # 1 up to and including the first <eos>
+    assert G.active_steps(mask) == 4
+    assert G.active_steps(torch.as_tensor(mask)) == 4
+    assert G.active_steps(np.zeros((2, 5), np.float32)) == 1
+    assert G.active_steps(np.ones((2, 5), np.float32)) == 5
+    assert G.active_steps(None) is None
