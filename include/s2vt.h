@@ -131,6 +131,15 @@ int s2vt_gemm_nt(const s2vt_operand* segs, int32_t nseg, const float* Wt, int32_
                  const float* Cinit, int32_t ldcinit, float* C, int32_t ldc, int32_t M, int32_t N, int32_t act_tanh,
                  int32_t tile_cfg, s2vt_stream stream);
 
+/* The order-free form of the same product for GRADIENTS (dX = dZ @ W^T, compared within tolerance, never part of the
+ * bit-exact forward): C[M, N] = A[M, K] @ Wt[N, K]^T with the reduction cut into `splits` K slabs that run as
+ * independent tiles -- a product with a long K and few output tiles (dO2 at B = 64: 1280 x 1000 outputs, K = 12000)
+ * otherwise leaves most CUs idle -- written to `slabs` [splits][M][N] (slab_floats floats) and summed into C (ldc == N).
+ * splits = 0: the library's choice for the shape (1 = no slabs; then `slabs` may be NULL); tile_cfg < 0: its tile. */
+int s2vt_gemm_nt_splitk(const float* A, int32_t lda, const float* Wt, int32_t ldw, float* C, int32_t ldc, int32_t M,
+                        int32_t N, int32_t K, int32_t splits, int32_t tile_cfg, float* slabs, size_t slab_floats,
+                        s2vt_stream stream);
+
 /* ---- BasicLSTMCell + DropoutWrapper, one call (tf_s2vt.py:74-77,119-143) --------------------
  * z = [x0 ; x1 ; h_prev] @ W + b ; i,j,f,o = split(z) ; c' = c*sig(f+1) + sig(i)*tanh(j) ;
  * h' = tanh(c')*sig(o) ; out = keep<1 ? (h'/keep)*mask : h'  (mask from the dropout Philox

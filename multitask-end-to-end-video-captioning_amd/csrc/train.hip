@@ -43,21 +43,39 @@ struct TrainWs {
 // pointwise kernel.
 constexpr int kMaxSlabs = 16;
 // dO2 = dlogits[Tc N, V] @ Wout^T -> [Tc N, H] has K = |V| = 12000 but, at N = 64, only 1280 x 1000 outputs: as 64x32 tiles with
-// the whole K each it ran 80 TFLOP/s (12 % of the XE step).  Order-free, so up to this many rows it is cut into K slabs on
-// 128x128 tiles and the slabs are summed (5 MB each).
-constexpr int kDo2SplitRows = 2048, kDo2Slabs = 6;
+// the whole K each it ran 80 TFLOP/s (12 % of the XE step).  Order-free, so up to this many rows it is cut into K slabs
+// and the slabs are summed.
+constexpr int kDo2SplitRows = 2048, kDo2Slabs = 12;
 // The same for the other two data-gradient products of the backward when they are short of tiles: dX2 = dZ2 @ W2[0:H+E]^T
 // ([T N, H+E], K = 4H) and dX1 = dZ1 @ W1[0:E]^T ([Tv B, E], K = 4H).  One slab buffer serves both (they run one after the other).
 constexpr int kDxSlabRows = 2048, kDxMaxSlabs = 12;
+// Tile and slab count of such a product, from a sweep over 384..1600 rows x {dO2, dX2} x six tiles x seven slab counts
+// (tools/tune_slabs.py): the 64x64 tile (four waves along the rows) wins or ties everywhere -- slabs of ~1500 reduction steps
+// spend a third of their time in prologue and epilogue, which many small co-resident workgroups overlap and two big ones
+// per CU cannot -- with slabs of ~1536 steps and at least ~768 workgroups: dX2 at 1216 rows 213 -> 142 us, at 640 rows
+// 130 -> 83; dO2 at 384 rows 169 -> 95, at 896 rows 216 -> 185.
+constexpr int kSlabTileCfg = 0;        // kStoreNT[0] = nt64x64(4x1)
+int slab_splits(int M, int N, int K, int max_slabs)
+{
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    long s = (K + 1535) / 1536;
+    const long fill = (768 + tiles - 1) / tiles;
+    if (fill > s) s = fill;
+    if (s > max_slabs) s = max_slabs;
+    while (s > 1 && K / s < 256) --s;                                            // keep >= 8 chunks per slab
+    return s < 1 ? 1 : (int)s;
+}
 int dx_splits(int M, int N, int K)
 {
     static const bool off = [] { const char* e = getenv("S2VT_DX_SPLITS"); return e && e[0] == '0'; }();      // dev knob
     if (off || M > kDxSlabRows || ((size_t)M * N & 3)) return 1;
-    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);            // 128x128 tiles; aim at ~480 workgroups
-    int s = (int)((480 + tiles - 1) / tiles);
-    if (s > kDxMaxSlabs) s = kDxMaxSlabs;
-    while (s > 1 && K / s < 256) --s;                                           // keep >= 8 chunks per slab
-    return s < 1 ? 1 : s;
+    return slab_splits(M, N, K, kDxMaxSlabs);
+}
+int do2_splits(int rows, int H, int V)
+{
+    static const int cap = [] { const char* e = getenv("S2VT_DO2_SPLITS"); const int v = e ? atoi(e) : kDo2Slabs; return v < 1 ? 1 : (v > kDo2Slabs ? kDo2Slabs : v); }();   // dev knob
+    if (rows > kDo2SplitRows || (H & 3)) return 1;
+    return slab_splits(rows, H, V, cap);
 }
 struct SlabPlan { int splits, kper, nslab; };
 SlabPlan slab_plan(int M, int H)
@@ -116,8 +134,12 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     // (a truncated unroll -- caption_steps < Tc, the *_steps entry points -- has fewer rows and may split where the full one
     //  does not: both scratch blocks are sized for the worst of all step counts)
     {
-        const size_t rows = Tc * n <= (size_t)kDo2SplitRows ? Tc * n : (n <= (size_t)kDo2SplitRows ? (size_t)kDo2SplitRows / n * n : 0);
-        w.dO2s = (rows && (H & 3) == 0) ? c.take<float>((size_t)kDo2Slabs * rows * H) : nullptr;
+        size_t need = 0;
+        for (size_t tc = 1; tc <= Tc; ++tc) {
+            const int s2 = do2_splits((int)(tc * n), (int)H, d->n_words);
+            if (s2 > 1 && (size_t)s2 * tc * n > need) need = (size_t)s2 * tc * n;
+        }
+        w.dO2s = need ? c.take<float>(need * H) : nullptr;
     }
     {
         size_t need = 0;
@@ -176,7 +198,7 @@ bool params_ok(const s2vt_params* p)
 // order-free product for the backward data path: C[s] = A[:, Ks] @ Wt[:, Ks]^T with Wt = the FORWARD weight block as it
 // lies in memory ([N rows][K columns], row stride ldw) -- no transposed copies (split-K slabs when splits > 1)
 hipError_t nn_bwd(const float* A, int lda, const float* Wt, int ldw, float* C, int ldc, int M, int N, int K, int splits,
-                  size_t slab_stride, hipStream_t st)
+                  size_t slab_stride, hipStream_t st, int tile_cfg = -1)
 {
     GemmArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -190,7 +212,7 @@ hipError_t nn_bwd(const float* A, int lda, const float* Wt, int ldw, float* C, i
         a.slab_stride = slab_stride;
     }
     static const int cfg_ = [] { const char* e = getenv("S2VT_SLAB_CFG"); return e ? atoi(e) : -1; }();     // dev knob
-    return launch_gemm(a, EPI_STORE_NT, splits > 1 ? cfg_ : -1, st);
+    return launch_gemm(a, EPI_STORE_NT, tile_cfg >= 0 ? tile_cfg : (splits > 1 ? cfg_ : -1), st);
 }
 
 // Back-propagation through one cell's unroll: dZ[t] for t = T-1 .. 0.  ONE persistent launch when the shape fits
@@ -236,7 +258,7 @@ hipError_t nn_bwd_slabs(const float* A, int lda, const float* Wt, int ldw, float
     const int s = slabs ? dx_splits(M, N, K) : 1;
     if (s <= 1 || ldc != N) return nn_bwd(A, lda, Wt, ldw, C, ldc, M, N, K, 1, 0, st);
     const size_t stride = (size_t)M * N;
-    hipError_t e = nn_bwd(A, lda, Wt, ldw, slabs, N, M, N, K, s, stride, st);
+    hipError_t e = nn_bwd(A, lda, Wt, ldw, slabs, N, M, N, K, s, stride, st, kSlabTileCfg);
     if (e != hipSuccess) return e;
     const int kper = ((K + s - 1) / s + BK - 1) / BK * BK;                     // what nn_bwd made of `splits`
     return launch_sum_slabs(C, slabs, (K + kper - 1) / kper, stride, stride, st);
@@ -401,6 +423,23 @@ int s2vt_pg_coef(const float* mask, const float* rewards, const float* baseline,
     return S2VT_OK;
 }
 
+int s2vt_gemm_nt_splitk(const float* A, int32_t lda, const float* Wt, int32_t ldw, float* C, int32_t ldc, int32_t M, int32_t N,
+                        int32_t K, int32_t splits, int32_t tile_cfg, float* slabs, size_t slab_floats, s2vt_stream stream)
+{
+    if (!A || !Wt || !C || M < 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldc < N || splits < 0 || splits > 64) return S2VT_E_BADARG;
+    if (M == 0) return S2VT_OK;
+    hipStream_t st = S(stream);
+    int s = splits == 0 ? dx_splits(M, N, K) : splits;
+    if (s > 1 && (ldc != N || !slabs)) { if (splits) return S2VT_E_BADARG; s = 1; }
+    if (s <= 1) { HIP_TRY(nn_bwd(A, lda, Wt, ldw, C, ldc, M, N, K, 1, 0, st, tile_cfg)); return S2VT_OK; }
+    const size_t stride = (size_t)M * N;
+    const int kper = ((K + s - 1) / s + BK - 1) / BK * BK, nslab = (K + kper - 1) / kper;     // what nn_bwd makes of `s`
+    if ((size_t)nslab * stride > slab_floats) return S2VT_E_WORKSPACE;
+    HIP_TRY(nn_bwd(A, lda, Wt, ldw, slabs, N, M, N, K, s, stride, st, tile_cfg >= 0 ? tile_cfg : kSlabTileCfg));
+    HIP_TRY(launch_sum_slabs(C, slabs, nslab, stride, stride, st));
+    return S2VT_OK;
+}
+
 int s2vt_step_scalars(const float* coef, const float* nll, int64_t R, const float* mask_sum_local, const float* mask_sum_global, float* loss,
                       float* gscale, float* sumsq, s2vt_stream stream)
 {
@@ -486,11 +525,11 @@ int s2vt_bptt_bwd_steps(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         TnArgs a{w.O2 + (size_t)Tv * NH, nullptr, H, dlogits, V, grads->embed_word_W, V, Tc * N, H, V, 1};
         a.colsum = grads->embed_word_b;                     // the bias gradient rides in the same pass over dlogits
         HIP_TRY(launch_gemm_tn(a, sv));
-        static const int do2_splits = [] { const char* e = getenv("S2VT_DO2_SPLITS"); const int v = e ? atoi(e) : kDo2Slabs; return v < 1 ? 1 : (v > kDo2Slabs ? kDo2Slabs : v); }();   // dev knob
-        if (w.dO2s && do2_splits > 1 && Tc * N <= kDo2SplitRows) {
+        const int s2 = w.dO2s ? do2_splits(Tc * N, H, V) : 1;
+        if (s2 > 1) {
             const size_t stride = (size_t)Tc * N * H;
-            HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2s, H, Tc * N, H, V, do2_splits, stride, st));
-            const int kper = ((V + do2_splits - 1) / do2_splits + BK - 1) / BK * BK;       // what nn_bwd made of `splits`
+            HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2s, H, Tc * N, H, V, s2, stride, st, kSlabTileCfg));
+            const int kper = ((V + s2 - 1) / s2 + BK - 1) / BK * BK;       // what nn_bwd made of `splits`
             HIP_TRY(launch_sum_slabs(w.dO2, w.dO2s, (V + kper - 1) / kper, stride, stride, st));
         } else {
             HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2, H, Tc * N, H, V, 1, 0, st));

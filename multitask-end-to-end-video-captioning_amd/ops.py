@@ -96,6 +96,22 @@ def gemm_nt(segs, Wt, bias=None, M=None, cinit=None, act_tanh=False, tile_cfg=-1
     return out
 
 
+def gemm_nt_splitk(A, Wt, splits=0, tile_cfg=-1, out=None, slabs=None):
+    """C = A @ Wt^T with the reduction cut into K slabs that are summed (order-free: gradients only).  splits = 0: the
+    library's choice for the shape."""
+    _chk_f32(A, Wt)
+    M, K = A.shape
+    N = Wt.shape[0]
+    assert Wt.shape[1] == K and A.stride(1) == 1 and Wt.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if slabs is None:
+        slabs = torch.empty((max(splits, 12) + 1) * M * N, dtype=torch.float32, device=A.device)
+    check(lib().s2vt_gemm_nt_splitk(_ptr(A), A.stride(0), _ptr(Wt), Wt.stride(0), _ptr(out), out.stride(0), M, N, K, int(splits),
+                                    int(tile_cfg), _ptr(slabs), slabs.numel(), _stream()), "s2vt_gemm_nt_splitk")
+    return out
+
+
 def lstm_cell_fwd(x0, x1, h_prev, c_prev, W, b, M, state_rowmod=0, keep=1.0, seed=0, video_id=None, sample_id=None,
                   drop_code=0, want_gates=False, tile_cfg=-1):
     _chk_f32(h_prev, c_prev, W, b)
