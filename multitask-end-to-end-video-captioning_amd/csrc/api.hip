@@ -329,13 +329,32 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
     const size_t enc = (size_t)Tv * B * H;   // where sample_encode left the encoder state: slot Tv of the history
     int cur2 = 0;
     // 257-384 rows: the LSTM2 step runs on fragment-order operands packed once per call (decode4.hip); same chain, same bits
-    const bool dec4 = w.wemb_p && decode4_eligible(R, H, E);
+    const bool loop1 = w.wemb_p && (B & 15) == 0 && decode_loop_eligible(R, H, E, V) && chain_operands_ok(p->embed_word_W, V, w.himg[0]);
+    const bool dec4 = loop1 || (w.wemb_p && decode4_eligible(R, H, E));
     Dec4Geom q4;
     if (dec4) {
         decode4_geometry(R, H, E, &q4);
         HIP_TRY(decode4_pack(p->Wemb, p->lstm2_W, V, H, E, q4, w.wemb_p, w.w2_p, st));
         HIP_TRY(decode4_state_to_image(w.h2e + enc, B, R, H, q4, w.himg[0], st));
         HIP_TRY(hipMemsetAsync(w.himg[1], 0, (size_t)q4.img_tiles * q4.hgp * 1024, st));
+    }
+    if (loop1) {
+        // all Tc steps -- LSTM2, vocabulary logits, pick -- in one persistent launch (decode_loop.hip)
+        DecLoopLaunch a;
+        std::memset(&a, 0, sizeof(a));
+        a.wemb_p = w.wemb_p; a.w2_p = w.w2_p; a.bias2 = p->lstm2_b;
+        a.P2 = w.P2 + (size_t)Tv * 4 * BH; a.p2_tstride = (size_t)4 * BH; a.ldp2 = 4 * H; a.B = B;
+        a.c0 = w.c2e + enc;
+        a.himg0 = w.himg[0]; a.himg1 = w.himg[1];
+        a.packed = w.packed; a.pick_stride = kPickStride;
+        a.Wout = p->embed_word_W; a.ldwo = V; a.bout = p->embed_word_b;
+        a.seed = seed; a.video_base = video_base; a.noise_rows = K * B;
+        a.R = R; a.H = H; a.E = E; a.V = V; a.Tc = Tc;
+        a.sync = w.chain_sync;
+        HIP_TRY(launch_decode_loop(a, q4, st));
+        hipLaunchKernelGGL(unpack_ids_kernel, dim3((R * Tc + 255) / 256), dim3(256), 0, st, w.packed, ids_out, R, Tc, kPickStride);
+        HIP_TRY(hipGetLastError());
+        return S2VT_OK;
     }
     for (int t = 0; t < Tc; ++t) {
         const int nxt2 = cur2 ^ 1;

@@ -1,0 +1,564 @@
+// decode_loop.hip -- the sampler's whole decode loop (reinforcement_multisampling_tf_s2vt.py:318-337: Tc steps of
+// {embedding lookup of the previous pick, LSTM2, vocabulary logits, multinomial / argmax pick} for the R = (K + 1) B rows
+// that advance together) as ONE persistent launch, instead of 2 Tc launches {LSTM2 step, vocabulary pick}.
+//
+//   256 workgroups, one per CU, four waves, one wave per SIMD.  A step is two phases separated by grid-wide hand-offs
+//   (chain_common.h GridSync, the forms of the persistent recurrences):
+//
+//   A  LSTM2 step -- the inner loop of decode4.hip: workgroup (unit group cg of 16 hidden units, row part rp) multiplies its
+//      TPP row tiles with the fragment-order W2' stream (global -> registers) and the A fragments of the embedding rows of the
+//      previous picks (Wemb', gathered by the DMA source offset) and of h2_{t-1} (the state IMAGE [tile][k group][64][4],
+//      write-through stores / sc1 loads: what chain.hip exchanges), continues the chain from the carried partial P2_t,
+//      BasicLSTMCell pointwise with c_t kept in registers for the whole loop, h_t -> the other image.            [arrive / wait]
+//   B  vocabulary pick -- the layout of tools/micro/pick_phase.hip: workgroup b owns 48 vocabulary columns for ALL rows; every
+//      wave streams the image blocks of its own TPP row tiles straight into registers (sc1), the 48 columns of embed_word_W go
+//      global -> LDS by buffer_load ... lds in 16-row stages; epilogue = the PICK epilogue of gemm_mfma.h (bias, two-tier
+//      Gumbel-max on the Philox stream of (video, sample, step, column), per-row maximum over the 16 lanes of a row) and one
+//      agent-scope 64-bit atomic max per row into the packed pick words, which phase A of the next step reads.   [arrive / wait]
+//
+// Same arithmetic as the launches it replaces: each z and each logit is the same ascending-k fmaf chain (carried partial,
+// embedding rows, recurrent rows; then + bias), the keys are the same expressions, ties go to the lowest column -- ids are
+// bit-identical (tests/test_gpu_decode_loop.py runs the sampler both ways, and the oracle cases in a child process with this
+// form forced on).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "chain_common.h"
+
+namespace s2vt {
+
+namespace {
+
+struct DecLoopArgs {
+    // phase A
+    const float* wemb_p; int erow;                 // Wemb' [V][erow]
+    const float* w2_p;                             // W2' [ncg][4][ngt][256]
+    const float* bias2;                            // [4H]
+    const float* P2; size_t p2_tstride; int ldp2; int B;     // carried partial of decode step t: P2 + t * p2_tstride, row % B
+    const float* c0;                               // c2 at the start of the decoding stage [B, H] (row % B)
+    float* himg0; float* himg1;                    // state images; himg0 holds h2 at the start
+    unsigned long long* packed; int pick_stride;   // [Tc][R][pick_stride] packed picks, zeroed before the launch
+    // phase B
+    const float* Wout; int ldwo; const float* bout;
+    int video_base;                                // noise-stream ids as sampler_rows_kernel assigns them: video = video_base + row % B, sample = row / B
+    uint32_t seed_lo, seed_hi;
+    int noise_rows;                                // rows [0, noise_rows) draw Gumbel noise (sample_id >= 0), the rest are argmax rows
+    int R, H, V, Tc;
+    int eg, hg, hgp, ncg, ech, hch;
+    unsigned* sync; unsigned* status; unsigned* fault; unsigned spin_limit;
+};
+
+constexpr int kCG = 8, kNBUF = 3;                  // phase A: k-groups per chunk, LDS chunk buffers (decode4.hip's values)
+constexpr int kNB = 3, kRING = 3, kTNC = 3;        // phase B: LDS stages of W, A groups in flight per wave (pick_phase.hip: 3/3 .. 8/12 all 86-87 us), column tiles per workgroup
+
+#ifdef S2VT_DL_STAMP
+__device__ unsigned long long dl_stamp_acc[16];
+#define DL_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x == 40 && threadIdx.x == 0) atomicAdd(&dl_stamp_acc[i], n_ - st_prev); st_prev = n_; } while (0)
+#else
+#define DL_STAMP(i) do { } while (0)
+#endif
+
+template <int TPP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void decode_loop_kernel(const DecLoopArgs g)
+{
+#ifdef S2VT_DL_STAMP
+    unsigned long long st_prev = __builtin_readcyclecounter();
+#endif
+    constexpr int ZS = 20;
+    constexpr int CG = kCG, NBUF = kNBUF;
+    constexpr int PPG = TPP;
+    constexpr int CHF = CG * PPG * 256;                        // floats per chunk buffer
+    constexpr int GPW = CG / 4;
+    constexpr int YOUNGER = (NBUF - 2) * GPW * TPP + (NBUF - 1) * CG;
+    static_assert(YOUNGER <= 63, "vmcnt range");
+    constexpr int NB = kNB, RING = kRING, TNC = kTNC, TMW = TPP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ab = smem;                                          // phase A: [NBUF][CG][PPG][64][4]
+    float* Bs = smem;                                          // phase B: [NB][16 * 48] (<= 4096 floats), then the accumulator slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* zb = smem + NBUF * CHF + wave * (16 * ZS);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int H = g.H, R = g.R;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    // ---- phase A identity: the four row parts of a unit group share blockIdx % 8 (one XCD: one fetch of the W2' slice)
+    const int cg = ((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7), rp = ((int)blockIdx.x >> 3) & 3;
+    const bool aact = cg < g.ncg;                              // (256 workgroups, 4 * ncg <= 252 of them own LSTM2 work)
+    const int u0 = cg * 16 + wave * 4;
+    const bool wact = aact && u0 < H;
+    const int tb = rp * TPP;
+    const int ech = g.ech, hch = g.hch, nch = ech + hch;
+    const int ngt = nch * CG;
+    // ---- phase B identity: 48 vocabulary columns
+    const int nct = (g.V + 15) / 16;
+    const int n0 = (int)blockIdx.x * (16 * TNC);
+    const bool bact = (int)blockIdx.x * TNC < nct;
+    const int kg = g.hg;
+
+    GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, (int)gridDim.x, false};
+
+    // ---- loop-invariant operands
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wemb_p), 0, (int)0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w2_p + ((size_t)(aact ? cg : 0) * 4 + wave) * ngt * 256), 0, ngt * 1024, 0x00020000);
+    const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);
+    // carried partial P2_t[row % B]: B is a multiple of 16, so row % B = (tile's first row) % B + row in tile -- one uniform
+    // remainder per row tile, kept in scalar registers; the byte offsets are rebuilt every step (two VALU per element)
+    int tmod[TPP];
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) tmod[i] = __builtin_amdgcn_readfirstlane(((tb + i) * 16) % g.B);
+    auto load_cinit = [&](int t, float (&ci)[TPP][4]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.P2 + (size_t)t * g.p2_tstride), 0, (int)0x80000000u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TPP; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = (tb + i) * 16 + lq * 4 + r;
+                const int off = (wact && m < R) ? ((tmod[i] + lq * 4 + r) * g.ldp2 + ccol) * 4 : (int)0x80000000u;
+                ci[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, off, 0, 0));
+            }
+    };
+    // c_{t-1} of the (row, unit) pairs this lane finishes: in registers for the whole loop
+    const int rt = lane >> 2, uu = lane & 3;
+    const int u = u0 + uu;
+    float c_reg[TPP];
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) {
+        const int row = (tb + i) * 16 + rt;
+        c_reg[i] = (wact && row < R) ? g.c0[(size_t)(tmod[i] + rt) * H + u] : 0.0f;
+    }
+    float bi = 0.f, bj = 0.f, bf = 0.f, bo = 0.f;
+    if (wact) { bi = g.bias2[u]; bj = g.bias2[H + u]; bf = g.bias2[2 * H + u]; bo = g.bias2[3 * H + u]; }
+    // phase B epilogue operands: bias of this lane's columns, noise ids of its rows
+    float ep_bias[TNC];
+#pragma unroll
+    for (int j = 0; j < TNC; ++j) {
+        const int col = n0 + j * 16 + l15;
+        ep_bias[j] = (bact && col < g.V) ? g.bout[col] : 0.0f;
+    }
+    DL_STAMP(0);
+
+    for (int t = 0; t < g.Tc; ++t) {
+        const float* him_in = (t & 1) ? g.himg1 : g.himg0;
+        float* him_out = (t & 1) ? g.himg0 : g.himg1;
+        // =============================================================== phase A: LSTM2 step t
+        if (aact) {
+            // tokens of this wave's DMA rows: the previous step's picks (agent-scope loads: the atomics' home), <bos> = 1 at t = 0
+            int tokoff[TPP];
+#pragma unroll
+            for (int i = 0; i < TPP; ++i) {
+                const int m = (tb + i) * 16 + l15;
+                int tk = 1;
+                if (t > 0 && m < R) {
+                    const unsigned long long wd = __hip_atomic_load(g.packed + ((size_t)(t - 1) * R + m) * g.pick_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tk = (int)(~(uint32_t)wd);
+                }
+                if (m >= R || tk < 0 || tk >= g.V) tk = 0;
+                tokoff[i] = tk * g.erow * 4 + lq * 16;
+            }
+            const __amdgpu_buffer_rsrc_t rsH =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(him_in + (size_t)tb * g.hgp * 256), 0, TPP * g.hgp * 1024, 0x00020000);
+            constexpr int NPA = GPW * TPP, NP = NPA + CG;
+            auto issue_piece = [&](auto j_, int c, float* dstb, f32x4* bdst) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_)::value;
+                const int oob = c >= nch ? (int)0x80000000u : 0;
+                if constexpr (j < NPA) {
+                    constexpr int gl = j / TPP, i = j % TPP;
+                    const int gq = wave + 4 * gl;
+                    const int Ga = c * CG + gq;
+                    const bool emb = c < ech;
+                    const int Gh = Ga - ech * CG;
+                    const bool inr = emb ? Ga < g.eg : Gh < g.hgp;
+                    const int vo = (inr ? (emb ? tokoff[i] + Ga * 64 : lane * 16) : (int)0x80000000u) | oob;
+                    const int so = (emb || !inr) ? 0 : (Gh + i * g.hgp) * 1024;
+                    // aux 16 = sc1: the image is this launch's hand-off (the embedding rows take the same form: the two sources
+                    // differ in operands only, not in control flow)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(emb ? rsE : rsH, (lds_ptr)(dstb + (gq * PPG + i) * 256), 16, vo, so, 0, 16);
+                } else {
+                    constexpr int gq = j - NPA;
+                    const int sb = (oob ? 0 : c * CG) * 1024;
+                    bdst[gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (lane * 16) | oob, sb + gq * 1024, 0));
+                }
+            };
+            auto issue_chunk = [&](int c, float* dstb, f32x4* bdst) __attribute__((always_inline)) {
+                static_for<0, NP>([&](auto j_) { issue_piece(j_, c, dstb, bdst); });
+            };
+            f32x4 acc[TPP];
+            {
+                float ci[TPP][4];
+                load_cinit(t, ci);                                  // (its latency passes with the token loads')
+#pragma unroll
+                for (int i = 0; i < TPP; ++i) {
+                    acc[i] = f32x4{ci[i][0], ci[i][1], ci[i][2], ci[i][3]};
+                    asm volatile("" : "+v"(acc[i]));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tokens and the carried partial in registers before the ring starts (vmcnt bookkeeping)
+            f32x4 breg[NBUF][CG];
+            static_for<0, NBUF - 1>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                issue_chunk(c, Ab + c * CHF, breg[c]);
+            });
+            for (int c0 = 0; c0 < nch; c0 += NBUF) {
+                static_for<0, NBUF>([&](auto k_) {
+                    constexpr int k = decltype(k_)::value;
+                    const int c = c0 + k;
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+                    __syncthreads();
+                    float* const nbuf = Ab + ((k + NBUF - 1) % NBUF) * CHF;
+                    f32x4* const nreg = breg[(k + NBUF - 1) % NBUF];
+                    static_assert(NP <= CG * 4, "one piece per k-step");
+                    const f32x4* ab = reinterpret_cast<const f32x4*>(Ab + k * CHF) + lane;
+                    f32x4 a[2][TPP];
+#pragma unroll
+                    for (int i = 0; i < TPP; ++i) a[0][i] = ab[i * 64];
+                    static_for<0, CG>([&](auto q_) {
+                        constexpr int gq = decltype(q_)::value;
+                        if constexpr (gq + 1 < CG) {
+#pragma unroll
+                            for (int i = 0; i < TPP; ++i) a[(gq + 1) & 1][i] = ab[((gq + 1) * PPG + i) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        static_for<0, 4>([&](auto e_) {
+                            constexpr int e = decltype(e_)::value;
+                            static_for<0, TPP>([&](auto i_) {
+                                constexpr int i = decltype(i_)::value;
+                                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gq & 1][i][e], breg[k][gq][e], acc[i], 0, 0, 0);
+                            });
+                            if constexpr (gq * 4 + e < NP) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(std::integral_constant<int, gq * 4 + e>{}, c + NBUF - 1, nbuf, nreg);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            DL_STAMP(1);
+            // ---- BasicLSTMCell pointwise (gate order i, j, f, o; forget_bias 1.0 at run time): the EPI_LSTM expressions
+            float* const stg = Ab;                                 // [TPP][16 rows][16 units]
+#pragma unroll
+            for (int i = 0; i < TPP; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 z = *reinterpret_cast<const f32x4*>(zb + rt * ZS + uu * 4);
+                __builtin_amdgcn_wave_barrier();
+                const float zi = z[0] + bi, zj = z[1] + bj, zf = z[2] + bf, zo = z[3] + bo;
+                const float si = dm_sigmoidf(zi);
+                const float tj = dm_tanhf(zj);
+                const float sf = dm_sigmoidf(zf + 1.0f);
+                const float so = dm_sigmoidf(zo);
+                const float t1 = c_reg[i] * sf;
+                const float t2 = si * tj;
+                const float cc = t1 + t2;
+                const float hv = dm_tanhf(cc) * so;
+                c_reg[i] = cc;
+                stg[(i * 16 + rt) * 16 + wave * 4 + uu] = wact ? hv : 0.0f;   // (units beyond H: zeros into the image, they multiply zero weights)
+            }
+            __syncthreads();
+            {
+                // the next image: block (tile, group cg), lane L = kq * 16 + r takes row r, units kq + 4e; write-through
+                const __amdgpu_buffer_rsrc_t rsN =
+                    __builtin_amdgcn_make_buffer_rsrc(him_out + ((size_t)tb * g.hgp + cg) * 256, 0, TPP * g.hgp * 1024, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < (TPP + 3) / 4; ++q) {
+                    const int i = wave + 4 * q;
+                    if (i < TPP) {
+                        const int r = lane & 15, kq = lane >> 4;
+                        u32x4v w4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w4[e] = __float_as_uint(stg[(i * 16 + r) * 16 + kq + 4 * e]);
+                        bstore16_sc1(rsN, w4, (i * g.hgp * 256 + lane * 4) * 4, 0);
+                    }
+                }
+            }
+            DL_STAMP(2);
+        }
+        gs.arrive(tid);
+        gs.wait_all((unsigned)(2 * t), wave, lane);
+        DL_STAMP(3);
+        // =============================================================== phase B: vocabulary pick of step t
+        if (bact) {
+            f32x4 acc[TMW][TNC];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // W stage: 16 rows x 48 floats = 192 float4 = three 1-KiB DMA pieces; wave w < 3 issues piece w
+            const int q = wave * 64 + lane, brow = q / 12, bc4 = (q % 12) * 4;
+            auto issue_b = [&](int gi, int buf) __attribute__((always_inline)) {
+                if (wave < 3) {
+                    const int k = gi * 16 + brow;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wout + (size_t)gi * 16 * g.ldwo), 0, 0x7fffffff, 0x00020000);
+                    const unsigned off = (k < H && gi < kg && n0 + bc4 < g.V) ? (unsigned)(brow * g.ldwo + n0 + bc4) * 4u : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(Bs + buf * (16 * 48) + wave * 256), 16, off, 0, 0, 0);
+                }
+            };
+            // A fragments of this wave's row tiles: image block (tile, group) = 1 KB, lane-linear; sc1 (another XCD wrote it)
+            const __amdgpu_buffer_rsrc_t rsI =
+                __builtin_amdgcn_make_buffer_rsrc(him_out + (size_t)wave * TMW * g.hgp * 256, 0, TMW * g.hgp * 1024, 0x00020000);
+            f32x4 a[RING][TMW];
+            static_for<0, RING>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) a[r][i] = bload16_sc1(rsI, lane * 16, (i * g.hgp + (r < kg ? r : kg - 1)) * 1024);
+            });
+            static_for<0, NB - 1>([&](auto g_) { issue_b(decltype(g_)::value, decltype(g_)::value); });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int buf = 0, nbuf = NB - 1;
+            float bvc[4][TNC], bvn[4][TNC];
+            {
+                const float* b = Bs + lq * 48 + l15;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TNC; ++j) bvc[e][j] = b[e * 4 * 48 + j * 16];
+            }
+            for (int g0 = 0; g0 < kg; g0 += RING) {
+                static_for<0, RING>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    const int gi = g0 + r;
+                    if (gi < kg) {
+                        issue_b(gi + NB - 1, nbuf);
+                        const int b1 = buf + 1 == NB ? 0 : buf + 1;
+                        const float* b = Bs + b1 * (16 * 48) + lq * 48 + l15;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int j = 0; j < TNC; ++j) bvn[e][j] = b[e * 4 * 48 + j * 16];
+                        __builtin_amdgcn_sched_barrier(0);
+                        static_for<0, 4>([&](auto e_) {
+                            constexpr int e = decltype(e_)::value;
+#pragma unroll
+                            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                                for (int j = 0; j < TNC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][i][e], bvc[e][j], acc[i][j], 0, 0, 0);
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int gn = gi + RING < kg ? gi + RING : kg - 1;
+#pragma unroll
+                        for (int i = 0; i < TMW; ++i) a[r][i] = bload16_sc1(rsI, lane * 16, (i * g.hgp + gn) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // stage gi + 2 must have landed (its DMA was issued NB - 3 groups ago); the A loads just issued stay in flight
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TMW + (NB - 3) * (TMW + 1)) : "memory");
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int j = 0; j < TNC; ++j) bvc[e][j] = bvn[e][j];
+                        nbuf = buf;
+                        buf = b1;
+                    }
+                });
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DL_STAMP(4);
+            // ---- the PICK epilogue of gemm_mfma.h (EPI_PICK, two-tier Gumbel-max) on this layout: accumulator (i, j)[r] = row
+            // (wave TMW + i) 16 + lq 4 + r, column n0 + 16 j + l15.  The quad l15 = 4q .. 4q+3 holds columns 4Q .. 4Q+3 of the same
+            // four rows: quad lane e draws the Philox block of row r = e, words exchanged by DPP.
+            const uint32_t e4 = (uint32_t)l15 & 3u;
+            unsigned long long* const pk = g.packed + (size_t)t * R * g.pick_stride;
+            // The tile loop below stays ROLLED (its body -- three Philox blocks, the two-tier keys, the lane reduction -- is ~1500
+            // instructions; unrolled six times it leaves the instruction cache): the accumulators go through a lane-private LDS
+            // slot (each lane reads back what it wrote: no barrier), beyond the W stages other waves may still be reading.
+            f32x4* const za = reinterpret_cast<f32x4*>(smem + 4096) + wave * (TMW * TNC * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNC; ++j) za[(i * TNC + j) * 64] = acc[i][j];
+#pragma nounroll
+            for (int i = 0; i < TMW; ++i) {
+                f32x4 ac[TNC];
+#pragma unroll
+                for (int j = 0; j < TNC; ++j) ac[j] = za[(i * TNC + j) * 64];
+                const int trow = (wave * TMW + i) * 16;                 // (uniform) first row of the tile: B is a multiple of 16, so the
+                const int tq = __builtin_amdgcn_readfirstlane(trow / g.B);      // tile lies in ONE sample block
+                const int mrow = trow + lq * 4;
+                // noise ids of the row whose Philox blocks this lane draws (quad lane e4: row lq * 4 + e4), as sampler_rows_kernel
+                const int m_own = mrow + (int)e4;
+                const int sid_own = m_own < g.noise_rows ? tq : -1;
+                const int vid_own = g.video_base + (m_own - tq * g.B);
+                bool noisy[4];                                      // sample_id >= 0: the first K B rows
+#pragma unroll
+                for (int r = 0; r < 4; ++r) noisy[r] = mrow + r < g.noise_rows;
+                float best[4];
+                uint32_t bidx[4];
+                bool have[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { best[r] = 0.0f; bidx[r] = 0xFFFFFFFFu; have[r] = false; }
+                float v0[TNC][4], ka[TNC][4];
+                uint32_t wd[TNC][4];
+#pragma unroll
+                for (int j = 0; j < TNC; ++j) {
+                    const int col = n0 + j * 16 + l15;
+                    u32x4 blk = {0u, 0u, 0u, 0u};
+                    if (sid_own >= 0) blk = philox4x32_10((uint32_t)col >> 2, (uint32_t)vid_own, (uint32_t)sid_own, (uint32_t)t, g.seed_lo, g.seed_hi);
+                    wd[j][0] = quad_word_from<0>(blk, e4);
+                    wd[j][1] = quad_word_from<1>(blk, e4);
+                    wd[j][2] = quad_word_from<2>(blk, e4);
+                    wd[j][3] = quad_word_from<3>(blk, e4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = mrow + r < R && col < g.V;
+                        const float v = ac[j][r] + ep_bias[j];
+                        v0[j][r] = v;
+                        float k = v;
+                        if (noisy[r]) k = v + gumbel_fast_from_word(wd[j][r]);
+                        ka[j][r] = ok ? k : -__builtin_inff();
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float mx = ka[0][r];
+                    int js = 0;
+#pragma unroll
+                    for (int j = 1; j < TNC; ++j)
+                        if (ka[j][r] > mx) { mx = ka[j][r]; js = j; }
+                    float rmx = mx;
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, off, 64));
+                    const float thr = rmx - 2.0f * kGumbelScreenMargin;
+                    float vs = v0[0][r];
+                    uint32_t ws = wd[0][r];
+#pragma unroll
+                    for (int j = 1; j < TNC; ++j)
+                        if (js == j) { vs = v0[j][r]; ws = wd[j][r]; }
+                    const int cols = n0 + js * 16 + l15;
+                    const bool okr = mrow + r < R;
+                    if (okr && cols < g.V && !(mx < thr)) {
+                        float v = vs;
+                        if (noisy[r]) v = v + gumbel_from_word(ws);
+                        v = v + 0.0f;                              // -0 -> +0 so that the integer order equals the float order
+                        best[r] = v; bidx[r] = (uint32_t)cols; have[r] = true;
+                    }
+#pragma unroll
+                    for (int j = 0; j < TNC; ++j) {
+                        const int col = n0 + j * 16 + l15;
+                        const bool extra = okr && col < g.V && j != js && !(ka[j][r] < thr);
+                        if (__any(extra)) {
+                            if (extra) {
+                                float v = v0[j][r];
+                                if (noisy[r]) v = v + gumbel_from_word(wd[j][r]);
+                                v = v + 0.0f;
+                                if (!have[r] || v > best[r] || (v == best[r] && (uint32_t)col < bidx[r])) { best[r] = v; bidx[r] = (uint32_t)col; have[r] = true; }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow + r;
+                    unsigned long long key = have[r] ? (((unsigned long long)orderable(best[r]) << 32) | (uint32_t)(~bidx[r])) : 0ull;
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) {
+                        const unsigned long long o = __shfl_xor(key, off, 64);
+                        key = o > key ? o : key;
+                    }
+                    if (l15 == 0 && m < R && key != 0ull)
+                        (void)__hip_atomic_fetch_max(pk + (size_t)m * g.pick_stride, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            DL_STAMP(5);
+        }
+        if (t + 1 < g.Tc) {
+            gs.arrive(tid);
+            gs.wait_all((unsigned)(2 * t + 1), wave, lane);
+        }
+        DL_STAMP(6);
+    }
+}
+
+typedef void (*DecLoopFn)(const DecLoopArgs);
+struct DecLoopCfg { int tpp; DecLoopFn fn; const char* name; };
+const DecLoopCfg kDecLoop[] = {{5, decode_loop_kernel<5>, "decloop(m320)"}, {6, decode_loop_kernel<6>, "decloop(m384)"}};
+int decloop_lds_bytes(int tpp)
+{
+    const int a = (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4, b = 4096 * 4 + 4 * tpp * kTNC * 64 * 16;      // phase A ring + gate tiles | phase B stages + accumulator slots
+    return a > b ? a : b;
+}
+std::once_flag g_dl_once;
+bool g_dl_ok = false;
+constexpr int kDecLoopGrid = 256;
+
+}  // namespace
+
+// The shape fits, the device has a CU for every workgroup, and the form is switched on (S2VT_DECLOOP=1; default off until it
+// is the faster one -- see DESIGN.md section 11 for the measurement).
+bool decode_loop_eligible(int R, int H, int E, int V)
+{
+    static const int on = [] { const char* e = getenv("S2VT_DECLOOP"); return e ? atoi(e) : 0; }();
+    if (!on || R <= 256 || R > 384 || (H & 3) || H < 132 || H > 1008 || E < 1 || (V & 3) || (V + 15) / 16 > kDecLoopGrid * kTNC) return false;
+    if (chain_persistent_disabled()) return false;
+    ChainHost h;
+    if (!chain_host(&h) || h.num_cus < kDecLoopGrid) return false;
+    std::call_once(g_dl_once, [] {
+        bool ok = true;
+        for (const DecLoopCfg& c : kDecLoop) {
+            ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, decloop_lds_bytes(c.tpp)) == hipSuccess;
+            int nb = 0;
+            ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(c.fn), 256, decloop_lds_bytes(c.tpp)) == hipSuccess && nb >= 1;
+        }
+        g_dl_ok = ok;
+    });
+    return g_dl_ok;
+}
+
+hipError_t launch_decode_loop(const DecLoopLaunch& a, const Dec4Geom& q, hipStream_t st)
+{
+    ChainHost h;
+    if (!chain_host(&h)) return hipErrorInvalidValue;
+    DecLoopArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.wemb_p = a.wemb_p; k.erow = q.erow; k.w2_p = a.w2_p; k.bias2 = a.bias2;
+    k.P2 = a.P2; k.p2_tstride = a.p2_tstride; k.ldp2 = a.ldp2; k.B = a.B; k.c0 = a.c0;
+    k.himg0 = a.himg0; k.himg1 = a.himg1; k.packed = a.packed; k.pick_stride = a.pick_stride;
+    k.Wout = a.Wout; k.ldwo = a.ldwo; k.bout = a.bout;
+    k.seed_lo = (uint32_t)a.seed; k.seed_hi = (uint32_t)(a.seed >> 32); k.noise_rows = a.noise_rows; k.video_base = a.video_base;
+    k.R = a.R; k.H = a.H; k.V = a.V; k.Tc = a.Tc;
+    k.eg = q.eg; k.hg = q.hg; k.hgp = q.hgp; k.ncg = q.ncg; k.ech = q.ech; k.hch = q.hch;
+    k.sync = a.sync; k.status = h.status_dev; k.fault = h.fault; k.spin_limit = h.spin_limit;
+    const DecLoopCfg& c = kDecLoop[q.tpp == 5 ? 0 : 1];
+    ChainLaunchOrder order;                                     // one persistent grid at a time per process
+    hipError_t e = order.before(st, h.device);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(a.sync, 0, kChainSyncBytes, st);
+    if (e != hipSuccess) return e;
+    const double flops = (2.0 * a.R * (double)(a.E + a.H) * 4.0 * a.H + 2.0 * a.R * (double)a.H * a.V) * a.Tc;
+    const int ci = 14 + (q.tpp == 5 ? 0 : 1);                   // profiler slot: class 2 (vocabulary pick), beyond the gemm_kernel table
+    if (!prof_wants(2, ci)) {
+        hipLaunchKernelGGL(c.fn, dim3(kDecLoopGrid), dim3(256), decloop_lds_bytes(c.tpp), st, k);
+        e = hipGetLastError();
+        return e != hipSuccess ? e : order.after(st, h.device);
+    }
+    hipEvent_t e0, e1;
+    hipError_t pe = prof_events(&e0, &e1);
+    if (pe != hipSuccess) return pe;
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(c.fn, dim3(kDecLoopGrid), dim3(256), decloop_lds_bytes(c.tpp), st, k);
+    (void)hipEventRecord(e1, st);
+    prof_record(2, ci, c.name, flops, e0, e1);
+    e = hipGetLastError();
+    return e != hipSuccess ? e : order.after(st, h.device);
+}
+
+}  // namespace s2vt
+
+#ifdef S2VT_DL_STAMP
+extern "C" int s2vt_dl_stamp_read(unsigned long long* out16)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(s2vt::dl_stamp_acc), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(s2vt::dl_stamp_acc), z, sizeof(z)) == hipSuccess ? 0 : -4;
+}
+#endif

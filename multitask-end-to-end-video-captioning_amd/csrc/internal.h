@@ -137,6 +137,22 @@ hipError_t decode4_pack(const float* Wemb, const float* W2, int V, int H, int E,
 hipError_t decode4_state_to_image(const float* h, int B, int R, int H, const Dec4Geom& q, float* img, hipStream_t st);
 hipError_t launch_decode_lstm4(const Dec4Launch& a, const Dec4Geom& q, hipStream_t st);
 
+// ---- the sampler's whole decode loop in one persistent launch (decode_loop.hip), on decode4's packed operands
+struct DecLoopLaunch {
+    const float* wemb_p; const float* w2_p; const float* bias2;
+    const float* P2; size_t p2_tstride; int ldp2; int B;      // carried partial of decode step t (row % B)
+    const float* c0;                                          // [B, H] cell state at the start of the decoding stage
+    float* himg0; float* himg1;                               // state images (himg0 = h at the start, himg1 zeroed)
+    unsigned long long* packed; int pick_stride;              // [Tc][R][pick_stride], zeroed
+    const float* Wout; int ldwo; const float* bout;
+    uint64_t seed; int video_base;                            // noise ids as sampler_rows_kernel: video = video_base + row % B, sample = row / B
+    int noise_rows;                                           // rows [0, noise_rows) are sampled (sample id >= 0), the rest argmax
+    int R, H, E, V, Tc;
+    unsigned* sync;                                           // kChainSyncBytes
+};
+bool decode_loop_eligible(int R, int H, int E, int V);
+hipError_t launch_decode_loop(const DecLoopLaunch& a, const Dec4Geom& q, hipStream_t st);
+
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.
 struct NnBwdArgs {
