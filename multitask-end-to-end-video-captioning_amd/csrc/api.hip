@@ -279,10 +279,11 @@ int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, 
     const int T = Tv + Tc;
     const size_t BH = (size_t)B * H;
     // zero initial states (tf_s2vt.py:105-107)
-    HIP_TRY(hipMemsetAsync(w.c1, 0, BH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.h1, 0, BH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.c2e, 0, BH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.h2e, 0, BH * 4, st));
+    {
+        ZeroList z;
+        z.add(w.c1, BH * 4); z.add(w.h1, BH * 4); z.add(w.c2e, BH * 4); z.add(w.h2e, BH * 4);
+        HIP_TRY(launch_zero_regions(z, st));
+    }
     int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
     if (rc != S2VT_OK) return rc;
 

@@ -516,6 +516,36 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(float* dst, const float*
     reinterpret_cast<f32x4*>(dst)[i] = acc;
 }
 
+// Several buffers that must read as zeros when a pass starts (initial states, hand-off counters, fragment images), in ONE
+// launch: each hipMemsetAsync is a ~5 us kernel of its own, and a REINFORCE step had 19 of them.
+__global__ void zero_regions_kernel(const ZeroList z)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int r = 0; r < z.count; ++r) {
+        uint32_t* p = z.p[r];
+        const size_t n = z.n[r];
+        if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+            uint4* p4 = reinterpret_cast<uint4*>(p);
+            const size_t n4 = n >> 2;
+            for (size_t i = first; i < n4; i += stride) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (size_t i = (n4 << 2) + first; i < n; i += stride) p[i] = 0u;
+        } else {
+            for (size_t i = first; i < n; i += stride) p[i] = 0u;
+        }
+    }
+}
+
+hipError_t launch_zero_regions(const ZeroList& z, hipStream_t st)
+{
+    size_t most = 0;
+    for (int r = 0; r < z.count; ++r) most = z.n[r] > most ? z.n[r] : most;
+    if (z.count <= 0 || most == 0) return hipSuccess;
+    const size_t want = (most / 4 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(blocks), dim3(256), 0, st, z);
+    return hipGetLastError();
+}
+
 hipError_t launch_sum_slabs(float* dst, const float* slabs, int nslab, size_t stride, size_t n, hipStream_t st)
 {
     if (n == 0 || nslab <= 0) return hipSuccess;

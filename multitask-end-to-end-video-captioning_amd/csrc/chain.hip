@@ -762,9 +762,9 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
         if (we != hipSuccess) return we;
     }
     // every polled word and the fragment images start from zero on EVERY call (a memset node ahead of the launch)
-    hipError_t e = hipMemsetAsync(a.sync, 0, kChainSyncBytes, st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.abuf, 0, (size_t)2 * a2.img_tiles * c.ng * 256 * 4, st);
+    ZeroList z;
+    z.add(a.sync, kChainSyncBytes); z.add(a.abuf, (size_t)2 * a2.img_tiles * c.ng * 256 * 4);
+    hipError_t e = launch_zero_regions(z, st);
     if (e != hipSuccess) return e;
     const int lds = chain_lds_bytes(c);
     const dim3 grid((unsigned)(parts * a2.ncg));

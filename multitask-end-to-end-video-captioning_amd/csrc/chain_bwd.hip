@@ -643,9 +643,9 @@ hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
         hipError_t we = order.before(st, dev);
         if (we != hipSuccess) return we;
     }
-    hipError_t e = hipMemsetAsync(a.sync, 0, syncb, st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(a.img, 0, imgf * 4, st);                // rows >= M and k >= H of the images must read as zeros
+    ZeroList z;
+    z.add(a.sync, syncb); z.add(a.img, imgf * 4);              // (rows >= M and k >= H of the images must read as zeros)
+    hipError_t e = launch_zero_regions(z, st);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((k.ncg + 7) / 8 * 32 * nc_));
     const double flops = 2.0 * a.M * (double)a.H * 4.0 * a.H * (a.T - 1);

@@ -63,6 +63,13 @@ hipError_t launch_reduce_dropout(const float* dout, int ld_out, float* dh, int T
                                  hipStream_t st);
 hipError_t launch_colsum(const float* X, int ld, int M, int N, float* out, hipStream_t st);
 hipError_t launch_sum_slabs(float* dst, const float* slabs, int nslab, size_t stride, size_t n, hipStream_t st);
+// up to 8 buffers zeroed by one launch (sizes in 4-byte words)
+struct ZeroList {
+    uint32_t* p[8]; size_t n[8]; int count;
+    ZeroList() : count(0) {}
+    void add(void* ptr, size_t bytes) { if (ptr && bytes) { p[count] = static_cast<uint32_t*>(ptr); n[count] = bytes / 4; ++count; } }
+};
+hipError_t launch_zero_regions(const ZeroList& z, hipStream_t st);
 hipError_t launch_scatter_add_rows(const float* dE, int ld, const int32_t* idx, int R, int E, float* dW, int ldw,
                                    hipStream_t st);
 hipError_t launch_transpose(const float* in, int ldi, float* out, int ldo, int R, int Cc, hipStream_t st);

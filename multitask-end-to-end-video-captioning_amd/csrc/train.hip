@@ -356,10 +356,12 @@ int s2vt_teacher_forced_fwd_steps(const s2vt_dims* d, const s2vt_params* p, cons
     HIP_TRY(hipGetLastError());
     const size_t NH = (size_t)N * H, BH = (size_t)B * H;
     // zero initial states (tf_s2vt.py:105-107): slot 0 of the state histories
-    HIP_TRY(hipMemsetAsync(w.C1, 0, BH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.H1, 0, BH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.C2, 0, NH * 4, st));
-    HIP_TRY(hipMemsetAsync(w.H2, 0, NH * 4, st));
+    {
+        ZeroList z;
+        if (!sampler_workspace) { z.add(w.C1, BH * 4); z.add(w.H1, BH * 4); }      // (taken whole from the sampler pass otherwise)
+        z.add(w.C2, NH * 4); z.add(w.H2, NH * 4);
+        HIP_TRY(launch_zero_regions(z, st));
+    }
     int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
     if (rc != S2VT_OK) return rc;
 
