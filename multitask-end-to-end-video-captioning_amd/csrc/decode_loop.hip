@@ -2,16 +2,20 @@
 // {embedding lookup of the previous pick, LSTM2, vocabulary logits, multinomial / argmax pick} for the R = (K + 1) B rows
 // that advance together) as ONE persistent launch, instead of 2 Tc launches {LSTM2 step, vocabulary pick}.
 //
-//   256 workgroups, one per CU, four waves, one wave per SIMD.  A step is two phases separated by grid-wide hand-offs
+//   256 workgroups, one per CU, EIGHT waves (two per SIMD).  A step is two phases separated by grid-wide hand-offs
 //   (chain_common.h GridSync, the forms of the persistent recurrences):
 //
-//   A  LSTM2 step -- the inner loop of decode4.hip: workgroup (unit group cg of 16 hidden units, row part rp) multiplies its
+//   A  LSTM2 step (waves 0-3; waves 4-7 only keep the workgroup barriers: with four waves the phase already runs at the
+//      pipe's dependent-issue rate, and its 250 registers per wave are what two waves per SIMD leave) -- the inner loop of
+//      decode4.hip: workgroup (unit group cg of 16 hidden units, row part rp) multiplies its
 //      TPP row tiles with the fragment-order W2' stream (global -> registers) and the A fragments of the embedding rows of the
 //      previous picks (Wemb', gathered by the DMA source offset) and of h2_{t-1} (the state IMAGE [tile][k group][64][4],
 //      write-through stores / sc1 loads: what chain.hip exchanges), continues the chain from the carried partial P2_t,
 //      BasicLSTMCell pointwise with c_t kept in registers for the whole loop, h_t -> the other image.            [arrive / wait]
-//   B  vocabulary pick -- the layout of tools/micro/pick_phase.hip: workgroup b owns 48 vocabulary columns for ALL rows; every
-//      wave streams the image blocks of its own TPP row tiles straight into registers (sc1), the 48 columns of embed_word_W go
+//   B  vocabulary pick (all eight waves: at ONE wave per SIMD nothing hid the latencies of its loop and of the pick epilogue --
+//      84 + 30 us against 70 + 11 in the launch form, profiles/r03_decode_loop_probe.jsonl) -- the layout of
+//      tools/micro/pick_phase.hip: workgroup b owns 48 vocabulary columns for ALL rows; every wave streams the image blocks of
+//      its own three row tiles straight into registers (sc1), the 48 columns of embed_word_W go
 //      global -> LDS by buffer_load ... lds in 16-row stages; epilogue = the PICK epilogue of gemm_mfma.h (bias, two-tier
 //      Gumbel-max on the Philox stream of (video, sample, step, column), per-row maximum over the 16 lanes of a row) and one
 //      agent-scope 64-bit atomic max per row into the packed pick words, which phase A of the next step reads.   [arrive / wait]
@@ -62,7 +66,7 @@ __device__ unsigned long long dl_stamp_acc[16];
 #endif
 
 template <int TPP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void decode_loop_kernel(const DecLoopArgs g)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void decode_loop_kernel(const DecLoopArgs g)
 {
 #ifdef S2VT_DL_STAMP
     unsigned long long st_prev = __builtin_readcyclecounter();
@@ -74,13 +78,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int GPW = CG / 4;
     constexpr int YOUNGER = (NBUF - 2) * GPW * TPP + (NBUF - 1) * CG;
     static_assert(YOUNGER <= 63, "vmcnt range");
-    constexpr int NB = kNB, RING = kRING, TNC = kTNC, TMW = TPP;
+    constexpr int NB = kNB, RING = kRING, TNC = kTNC;
+    constexpr int TMW = 3;                                     // phase B: row tiles per wave (8 waves x 3 >= 4 TPP)
+    static_assert(8 * TMW >= 4 * TPP, "phase B covers every row tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ab = smem;                                          // phase A: [NBUF][CG][PPG][64][4]
     float* Bs = smem;                                          // phase B: [NB][16 * 48] (<= 4096 floats), then the accumulator slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* zb = smem + NBUF * CHF + wave * (16 * ZS);
+    float* zb = smem + NBUF * CHF + (wave & 3) * (16 * ZS);
     const int l15 = lane & 15, lq = lane >> 4;
     const int H = g.H, R = g.R;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- loop-invariant operands
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.wemb_p), 0, (int)0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w2_p + ((size_t)(aact ? cg : 0) * 4 + wave) * ngt * 256), 0, ngt * 1024, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w2_p + ((size_t)(aact ? cg : 0) * 4 + (wave & 3)) * ngt * 256), 0, ngt * 1024, 0x00020000);
     const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);
     // carried partial P2_t[row % B]: B is a multiple of 16, so row % B = (tile's first row) % B + row in tile -- one uniform
     // remainder per row tile, kept in scalar registers; the byte offsets are rebuilt every step (two VALU per element)
@@ -146,7 +152,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float* him_in = (t & 1) ? g.himg1 : g.himg0;
         float* him_out = (t & 1) ? g.himg0 : g.himg1;
         // =============================================================== phase A: LSTM2 step t
-        if (aact) {
+        if (aact && wave >= 4) {
+            // waves 4-7 have no part in phase A: they keep its workgroup barriers (one per chunk, two behind the loop)
+            for (int c0 = 0; c0 < nch; c0 += NBUF)
+#pragma unroll
+                for (int k = 0; k < NBUF; ++k) __syncthreads();
+            __syncthreads();
+            __syncthreads();
+        } else if (aact) {
             // tokens of this wave's DMA rows: the previous step's picks (agent-scope loads: the atomics' home), <bos> = 1 at t = 0
             int tokoff[TPP];
 #pragma unroll
@@ -303,8 +316,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             };
             // A fragments of this wave's row tiles: image block (tile, group) = 1 KB, lane-linear; sc1 (another XCD wrote it)
-            const __amdgpu_buffer_rsrc_t rsI =
-                __builtin_amdgcn_make_buffer_rsrc(him_out + (size_t)wave * TMW * g.hgp * 256, 0, TMW * g.hgp * 1024, 0x00020000);
+            // (wave w: row tiles 3w .. 3w+2; a tile beyond the 4 TPP of the image reads zeros through the bounds check)
+            const int tvalid = 4 * TPP - wave * TMW;               // tiles of this wave inside the image
+            const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(him_out + (size_t)wave * TMW * g.hgp * 256, 0,
+                                                                                 (tvalid <= 0 ? 0 : (tvalid < TMW ? tvalid : TMW)) * g.hgp * 1024, 0x00020000);
             f32x4 a[RING][TMW];
             static_for<0, RING>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
@@ -483,7 +498,7 @@ struct DecLoopCfg { int tpp; DecLoopFn fn; const char* name; };
 const DecLoopCfg kDecLoop[] = {{5, decode_loop_kernel<5>, "decloop(m320)"}, {6, decode_loop_kernel<6>, "decloop(m384)"}};
 int decloop_lds_bytes(int tpp)
 {
-    const int a = (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4, b = 4096 * 4 + 4 * tpp * kTNC * 64 * 16;      // phase A ring + gate tiles | phase B stages + accumulator slots
+    const int a = (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4, b = 4096 * 4 + 8 * 3 * kTNC * 64 * 16;      // phase A ring + gate tiles | phase B stages + accumulator slots
     return a > b ? a : b;
 }
 std::once_flag g_dl_once;
@@ -506,7 +521,7 @@ bool decode_loop_eligible(int R, int H, int E, int V)
         for (const DecLoopCfg& c : kDecLoop) {
             ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, decloop_lds_bytes(c.tpp)) == hipSuccess;
             int nb = 0;
-            ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(c.fn), 256, decloop_lds_bytes(c.tpp)) == hipSuccess && nb >= 1;
+            ok = ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(c.fn), 512, decloop_lds_bytes(c.tpp)) == hipSuccess && nb >= 1;
         }
         g_dl_ok = ok;
     });
@@ -536,7 +551,7 @@ hipError_t launch_decode_loop(const DecLoopLaunch& a, const Dec4Geom& q, hipStre
     const double flops = (2.0 * a.R * (double)(a.E + a.H) * 4.0 * a.H + 2.0 * a.R * (double)a.H * a.V) * a.Tc;
     const int ci = 14 + (q.tpp == 5 ? 0 : 1);                   // profiler slot: class 2 (vocabulary pick), beyond the gemm_kernel table
     if (!prof_wants(2, ci)) {
-        hipLaunchKernelGGL(c.fn, dim3(kDecLoopGrid), dim3(256), decloop_lds_bytes(c.tpp), st, k);
+        hipLaunchKernelGGL(c.fn, dim3(kDecLoopGrid), dim3(512), decloop_lds_bytes(c.tpp), st, k);
         e = hipGetLastError();
         return e != hipSuccess ? e : order.after(st, h.device);
     }
@@ -544,7 +559,7 @@ hipError_t launch_decode_loop(const DecLoopLaunch& a, const Dec4Geom& q, hipStre
     hipError_t pe = prof_events(&e0, &e1);
     if (pe != hipSuccess) return pe;
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(c.fn, dim3(kDecLoopGrid), dim3(256), decloop_lds_bytes(c.tpp), st, k);
+    hipLaunchKernelGGL(c.fn, dim3(kDecLoopGrid), dim3(512), decloop_lds_bytes(c.tpp), st, k);
     (void)hipEventRecord(e1, st);
     prof_record(2, ci, c.name, flops, e0, e1);
     e = hipGetLastError();
