@@ -48,11 +48,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(const TnKArgs g)
     if (g.xmap) {
         // XCD-aware order (workgroup i runs on XCD i % 8): the row panels of one (column panel, reduction slab) pair sit in
         // consecutive slots of ONE XCD, so that slab of B crosses the fabric once and the XCD's L2 serves the other panels;
-        // the pairs an XCD works on at the same time belong to the same slab and share the A slices the same way.
+        // an XCD takes a CONTIGUOUS range of pairs (slab-major), so the pairs it works on belong to one or two slabs and
+        // share those slabs' A slices (dealt round-robin, every XCD touched every slab: all of A, eight times).
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int nrow = (g.Kout + BMo - 1) / BMo;
-        const int pr = (slot / nrow) * 8 + xcd;
-        if (pr >= ntn * g.splits) return;
+        const int npr = ntn * g.splits;
+        const int pr = xcd * ((npr + 7) >> 3) + slot / nrow;
+        if (slot / nrow >= ((npr + 7) >> 3) || pr >= npr) return;
         k0 = (slot % nrow) * BMo; n0 = (pr % ntn) * BNo; mbeg = (pr / ntn) * g.mper;
     } else {
         k0 = (blockIdx.x / ntn) * BMo; n0 = (blockIdx.x % ntn) * BNo; mbeg = blockIdx.y * g.mper;
@@ -355,8 +357,9 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
     if (g.xmap) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int nrow = (g.Kout + BMo - 1) / BMo;
-        const int pr = (slot / nrow) * 8 + xcd;
-        if (pr >= ntn * g.splits) return;
+        const int npr = ntn * g.splits;
+        const int pr = xcd * ((npr + 7) >> 3) + slot / nrow;          // a contiguous, slab-major range of pairs per XCD (see gemm_tn_kernel)
+        if (slot / nrow >= ((npr + 7) >> 3) || pr >= npr) return;
         k0 = (slot % nrow) * BMo; n0 = (pr % ntn) * BNo; mbeg = (pr / ntn) * g.mper;
     } else {
         k0 = (blockIdx.x / ntn) * BMo; n0 = (blockIdx.x % ntn) * BNo; mbeg = blockIdx.y * g.mper;
