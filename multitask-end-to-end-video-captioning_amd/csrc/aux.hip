@@ -765,6 +765,8 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st)
     k.splits = splits;
     static const int xmap = [] { const char* e = getenv("S2VT_TN_XMAP"); return e ? atoi(e) : 1; }();         // dev knob
     k.xmap = xmap;
+    static const int prio = [] { const char* e = getenv("S2VT_TN_PRIO"); return e ? atoi(e) : 32; }();       // dev knob (tools/ab_tn_prio.sh)
+    k.prio_rot = prio;
     const long nrow = (a.Kout + c.BMo - 1) / c.BMo, ncol = (a.N + c.BNo - 1) / c.BNo;
     const dim3 grid = xmap ? dim3((unsigned)(8 * nrow * ((ncol * splits + 7) / 8))) : dim3((unsigned)nt, (unsigned)splits);
     k.accumulate = a.accumulate;

@@ -24,6 +24,7 @@ struct TnKArgs {
     int xmap;          // 1: one-dimensional grid, XCD-aware workgroup -> (row panel, column panel, slab) order
     int atomic;        // 1: atomicAdd into C (C pre-zeroed or accumulating); 0: plain store
     int accumulate;    // with atomic == 0: C += acc
+    int prio_rot;      // > 0: the workgroup's waves rotate their issue priority every chunk (see gemm_tn_dma_kernel)
     float* colsum;     // optional [N]: += sum_m B[m, n] (the bias gradient that goes with this weight gradient: the B tiles are
                        // in registers anyway); added by the workgroups of the first row panel, fp32 atomics; vector path only
 };
@@ -354,6 +355,12 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
     const int ntn = (g.N + BNo - 1) / BNo;
     int k0, n0, mbeg;
+    // Three workgroups share a CU and the hardware issues the OLDEST wave first: the oldest workgroup of a CU runs ahead, the
+    // three "age ranks" of an XCD drift apart by more than its L2 holds, and the A panels all of them need are fetched once per
+    // rank (dWout: 946 MB of fetches against 522 for the tile order's ideal).  prio_rot: every wave changes its issue priority
+    // each chunk, cycling 0, 1, 2 with a phase taken from the XCD-local workgroup index / 32 (co-resident workgroups differ in
+    // it under round-robin placement) -- no rank is favoured for long.
+    int prio_ph = (int)((blockIdx.x >> 3) >> 5) % 3, prio_cnt = 0;     // prio_rot = chunks per priority phase
     if (g.xmap) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         const int nrow = (g.Kout + BMo - 1) / BMo;
@@ -431,6 +438,13 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const TnKArgs g)
             constexpr bool CS = decltype(cs_)::value;
             int buf = 0, nbuf = NB - 1;                                  // the buffer multiplied / the one chunk c+NB-1 goes to
             for (int c = 0; c < nchunks; ++c) {
+                if (g.prio_rot && --prio_cnt <= 0) {                      // (uniform; s_setprio takes an immediate)
+                    prio_cnt = g.prio_rot;
+                    if (prio_ph == 0) __builtin_amdgcn_s_setprio(0);
+                    else if (prio_ph == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(2);
+                    prio_ph = prio_ph == 2 ? 0 : prio_ph + 1;
+                }
                 const f32x4* a = reinterpret_cast<const f32x4*>(As + (buf * BR + lq) * BMo + wm * 64 + l15 * 4);
                 const f32x4* b = reinterpret_cast<const f32x4*>(Bs + (buf * BR + lq) * BNo + wn * 64 + l15 * 4);
                 f32x4 av[2], bv[2];
