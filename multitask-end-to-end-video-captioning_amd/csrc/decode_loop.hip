@@ -22,8 +22,7 @@
 //
 // Same arithmetic as the launches it replaces: each z and each logit is the same ascending-k fmaf chain (carried partial,
 // embedding rows, recurrent rows; then + bias), the keys are the same expressions, ties go to the lowest column -- ids are
-// bit-identical (tests/test_gpu_decode_loop.py runs the sampler both ways, and the oracle cases in a child process with this
-// form forced on).
+// bit-identical (tests/test_gpu_decode_loop.py runs the sampler both ways in child processes: four shapes, two seeds each).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
