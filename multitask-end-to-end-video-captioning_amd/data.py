@@ -100,10 +100,16 @@ class FeatureStore:
             try:
                 import torch
                 if torch.cuda.is_available():
+                    # two staging buffers, used in turn: the training loops stage batch i + 1 while the GPU still works on
+                    # batch i, whose asynchronous copy from ITS buffer is known to have run only once step i is synchronised
                     B = len(rows)
-                    if self._pinned is None or self._pinned.shape[0] < B:
-                        self._pinned = torch.empty((B,) + self.features.shape[1:], dtype=torch.float32).pin_memory()
-                    out = self._pinned[:B]
+                    if self._pinned is None:
+                        self._pinned, self._pin_turn = [None, None], 0
+                    k = self._pin_turn
+                    self._pin_turn ^= 1
+                    if self._pinned[k] is None or self._pinned[k].shape[0] < B:
+                        self._pinned[k] = torch.empty((B,) + self.features.shape[1:], dtype=torch.float32).pin_memory()
+                    out = self._pinned[k][:B]
                     np.take(self.features, rows, axis=0, out=out.numpy())
                     return out
             except ImportError:

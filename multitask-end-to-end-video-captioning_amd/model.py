@@ -259,7 +259,9 @@ class Video_Caption_Generator:
     # -------------------------------------------------------------------------------- utilities
     def _dev(self, a, dtype):
         if isinstance(a, torch.Tensor):
-            return a.to(device=self.device, dtype=dtype).contiguous()
+            # (a pinned host tensor is copied asynchronously: the caller keeps it unchanged until the copy has run -- the
+            #  feature store's staging buffer is rewritten only after the step that used it has been synchronised)
+            return a.to(device=self.device, dtype=dtype, non_blocking=(not a.is_cuda and a.is_pinned())).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
 
     def _row_ids(self, B, rep, video_base):

@@ -126,16 +126,34 @@ class DataParallel:
         return out
 
 
-def run_step(model, fn, log=print, retries: int = 1):
+def lookahead(iterable):
+    """(item, has_next, peek) triples of an iterable: the training loops prepare batch i + 1 while the GPU works on batch i."""
+    it = iter(iterable)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
+def run_step(model, fn, log=print, retries: int = 1, overlap=None):
     """One training step with the persistent-recurrence guard: fn() runs the step and returns its statistics; the host then
     reads the loss (the synchronisation point the reference's sess.run is) and checks the library's health.  On
     S2VTChainTimeout -- a persistent LSTM recurrence was starved of CUs, e.g. by another process on the GPU -- the
     variables are intact (Adam launches behind the fault skip on the device): recover() rewinds the step counter to the
-    last applied update, switches to per-step launches, and the SAME batch is repeated."""
+    last applied update, switches to per-step launches, and the SAME batch is repeated.
+    overlap: host work that does not depend on this step's result (preparing the next batch, writing the previous step's
+    log lines); it runs once, after the step has been queued on the GPU and before the host blocks on its loss."""
     from ._lib import S2VTChainTimeout
     for attempt in range(retries + 1):
         try:
             st = fn()
+            if overlap is not None:
+                overlap, run = None, overlap
+                run()
             loss = float(st.loss)                      # device -> host: everything queued for this step has run
             model.check_health()
             return st, loss

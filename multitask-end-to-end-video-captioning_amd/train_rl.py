@@ -23,7 +23,7 @@ import time
 import numpy as np
 
 from . import hostglue, reward
-from .train_common import (Config, Corpus, DataParallel, StepLog, epoch_batches, greedy_eval, learning_rate, optimistic_restore,
+from .train_common import (Config, Corpus, DataParallel, StepLog, epoch_batches, greedy_eval, learning_rate, lookahead, optimistic_restore,
                            run_step, save_checkpoint)
 
 
@@ -65,17 +65,23 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
     steplog = StepLog(cfg.step_log if par.chief else None)
     if test_corpus is not None:
         log(f"before train: ciderD {greedy_eval(model, test_corpus, ixtoword, test_scorer, B, par)[1]}")
+    def prepare(gidx):
+        """Host side of one step: this rank's shard of the batch, its features on their way to the GPU (one copy, shared by
+        sample + update), the reward tables' rows of its videos."""
+        idx, lo = par.shard(gidx)
+        vid = caps[idx, 0]
+        return dict(lo=lo, video=model._dev(train_corpus.features.batch(vid), torch.float32),
+                    rows=np.asarray([train_corpus.index.row[v] for v in vid], np.int32))
+
     for epoch in range(cfg.n_epochs):
         losses, adv = [], []
-        for it, gidx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
-            if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
-                break
-            t0 = time.time()
-            idx, lo = par.shard(gidx)
-            vid = caps[idx, 0]
-            video = model._dev(train_corpus.features.batch(vid), torch.float32)      # one H2D copy, shared by sample + update
-            rows = np.asarray([train_corpus.index.row[v] for v in vid], np.int32)
-            rb = {}
+        batches = (g for it, g in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)) if not (cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch))
+        cur, pending, t0 = None, None, time.time()
+        for it, (gidx, gnext) in enumerate(lookahead(batches)):
+            if cur is None:
+                cur = prepare(gidx)
+            video, rows, lo = cur["video"], cur["rows"], cur["lo"]
+            rb, nxt = {}, {}
 
             def step():
                 samples, greedy_words = model.sample(video, K, True, seed=cfg.seed + 7919 * (model.global_step + 1), video_base=lo)
@@ -93,12 +99,23 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
                 return model.reinforce_update(video, samples, None, None, None, lr=learning_rate(cfg, model.global_step),
                                               clip_norm=cfg.clip_norm, video_base=lo, reuse_sampler_state=True, reward_fn=rewards,
                                               active_steps=steps)
-            st, loss = run_step(model, step, log)
+
+            def overlap():          # while the GPU runs the update: the next batch, and the previous step's log lines
+                if gnext is not None:
+                    nxt.update(prepare(gnext))
+                if pending is not None:
+                    pending()
+            st, loss = run_step(model, step, log, overlap=overlap)
             r, b = rb["r"], rb["b"]
             losses.append(loss); adv.append(float(r.mean() - b.mean()))
-            log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} loss: {losses[-1]:.5f} "
-                f"r: {r.mean():.4f} b: {b.mean():.4f} Elapsed time: {time.time() - t0:.3f}")
-            steplog.write(kind="step", epoch=epoch, step=model.global_step, lr=learning_rate(cfg, model.global_step), loss=losses[-1], reward=float(r.mean()), baseline=float(b.mean()), seconds=time.time() - t0)
+            t1 = time.time()
+
+            def pending(it=it, loss=loss, lr=learning_rate(cfg, model.global_step), step=model.global_step, rm=float(r.mean()), bm=float(b.mean()), secs=t1 - t0):
+                log(f"idx: {it * cfg.batch_size} rate: {lr:g} Epoch: {epoch} loss: {loss:.5f} r: {rm:.4f} b: {bm:.4f} Elapsed time: {secs:.3f}")
+                steplog.write(kind="step", epoch=epoch, step=step, lr=lr, loss=loss, reward=rm, baseline=bm, seconds=secs)
+            t0, cur = t1, (nxt if gnext is not None else None)
+        if pending is not None:
+            pending()
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None, "r_minus_b": float(np.mean(adv)) if adv else None}
         if test_corpus is not None:
             _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, test_scorer, B, par)

@@ -12,10 +12,11 @@ import random
 import time
 
 import numpy as np
+import torch
 
 from . import hostglue, reward
-from .train_common import (Config, Corpus, DataParallel, StepLog, epoch_batches, greedy_eval, learning_rate, optimistic_restore, run_step,
-                           save_checkpoint)
+from .train_common import (Config, Corpus, DataParallel, StepLog, epoch_batches, greedy_eval, learning_rate, lookahead, optimistic_restore,
+                           run_step, save_checkpoint)
 
 
 def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, log=print, resume=None):
@@ -39,27 +40,44 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
     caps = train_corpus.captions
     history = []
     steplog = StepLog(cfg.step_log if par.chief else None)
+    def prepare(gidx):
+        """Host side of one step: this rank's shard of the batch, padded captions, features staged for the copy to the GPU."""
+        idx, lo = par.shard(gidx)
+        vid = caps[idx, 0]
+        # the GLOBAL batch is padded (64 short strings) so that every rank knows its longest caption: the steps behind
+        # it are all padding on every rank and are not unrolled (Q1's batch mean couples the ranks at a live step)
+        g_ind, g_mask = hostglue.sentence_padding_toix(caps[gidx, 1].tolist(), wordtoix, cfg.n_caption_lstm_step)
+        g_mask = np.asarray(g_mask, np.float32)
+        return dict(lo=lo, ind=np.asarray(g_ind, np.int32)[lo:lo + len(idx)], mask=g_mask[lo:lo + len(idx)],
+                    steps=model.active_steps(g_mask), feats=model._dev(train_corpus.features.batch(vid), torch.float32))
+
     for epoch in range(cfg.n_epochs):
         losses = []
-        for it, gidx in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)):
-            if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
-                break
-            t0 = time.time()
-            idx, lo = par.shard(gidx)
-            vid = caps[idx, 0]
-            # the GLOBAL batch is padded (64 short strings) so that every rank knows its longest caption: the steps behind
-            # it are all padding on every rank and are not unrolled (Q1's batch mean couples the ranks at a live step)
-            g_ind, g_mask = hostglue.sentence_padding_toix(caps[gidx, 1].tolist(), wordtoix, cfg.n_caption_lstm_step)
-            captions_ind, captions_mask = np.asarray(g_ind, np.int32)[lo:lo + len(idx)], np.asarray(g_mask, np.float32)[lo:lo + len(idx)]
-            steps = model.active_steps(np.asarray(g_mask))
-            feats = train_corpus.features.batch(vid)
-            st, loss = run_step(model, lambda: model.xe_update(feats, captions_ind, captions_mask,
-                                                               lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm,
-                                                               video_base=lo, active_steps=steps), log)
+        batches = (g for it, g in enumerate(epoch_batches(len(caps), cfg.batch_size, rng)) if not (cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch))
+        cur, pending, t0 = None, None, time.time()
+        for it, (gidx, gnext) in enumerate(lookahead(batches)):
+            if cur is None:
+                cur = prepare(gidx)
+            nxt = {}
+
+            def overlap():          # while the GPU runs this step: the next batch, and the previous step's log lines
+                if gnext is not None:
+                    nxt.update(prepare(gnext))
+                if pending is not None:
+                    pending()
+            b = cur
+            st, loss = run_step(model, lambda: model.xe_update(b["feats"], b["ind"], b["mask"], lr=learning_rate(cfg, model.global_step),
+                                                               clip_norm=cfg.clip_norm, video_base=b["lo"], active_steps=b["steps"]),
+                                log, overlap=overlap)
             losses.append(loss)
-            log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
-                f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")
-            steplog.write(kind="step", epoch=epoch, step=model.global_step, lr=learning_rate(cfg, model.global_step), loss=losses[-1], seconds=time.time() - t0)
+            t1 = time.time()
+
+            def pending(it=it, loss=loss, lr=learning_rate(cfg, model.global_step), step=model.global_step, secs=t1 - t0):
+                log(f"idx: {it * cfg.batch_size} rate: {lr:g} Epoch: {epoch} loss: {loss:.5f} Elapsed time: {secs:.3f}")
+                steplog.write(kind="step", epoch=epoch, step=step, lr=lr, loss=loss, seconds=secs)
+            t0, cur = t1, (nxt if gnext is not None else None)
+        if pending is not None:
+            pending()
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None}
         if test_corpus is not None:
             _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, scorer, B, par)
