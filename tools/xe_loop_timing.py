@@ -15,7 +15,9 @@ corpus.captions = np.asarray(sents)
 corpus.features = data.FeatureStore(np.abs(rng.standard_normal((nvid, Tv, D)) * 0.5).astype(np.float32), [f"vid{v}" for v in range(nvid)])
 corpus.vocabulary = vocab
 corpus.index = data.CaptionIndex(corpus.captions)
-cfg = tc.Config(n_epochs=1, batch_size=64, max_steps_per_epoch=int(sys.argv[1]) if len(sys.argv) > 1 else 30, model_path="/tmp/xe_timing")
+cfg = tc.Config(n_epochs=1, batch_size=64, max_steps_per_epoch=int(sys.argv[1]) if len(sys.argv) > 1 else 30, model_path="/tmp/xe_timing", step_log="/tmp/xe_timing_steps.jsonl")
+if os.path.exists("/tmp/xe_timing_steps.jsonl"):
+    os.remove("/tmp/xe_timing_steps.jsonl")
 times = []
 
 
@@ -25,4 +27,7 @@ def log(msg):
 
 
 train_xe.train(cfg, corpus, None, log=log)
+import json
+secs = [json.loads(l)["seconds"] for l in open("/tmp/xe_timing_steps.jsonl") if '"kind": "step"' in l]
+print(f"step log: median {1e3 * np.median(secs[3:]):.3f} ms, p10 {1e3 * np.percentile(secs[3:], 10):.3f}, p90 {1e3 * np.percentile(secs[3:], 90):.3f}")
 print(f"{len(times)} steps; median wall per XE step {1e3 * np.median(times[3:]):.2f} ms at B=64, Tc=35 -> {64 / np.median(times[3:]):.0f} captions/s")
