@@ -213,6 +213,18 @@ int s2vt_teacher_forced_fwd_steps(const s2vt_dims* d, const s2vt_params* p, cons
                                   size_t workspace_bytes, const void* sampler_workspace, size_t sampler_workspace_bytes,
                                   int32_t sampler_rows, s2vt_stream stream);
 
+/* Same, and the vocabulary projection only for the LIVE (step, row) pairs: live_rows[r] (ascending, < caption_steps * N,
+ * time-major index t * N + n) names the unrolled row whose logits land in row r of logits_out [n_live, V].  A position behind a
+ * sample's first <eos> is masked (cider_evaluation.py:145-172): its logits feed nothing, its loss term and every gradient
+ * contribution are exact zeros -- on a trained model's samples (8 of 20 positions live) the four vocabulary-sized kernels of a
+ * step (logits, softmax, dWout, dO2: a third of it) shrink with the live fraction.  The recurrences are unchanged.
+ * live_rows == NULL (n_live == 0): every row, as s2vt_teacher_forced_fwd_steps.  Pair it with s2vt_bptt_bwd_live on the same list. */
+int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
+                                 const int32_t* caption, int32_t caption_steps, const int32_t* live_rows, int32_t n_live, float keep,
+                                 uint64_t seed, const int32_t* video_id, const int32_t* sample_id, float* logits_out,
+                                 void* workspace, size_t workspace_bytes, const void* sampler_workspace,
+                                 size_t sampler_workspace_bytes, int32_t sampler_rows, s2vt_stream stream);
+
 /* ---- softmax / NLL rows, forward + backward ----------------------------------------------------
  * nll[r] = -sum_v q[v] * log_softmax(logits[r])[v],  q = onehot(target[r])*(1-s) + s/V
  * (tf.losses.softmax_cross_entropy(label_smoothing=s), tf_s2vt.py:155; s = 0 gives the
@@ -252,6 +264,13 @@ int s2vt_bptt_bwd_steps(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                         int32_t N, const float* dlogits, int32_t caption_steps, float keep, uint64_t seed,
                         const int32_t* video_id, const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase,
                         s2vt_stream stream);
+
+/* The backward of s2vt_teacher_forced_fwd_live: dlogits is [n_live, V] (row r = unrolled row live_rows[r]); the vocabulary
+ * gradients are reduced over the live rows, the gradient w.r.t. LSTM2's outputs is computed for them and is zero elsewhere. */
+int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
+                       int32_t N, const float* dlogits, int32_t caption_steps, const int32_t* live_rows, int32_t n_live, float keep,
+                       uint64_t seed, const int32_t* video_id, const int32_t* sample_id, void* workspace, size_t workspace_bytes,
+                       int32_t phase, s2vt_stream stream);
 
 /* Gradient w.r.t. the frame features, for the end-to-end scripts where they are the CNN's output
  * (e2e_tf_s2vt.py:106-121,163-166: the optimizer differentiates through `video` into Inception-ResNet-v2):

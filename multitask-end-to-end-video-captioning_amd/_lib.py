@@ -72,6 +72,8 @@ SIGNATURES = {
     "s2vt_teacher_forced_fwd_reuse": (C.c_int, [_DP, _PP, _vp, _i32, _i32, _vp, _f32, _u64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i32, _vp]),
     "s2vt_gemm_nt_splitk": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "s2vt_teacher_forced_fwd_steps": (C.c_int, [_DP, _PP, _vp, _i32, _i32, _vp, _i32, _f32, _u64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i32, _vp]),
+    "s2vt_teacher_forced_fwd_live": (C.c_int, [_DP, _PP, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _f32, _u64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i32, _vp]),
+    "s2vt_bptt_bwd_live": (C.c_int, [_DP, _PP, _PP, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _f32, _u64, _vp, _vp, _vp, _sz, _i32, _vp]),
     "s2vt_bptt_bwd_steps": (C.c_int, [_DP, _PP, _PP, _vp, _i32, _i32, _vp, _i32, _f32, _u64, _vp, _vp, _vp, _sz, _i32, _vp]),
     "s2vt_softmax_nll_fwd_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp]),
     "s2vt_softmax_unshifted_argmax": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),

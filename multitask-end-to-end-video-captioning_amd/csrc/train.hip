@@ -35,6 +35,8 @@ struct TrainWs {
     float *bimg, *bex;   // persistent BACKWARD recurrence scratch (chain.hip): dz images, partial-tile exchange
     unsigned* bsync;
     float* dO2s;         // split-K slabs of dO2 = dlogits @ Wout^T when it has few rows (NULL otherwise)
+    size_t dO2s_rows;    // ... rows x slabs it holds
+    float* dO2p;         // dO2 of the LIVE rows only (the *_live entry points), scattered into dO2
     float* dXs;          // split-K slabs of dX2 / dX1 when they are short of tiles (NULL otherwise)
 };
 
@@ -120,6 +122,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.G2 = c.take<float>(T * n * 4 * H); w.C2 = c.take<float>((T + 1) * n * H); w.H2 = c.take<float>((T + 1) * n * H);
     w.O2 = c.take<float>(T * n * H);
     w.dO2 = c.take<float>(Tc * n * H);
+    w.dO2p = c.take<float>(Tc * n * H);
     w.dZ1 = c.take<float>(T * b * 4 * H); w.dZ2 = c.take<float>(T * n * 4 * H);
     w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * b * E); w.dH1 = c.take<float>(T * b * H);
     w.slab = c.take<float>((size_t)kMaxSlabs * n * H); w.dc = c.take<float>(n * H);
@@ -140,6 +143,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
             if (s2 > 1 && (size_t)s2 * tc * n > need) need = (size_t)s2 * tc * n;
         }
         w.dO2s = need ? c.take<float>(need * H) : nullptr;
+        w.dO2s_rows = need;
     }
     {
         size_t need = 0;
@@ -335,6 +339,17 @@ int s2vt_teacher_forced_fwd_steps(const s2vt_dims* d, const s2vt_params* p, cons
                                   size_t workspace_bytes, const void* sampler_workspace, size_t sampler_workspace_bytes,
                                   int32_t sampler_rows, s2vt_stream stream)
 {
+    return s2vt_teacher_forced_fwd_live(d, p, video, B, N, caption, caption_steps, nullptr, 0, keep, seed, video_id, sample_id, logits,
+                                        workspace, workspace_bytes, sampler_workspace, sampler_workspace_bytes, sampler_rows, stream);
+}
+
+int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
+                                 const int32_t* caption, int32_t caption_steps, const int32_t* live_rows, int32_t n_live, float keep,
+                                 uint64_t seed, const int32_t* video_id, const int32_t* sample_id, float* logits, void* workspace,
+                                 size_t workspace_bytes, const void* sampler_workspace, size_t sampler_workspace_bytes,
+                                 int32_t sampler_rows, s2vt_stream stream)
+{
+    if ((live_rows == nullptr) != (n_live == 0) || n_live < 0) return S2VT_E_BADARG;
     if (!dims_ok(d) || !params_ok(p) || !video || !caption || !logits || !workspace || B <= 0 || N <= 0 || N % B)
         return S2VT_E_BADARG;
     if (!(keep > 0.0f) || (keep < 1.0f && (!video_id || !sample_id))) return S2VT_E_BADARG;
@@ -404,9 +419,11 @@ int s2vt_teacher_forced_fwd_steps(const s2vt_dims* d, const s2vt_params* p, cons
     // the recurrence continues each chain from its partial in G2[t] and overwrites it with the activated gates
     HIP_TRY(lstm_recurrence(p->lstm2_W, H + E, p->lstm2_b, w.G2, (size_t)4 * NH, 4 * H, T, w.C2, w.H2, NH, w.G2, (size_t)4 * NH,
                             w.O2, NH, N, H, T, keep, ids, 512u, w.chain_abuf, w.chain_sync, st));
-    // vocab logits for all Tc steps at once (tf_s2vt.py:153): rows t*N + n
-    ASeg so = make_seg(w.O2 + (size_t)Tv * NH, H, H, 0);
-    HIP_TRY(store_call(&so, 1, p->embed_word_W, V, p->embed_word_b, logits, V, Tc * N, V, 0, -1, st));
+    // vocab logits for all Tc steps at once (tf_s2vt.py:153): rows t*N + n -- or only the LIVE ones (row r of the output is
+    // row live_rows[r] of the unroll: a masked position's logits feed nothing, its loss term and gradient are exact zeros)
+    if (live_rows && n_live > Tc * N) return S2VT_E_BADARG;
+    ASeg so = make_seg(w.O2 + (size_t)Tv * NH, H, H, 0, 0, live_rows);
+    HIP_TRY(store_call(&so, 1, p->embed_word_W, V, p->embed_word_b, logits, V, live_rows ? n_live : Tc * N, V, 0, -1, st));
     return S2VT_OK;
 }
 
@@ -495,6 +512,16 @@ int s2vt_bptt_bwd_steps(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                         const int32_t* video_id, const int32_t* sample_id, void* workspace, size_t workspace_bytes, int32_t phase,
                         s2vt_stream stream)
 {
+    return s2vt_bptt_bwd_live(d, p, grads, video, B, N, dlogits, caption_steps, nullptr, 0, keep, seed, video_id, sample_id, workspace,
+                              workspace_bytes, phase, stream);
+}
+
+int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
+                       int32_t N, const float* dlogits, int32_t caption_steps, const int32_t* live_rows, int32_t n_live, float keep,
+                       uint64_t seed, const int32_t* video_id, const int32_t* sample_id, void* workspace, size_t workspace_bytes,
+                       int32_t phase, s2vt_stream stream)
+{
+    if ((live_rows == nullptr) != (n_live == 0) || n_live < 0) return S2VT_E_BADARG;
     if (phase < 0 || phase > 4) return S2VT_E_BADARG;
     if (!dims_ok(d) || !params_ok(p) || !params_ok(grads) || !video || !dlogits || !workspace || B <= 0 || N <= 0 || N % B)
         return S2VT_E_BADARG;
@@ -524,17 +551,31 @@ int s2vt_bptt_bwd_steps(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
         // transposed weight copy for the data-gradient product + the vocab projection
         hipStream_t sv = phase == 0 ? sd : st;              // (phase 1: its gradients must be final on the caller's stream)
         if (sv != st) HIP_TRY(fork_to(st, sv, ss.ev[0]));
-        TnArgs a{w.O2 + (size_t)Tv * NH, nullptr, H, dlogits, V, grads->embed_word_W, V, Tc * N, H, V, 1};
+        // rows of the vocabulary-side products: every unrolled (step, row) pair, or the LIVE ones only (dlogits is then
+        // [n_live, V], row r belonging to row live_rows[r] of the unroll; the masked rows' dlogits are exact zeros in the full
+        // form, so leaving them out of the reductions changes nothing and their dO2 rows are the zeros written below)
+        const int R = live_rows ? n_live : Tc * N;
+        if (live_rows && n_live > Tc * N) return S2VT_E_BADARG;
+        TnArgs a{w.O2 + (size_t)Tv * NH, live_rows, H, dlogits, V, grads->embed_word_W, V, R, H, V, 1};
+        a.gather_rows = live_rows ? Tc * N : 0;
         a.colsum = grads->embed_word_b;                     // the bias gradient rides in the same pass over dlogits
         HIP_TRY(launch_gemm_tn(a, sv));
-        const int s2 = w.dO2s ? do2_splits(Tc * N, H, V) : 1;
+        float* const dO2t = live_rows ? w.dO2p : w.dO2;     // where the product lands: packed rows are scattered afterwards
+        int s2 = w.dO2s ? do2_splits(R, H, V) : 1;
+        if ((size_t)s2 * R > w.dO2s_rows) s2 = 1;            // (a live-row count between two step counts the carve did not see)
         if (s2 > 1) {
-            const size_t stride = (size_t)Tc * N * H;
-            HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2s, H, Tc * N, H, V, s2, stride, st, kSlabTileCfg));
+            const size_t stride = (size_t)R * H;
+            HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2s, H, R, H, V, s2, stride, st, kSlabTileCfg));
             const int kper = ((V + s2 - 1) / s2 + BK - 1) / BK * BK;       // what nn_bwd made of `splits`
-            HIP_TRY(launch_sum_slabs(w.dO2, w.dO2s, (V + kper - 1) / kper, stride, stride, st));
+            HIP_TRY(launch_sum_slabs(dO2t, w.dO2s, (V + kper - 1) / kper, stride, stride, st));
         } else {
-            HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, w.dO2, H, Tc * N, H, V, 1, 0, st));
+            HIP_TRY(nn_bwd(dlogits, V, p->embed_word_W, V, dO2t, H, R, H, V, 1, 0, st));
+        }
+        if (live_rows) {
+            ZeroList z;
+            z.add(w.dO2, (size_t)Tc * N * H * 4);
+            HIP_TRY(launch_zero_regions(z, st));
+            HIP_TRY(launch_scatter_add_rows(w.dO2p, H, live_rows, R, H, w.dO2, H, st));      // (distinct rows: an exact copy)
         }
     }
     if (do_l2) {

@@ -365,6 +365,26 @@ class Video_Caption_Generator:
         live = np.flatnonzero(np.asarray(m != 0).any(axis=0))
         return int(live[-1]) + 1 if live.size else 1
 
+    def live_rows(self, mask, steps):
+        """int32 device tensor of the unmasked (step, row) pairs of the first `steps` decode steps -- time-major index t * N + n,
+        ascending -- or None when the mask is not host-resident or so few positions are masked that packing them out would not
+        pay (> 85 % live).  The vocabulary-sized kernels of an update (logits, softmax, dWout, dO2) run on these rows only;
+        the others' loss terms and gradient contributions are exact zeros (ops.teacher_forced_fwd(live=))."""
+        if isinstance(mask, torch.Tensor):
+            if mask.is_cuda:
+                return None
+            mask = mask.numpy()
+        if mask is None:
+            return None
+        m = np.asarray(mask)
+        if m.ndim != 2 or m.size == 0:
+            return None
+        tm = np.ascontiguousarray(m[:, :steps].T).reshape(-1)
+        live = np.flatnonzero(tm != 0).astype(np.int32)
+        if live.size == 0 or live.size > 0.85 * tm.size:
+            return None
+        return torch.as_tensor(live).to(self.device)
+
     def _steps(self, active_steps, mask, local_ok=True):
         """Resolve an update method's `active_steps` argument: an int (clamped to 1..Tc), None / 0 = the full unroll, "auto" =
         from a host-resident mask when the local mask decides it (local_ok: single process, or rows that do not couple
@@ -380,7 +400,7 @@ class Video_Caption_Generator:
         return max(1, min(Tc, int(active_steps)))
 
     def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep, reuse_sampler_state=False, target_tm=None,
-                      steps=None):
+                      steps=None, live=None):
         """Teacher-forced forward + softmax-NLL fwd/bwd.  caption [N,Tc] int32 device, coef_tm
         time-major [Tc*N].  Leaves dlogits + activations ready for backward().  steps < Tc: only the first `steps` decode
         steps are unrolled (the caller vouches that coef_tm is zero behind them); nll / lp then have steps*N entries."""
@@ -403,14 +423,21 @@ class Video_Caption_Generator:
                                    "weights, as the last sampler call before the update")
             state = (ls[0], ls[1])
         logits, ws = ops.teacher_forced_fwd(self.dims, self.store.params, video, caption, N, keep, seed, vid, sid,
-                                            sampler_state=state, steps=steps)
+                                            sampler_state=state, steps=steps, live=live)
         if callable(coef_tm):            # host work (the reward) runs here, beside the forward just queued on the GPU
             coef_tm = coef_tm()
         target = caption.t().contiguous().view(-1) if target_tm is None else target_tm
         if isinstance(smoothing, torch.Tensor):
             smoothing = smoothing[:R]
-        nll, lp = ops.softmax_nll_fwd_bwd(logits, target[:R], coef_tm[:R], smoothing)      # (time-major: a prefix)
-        self._ctx = (video, N, logits, ws, keep, seed, vid, sid, steps)
+        target, coef = target[:R], coef_tm[:R]                  # (time-major: a prefix)
+        if live is not None:                                    # ... and of that, the unmasked positions (nll / lp: one entry per live row)
+            ix = live.long()
+            target, coef = target[ix].contiguous(), coef[ix].contiguous()
+            if isinstance(smoothing, torch.Tensor):
+                smoothing = smoothing[ix].contiguous()
+        nll, lp = ops.softmax_nll_fwd_bwd(logits, target, coef, smoothing)
+        self._coef_used = coef
+        self._ctx = (video, N, logits, ws, keep, seed, vid, sid, steps, live)
         return nll, lp
 
     def backward(self, accumulate=False, overlap=None, keep_tail=False):
@@ -423,7 +450,7 @@ class Video_Caption_Generator:
         rank under RCCL, tests/test_gpu_rccl.py -- no multi-GPU box was available to the build)."""
         if overlap is None:
             overlap = self.dp_overlap
-        video, N, dlogits, ws, keep, seed, vid, sid, steps = self._ctx
+        video, N, dlogits, ws, keep, seed, vid, sid, steps, live = self._ctx
         st = self.store
         if not accumulate:
             (st.grad[:st.numel] if keep_tail else st.grad).zero_()     # keep_tail: sum(mask) already sits in the tail slot (ops.caption_mask)
@@ -433,17 +460,17 @@ class Video_Caption_Generator:
             def span(first, last):
                 return st.offsets[first], st.offsets[last] + (int(np.prod(st.shapes[last])) + 63) // 64 * 64
             args = (self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid)
-            ops.bptt_bwd(*args, phase=1, steps=steps)
+            ops.bptt_bwd(*args, phase=1, steps=steps, live=live)
             lo1, hi1 = span("embed_word_W", "embed_word_b")
             self._pending.append(dp.allreduce_async(st.grad[lo1:hi1]))
-            ops.bptt_bwd(*args, phase=3, steps=steps)
+            ops.bptt_bwd(*args, phase=3, steps=steps, live=live)
             lo2, hi2 = span("lstm2_W", "lstm2_W")
             assert hi2 == lo1, "bucket layout: lstm2_W sits right below embed_word_W"
             self._pending.append(dp.allreduce_async(st.grad[lo2:hi2]))
             self._early = (lo2, hi1)                       # [lo2, hi1) is already on its way
-            ops.bptt_bwd(*args, phase=4, steps=steps)
+            ops.bptt_bwd(*args, phase=4, steps=steps, live=live)
         else:
-            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, steps=steps)
+            ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, steps=steps, live=live)
 
     def video_grad(self):
         """d(loss * sum(mask)) / d(video) [B, Tv, dim_image] of the pass backward() just ran -- the gradient the
@@ -532,7 +559,8 @@ class Video_Caption_Generator:
         return self.global_step, lost
 
     def reinforce_update(self, video, sampled, mask, rewards, baseline, lr, clip_norm=5.0, video_base=0, keep=None,
-                         true_labels=None, reuse_sampler_state=False, extra_sumsq=None, reward_fn=None, active_steps="auto"):
+                         true_labels=None, reuse_sampler_state=False, extra_sumsq=None, reward_fn=None, active_steps="auto",
+                         live_mask="auto"):
         """build_loss + the REINFORCE objective and train_op of train()
         (reinforcement_multisampling_tf_s2vt.py:227-292, 633-652): sampled [N,Tc] ids, mask [N,Tc] (None: derived from the
         ids on the device -- 1 up to and including the first <eos> -- with the coefficients, sum(mask) and the loss in three
@@ -547,8 +575,12 @@ class Video_Caption_Generator:
         `baseline` are ignored then.
         active_steps: decode steps to unroll -- "auto" (default): behind the longest sample of the batch every position is
         masked, so when `mask` is host-resident (numpy / CPU tensor, as the reference's loop has it) only the steps up
-        to it run; an int: the caller's own count; None: all Tc.  Exact: the skipped steps add zeros."""
+        to it run; an int: the caller's own count; None: all Tc.  Exact: the skipped steps add zeros.
+        live_mask: a HOST mask [N, Tc] naming the unmasked positions ("auto": `mask` itself when it is host-resident; None:
+        off): inside the unrolled steps the vocabulary projection, the softmax and their two gradient products run on those
+        (step, row) pairs only (live_rows()) -- exact as well: a masked position's coefficient is zero."""
         steps = self._steps(active_steps, mask)
+        live = self.live_rows(mask if isinstance(live_mask, str) else live_mask, steps) if live_mask is not None else None
         video = self._dev(video, torch.float32)
         cap = self._dev(sampled, torch.int32)
         st_ = self.store
@@ -574,8 +606,8 @@ class Video_Caption_Generator:
             return made["coef"]
         keep = self.dropout_rate if keep is None else keep
         nll, _ = self._forward_loss(video, cap, make_coef, 0.0, rep, video_base, keep, reuse_sampler_state, target_tm=target_tm,
-                                    steps=steps)
-        coef = made["coef"][:nll.numel()]
+                                    steps=steps, live=live)
+        coef = self._coef_used
         if not fused:
             msum = mask.sum().reshape(1)
         self.backward(keep_tail=fused)
@@ -596,13 +628,17 @@ class Video_Caption_Generator:
         return st
 
     def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, q1=True, smoothing=0.05, video_base=0, keep=None,
-                  extra_sumsq=None, decay_all=False, active_steps="auto"):
+                  extra_sumsq=None, decay_all=False, active_steps="auto", live_mask="auto"):
         """build_model + train_op of tf_s2vt.py:90-167,445-448 (label smoothing 0.05, Q1 batch-mean
         semantics, weight decay on the non-'bias' variables, clip 10).
         active_steps: as reinforce_update -- the padding behind the longest caption of the batch is not unrolled.  "auto"
         reads a host-resident caption_mask; data parallel with q1 it needs the GLOBAL batch's longest caption, which only the
-        caller knows (train_xe passes it), so "auto" keeps the full unroll there."""
+        caller knows (train_xe passes it), so "auto" keeps the full unroll there.
+        live_mask: as reinforce_update, without Q1 only (with Q1 every row of a live step carries the step's batch mean)."""
         steps = self._steps(active_steps, caption_mask, local_ok=not q1)
+        live = None
+        if not q1 and live_mask is not None:
+            live = self.live_rows(caption_mask if isinstance(live_mask, str) else live_mask, steps)
         video = self._dev(video, torch.float32)
         cap = self._dev(caption, torch.int32)
         mask = self._dev(caption_mask, torch.float32)
@@ -616,8 +652,8 @@ class Video_Caption_Generator:
             coef = mask.t() * self.loss_weight
         coef = coef.contiguous().view(-1)
         keep = self.dropout_rate if keep is None else keep
-        nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep, steps=steps)
-        coef = coef[:nll.numel()]
+        nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep, steps=steps, live=live)
+        coef = self._coef_used
         msum = mask.sum().reshape(1)
         self.backward()
         self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value, extra_sumsq=extra_sumsq, decay_all=decay_all,
@@ -641,6 +677,15 @@ class Video_Caption_Generator:
             sa, sb = self.active_steps(mask), self.active_steps(gt_mask)
             active_steps = None if (sa is None or sb is None or (q1 and self.world_size > 1)) else max(sa, sb)
         steps = self._steps(active_steps, None)
+        live = None
+        if not isinstance(mask, torch.Tensor) and not isinstance(gt_mask, torch.Tensor) and mask is not None and gt_mask is not None \
+                and not (q1 and self.world_size > 1):
+            # host masks: the sampled rows are live where their own mask is, the ground-truth rows wherever their coefficient is
+            # non-zero -- with Q1 every row of a step at which ANY ground-truth caption is unmasked
+            mp, mg = np.asarray(mask, np.float32), np.asarray(gt_mask, np.float32)
+            if q1:
+                mg = np.broadcast_to((mg != 0).any(0, keepdims=True), mg.shape)
+            live = self.live_rows(np.concatenate([mp, mg.astype(np.float32)], 0), steps)
         video = self._dev(video, torch.float32)
         cap = self._dev(sampled, torch.int32)
         mask = self._dev(mask, torch.float32)
@@ -667,10 +712,15 @@ class Video_Caption_Generator:
         smooth[rep * B:] = float(smoothing)
         smooth_tm = smooth.repeat(self.n_caption_lstm_step).contiguous()
         nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, rep + 1, video_base, keep,
-                                    steps=steps)
+                                    steps=steps, live=live)
         N = (rep + 1) * B
-        per_row = (coef[:nll.numel()] * nll).view(-1, N)
-        loss_pg, loss_xe = per_row[:, :rep * B].sum(), per_row[:, rep * B:].sum()
+        terms = self._coef_used * nll
+        if live is None:
+            per_row = terms.view(-1, N)
+            loss_pg, loss_xe = per_row[:, :rep * B].sum(), per_row[:, rep * B:].sum()
+        else:                                                    # (row of the unroll = live index % N: sampled rows first)
+            is_pg = (live.long() % N) < rep * B
+            loss_pg, loss_xe = terms[is_pg].sum(), terms[~is_pg].sum()
         self.backward(accumulate=False, overlap=False)
         attr_scale = attr_loss = None
         if true_labels is not None and self.label_dim > 0:

@@ -242,12 +242,14 @@ def train_workspace(dims: Dims, B: int, N: int, device):
 
 
 def teacher_forced_fwd(dims: Dims, params: Params, video, caption, N: int, keep=1.0, seed=0, video_id=None,
-                       sample_id=None, ws=None, logits=None, sampler_state=None, steps=None):
+                       sample_id=None, ws=None, logits=None, sampler_state=None, steps=None, live=None):
     """Teacher-forced unroll on N = rep*B sample-major rows.  Returns time-major logits [Tc*N, V].
     sampler_state = (workspace tensor, rows) of the sample() call of the same step on the same video block:
     LSTM1's trajectory is taken from it instead of being recomputed.
     steps (1..Tc): unroll only the first `steps` decode steps (every later position of the batch is masked); logits
-    is then [steps*N, V].  caption stays [N, Tc]."""
+    is then [steps*N, V].  caption stays [N, Tc].
+    live: int32 device tensor of the unrolled rows (time-major index t*N + n, ascending) whose logits are wanted: logits is
+    [len(live), V], the vocabulary projection of every other row is skipped."""
     _chk_f32(video)
     assert caption.is_cuda and caption.dtype == torch.int32 and caption.is_contiguous() and caption.shape[0] == N
     assert caption.shape[1] == dims.n_caption_lstm_step
@@ -255,11 +257,16 @@ def teacher_forced_fwd(dims: Dims, params: Params, video, caption, N: int, keep=
     steps = dims.n_caption_lstm_step if steps is None else int(steps)
     if ws is None:
         ws = train_workspace(dims, B, N, video.device)
+    R = steps * N
+    if live is not None:
+        assert live.is_cuda and live.dtype == torch.int32 and live.is_contiguous() and live.dim() == 1
+        R = live.numel()
     if logits is None:
-        logits = torch.empty((steps * N, dims.n_words), dtype=torch.float32, device=video.device)
-    assert logits.shape[0] == steps * N
+        logits = torch.empty((R, dims.n_words), dtype=torch.float32, device=video.device)
+    assert logits.shape[0] == R
     sws, srows = sampler_state if sampler_state is not None else (None, 0)
-    check(lib().s2vt_teacher_forced_fwd_steps(C.byref(dims), C.byref(params), _ptr(video), B, N, _ptr(caption), steps, float(keep), seed,
+    check(lib().s2vt_teacher_forced_fwd_live(C.byref(dims), C.byref(params), _ptr(video), B, N, _ptr(caption), steps,
+                                             _ptr(live), 0 if live is None else live.numel(), float(keep), seed,
                                               _ptr(video_id), _ptr(sample_id), _ptr(logits), _ptr(ws), ws.numel(), _ptr(sws),
                                               0 if sws is None else sws.numel(), srows, _stream()),
           "s2vt_teacher_forced_fwd")
@@ -297,14 +304,15 @@ def softmax_unshifted_argmax(logits, want_probs=False):
 
 
 def bptt_bwd(dims: Dims, params: Params, grads: Params, video, N: int, dlogits, ws, keep=1.0, seed=0, video_id=None,
-             sample_id=None, phase=0, steps=None):
+             sample_id=None, phase=0, steps=None, live=None):
     """phase 0 = the whole backward; 1 = vocab projection only; 2 = the rest (data-parallel overlap).
     steps: what the forward call (teacher_forced_fwd) was given."""
     _chk_f32(video, dlogits)
     steps = dims.n_caption_lstm_step if steps is None else int(steps)
-    assert dlogits.shape[0] == steps * N
-    check(lib().s2vt_bptt_bwd_steps(C.byref(dims), C.byref(params), C.byref(grads), _ptr(video), video.shape[0], N, _ptr(dlogits),
-                                    steps, float(keep), seed, _ptr(video_id), _ptr(sample_id), _ptr(ws), ws.numel(), phase, _stream()),
+    assert dlogits.shape[0] == (steps * N if live is None else live.numel())
+    check(lib().s2vt_bptt_bwd_live(C.byref(dims), C.byref(params), C.byref(grads), _ptr(video), video.shape[0], N, _ptr(dlogits),
+                                   steps, _ptr(live), 0 if live is None else live.numel(), float(keep), seed, _ptr(video_id),
+                                   _ptr(sample_id), _ptr(ws), ws.numel(), phase, _stream()),
           "s2vt_bptt_bwd")
 
 

@@ -98,7 +98,7 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
                 steps = int(np.where(eos.any(1), eos.argmax(1) + 1, s_host.shape[1]).max())
                 return model.reinforce_update(video, samples, None, None, None, lr=learning_rate(cfg, model.global_step),
                                               clip_norm=cfg.clip_norm, video_base=lo, reuse_sampler_state=True, reward_fn=rewards,
-                                              active_steps=steps)
+                                              active_steps=steps, live_mask=hostglue.masks_from_ids(s_host))
 
             def overlap():          # while the GPU runs the update: the next batch, and the previous step's log lines
                 if gnext is not None:

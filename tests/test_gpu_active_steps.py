@@ -107,15 +107,17 @@ def test_updates_with_and_without_the_padding_steps(gpu, oracle, mode):
         mdl.store.load(p)
         if mode == "xe_q1":
             st = mdl.xe_update(video, cap, mask, lr=1e-3, q1=True, active_steps=active)
-        elif mode == "xe_plain":
-            st = mdl.xe_update(video, cap, mask, lr=1e-3, q1=False, active_steps=active)
+        elif mode == "xe_plain":                           # (without Q1 the second run also packs the masked positions out: live rows)
+            st = mdl.xe_update(video, cap, mask, lr=1e-3, q1=False, active_steps=active, live_mask=None if active is None else "auto")
+            assert (mdl._ctx[9] is not None) == (active is not None)
         elif mode == "pg":
-            st = mdl.reinforce_update(video, cap, mask, r, b, lr=1e-3, active_steps=active)
+            st = mdl.reinforce_update(video, cap, mask, r, b, lr=1e-3, active_steps=active, live_mask=None)
         elif mode == "pg_fused_ids":                     # mask derived on the device: the caller passes the count (train_rl does)
             st = mdl.reinforce_update(video, cap, None, r, b, lr=1e-3, active_steps=None if active is None else M.Video_Caption_Generator.active_steps(mask))
         else:
-            st = mdl.mixed_update(video, cap, mask, r, b, gcap, gmask, lr=1e-3, active_steps=active)
-        ctx_steps = mdl._ctx[-1]
+            st = mdl.mixed_update(video, cap if active else _dev(cap), mask if active else _dev(mask), r, b, gcap, gmask, lr=1e-3, active_steps=active)
+            assert (mdl._ctx[9] is not None) == (active is not None)      # host masks: live rows; device masks: the dense pass
+        ctx_steps = mdl._ctx[8]
         outs.append((float(st.loss), mdl.store.theta[:mdl.store.numel].clone(), ctx_steps))
     assert outs[0][2] == Tc and outs[1][2] == Tc - 3            # the second run really skipped the padding
     assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * max(1.0, abs(outs[0][0]))

@@ -102,7 +102,7 @@ print("child ok")
         assert np.array_equal(res["0"][k], res["1"][k]), k
 
 
-@pytest.mark.parametrize("mode", ["xe", "pg"])
+@pytest.mark.parametrize("mode", ["xe", "pg", "pg_live"])
 def test_padding_steps_are_skipped_exactly_at_the_timed_shapes(full, mode):
     """active_steps at the bench shapes (persistent recurrences, split-K slabs, LDS-DMA weight gradients): the unroll
     stops behind the longest caption -- 13 of 20 steps here -- and loss and gradients are those of the full unroll (the
@@ -110,6 +110,7 @@ def test_padding_steps_are_skipped_exactly_at_the_timed_shapes(full, mode):
     import torch
     mdl, video = full
     rng = np.random.default_rng(3)
+    live = mode == "pg_live"          # ... and, inside the unrolled steps, the vocabulary-sized kernels on the unmasked positions only
     rep = 1 if mode == "xe" else K
     N = rep * B
     longest = 13
@@ -127,8 +128,9 @@ def test_padding_steps_are_skipped_exactly_at_the_timed_shapes(full, mode):
         if mode == "xe":
             st = mdl.xe_update(video, cap, mask, lr=0.0, q1=True, active_steps=active)
         else:
-            st = mdl.reinforce_update(video, cap, mask, r, b, lr=0.0, active_steps=active)
-        outs.append((float(st.loss), mdl.store.grad[:mdl.store.numel].clone(), float(st.grad_sumsq), mdl._ctx[-1]))
+            st = mdl.reinforce_update(video, cap, mask, r, b, lr=0.0, active_steps=active, live_mask="auto" if (live and active) else None)
+            assert (mdl._ctx[9] is not None) == bool(live and active)
+        outs.append((float(st.loss), mdl.store.grad[:mdl.store.numel].clone(), float(st.grad_sumsq), mdl._ctx[8]))
     mdl.global_step = step0
     assert outs[0][3] == TC and outs[1][3] == longest
     assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * max(1.0, abs(outs[0][0]))

@@ -1,0 +1,109 @@
+"""Live rows (s2vt_teacher_forced_fwd_live / s2vt_bptt_bwd_live): a position behind a sample's first <eos> is masked
+(cider_evaluation.py:145-172), its coefficient in the REINFORCE objective is zero, so the vocabulary projection, the softmax and
+their two gradient products run on the unmasked (step, row) pairs only.  Logits of the live rows are bit-identical to the full
+pass, the loss equal, gradients equal to the noise of the order-free reductions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DIMS = dict(dim_image=128, n_words=260, word_dim=32, lstm_dim=64, n_video_lstm_step=5, n_caption_lstm_step=9)
+
+
+def _dev(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _case(oracle, B, rep, seed=3):
+    d = oracle.Dims(label_dim=0, **DIMS)
+    p = oracle.init_params(d, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    for k in ("lstm1_b", "lstm2_b", "encode_image_b", "embed_word_b"):
+        p[k] = rng.uniform(-.1, .1, p[k].shape).astype(np.float32)
+    N = B * rep
+    video = np.abs(rng.standard_normal((B, d.n_video_lstm_step, d.dim_image)) * 0.5).astype(np.float32)
+    cap = rng.integers(2, d.n_words, (N, d.n_caption_lstm_step)).astype(np.int32)
+    ln = rng.integers(0, d.n_caption_lstm_step - 1, N)
+    ln[0] = d.n_caption_lstm_step - 2
+    for n in range(N):
+        cap[n, ln[n]:] = 0
+    vid = np.tile(np.arange(B, dtype=np.int32) + 5, rep); sid = np.repeat(np.arange(rep, dtype=np.int32), B)
+    return d, p, video, cap, vid, sid, N
+
+
+@pytest.mark.parametrize("keep", [1.0, 0.9])
+def test_live_rows_match_the_full_pass(gpu, oracle, keep):
+    import torch
+    from s2vt_amd import hostglue
+    d, p, video, cap, vid, sid, N = _case(oracle, B=4, rep=3)
+    Tc = d.n_caption_lstm_step
+    mask = hostglue.masks_from_ids(cap)
+    steps = int(np.flatnonzero(mask.any(0))[-1]) + 1
+    tm = mask[:, :steps].T.reshape(-1)
+    live = np.flatnonzero(tm != 0).astype(np.int32)
+    assert 0 < live.size < 0.8 * tm.size
+    gd = gpu.make_dims(d.dim_image, d.n_words, d.word_dim, d.lstm_dim, d.n_video_lstm_step, Tc)
+    dp_ = {k: _dev(v) for k, v in p.items()}
+    params = gpu.make_params(dp_)
+    rng = np.random.default_rng(7)
+    coef = (mask * rng.standard_normal(N)[:, None]).T.astype(np.float32).reshape(-1)[:steps * N]
+    tgt = _dev(cap).t().contiguous().view(-1)[:steps * N]
+    dl = _dev(live)
+
+    def run(lv):
+        logits, ws = gpu.teacher_forced_fwd(gd, params, _dev(video), _dev(cap), N, keep, 99, _dev(vid), _dev(sid), steps=steps, live=lv)
+        raw = logits.clone()
+        ix = slice(None) if lv is None else lv.long()
+        nll, _ = gpu.softmax_nll_fwd_bwd(logits, tgt[ix].contiguous(), _dev(coef)[ix].contiguous(), 0.0)
+        g = {k: torch.zeros_like(v) for k, v in dp_.items()}
+        gpu.bptt_bwd(gd, params, gpu.make_params(g), _dev(video), N, logits, ws, keep, 99, _dev(vid), _dev(sid), steps=steps, live=lv)
+        return raw, nll, g
+    full, nll_f, g_f = run(None)
+    part, nll_p, g_p = run(dl)
+    assert part.shape[0] == live.size
+    assert torch.equal(part, full[dl.long()])                      # the same chains, row by row
+    assert torch.equal(nll_p, nll_f[dl.long()])
+    for k in g_f:
+        ref = g_f[k].cpu().numpy(); got = g_p[k].cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-5 * (np.abs(ref).max() + 1e-12) + 1e-9, k
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_reinforce_update_on_live_rows(gpu, oracle, fused):
+    """model.reinforce_update: host mask -> live rows ("auto"), and the fused form (ids on the device, the caller passes the host
+    mask it derived from the fetched ids, as train_rl does) against the dense pass: same loss, same variables after Adam."""
+    import torch
+    from s2vt_amd import hostglue, model as M
+    d, p, video, cap, vid, sid, N = _case(oracle, B=4, rep=3)
+    Tc = d.n_caption_lstm_step
+    mask = hostglue.masks_from_ids(cap)
+    rng = np.random.default_rng(5)
+    r = rng.random(N).astype(np.float32) * 2; b = np.tile(rng.random(4).astype(np.float32) * 2, 3)
+    outs = []
+    for live in (False, True):
+        mdl = M.Video_Caption_Generator(d.dim_image, d.n_words, d.word_dim, d.lstm_dim, 4, 0, d.n_video_lstm_step, Tc, dropout_rate=0.9, seed=5)
+        mdl.store.load(p)
+        kw = dict(lr=1e-3, active_steps=None if not live else "auto", live_mask=None if not live else (mask if fused else "auto"))
+        if fused and live:
+            kw["active_steps"] = mdl.active_steps(mask)
+        st = mdl.reinforce_update(video, cap, None if fused else mask, r, b, **kw)
+        outs.append((float(st.loss), mdl.store.theta[:mdl.store.numel].clone(), mdl._ctx[9]))
+    assert outs[0][2] is None and outs[1][2] is not None and outs[1][2].numel() == int((mask != 0).sum())
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * max(1.0, abs(outs[0][0]))
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-4
+
+
+def test_live_rows_helper_thresholds():
+    from s2vt_amd.model import Video_Caption_Generator as G
+    import torch
+    mdl = G.__new__(G)
+    mdl.device = torch.device("cuda")
+    m = np.ones((4, 6), np.float32)
+    assert mdl.live_rows(m, 6) is None                              # nothing masked: not worth a gather
+    m[:, 3:] = 0
+    assert mdl.live_rows(m, 6).tolist() == list(range(12))          # time-major: steps 0..2 of the four rows
+    assert mdl.live_rows(m, 3) is None                              # inside the truncated unroll everything is live
+    m[1, 1:] = 0
+    assert mdl.live_rows(m, 3).tolist() == [0, 1, 2, 3, 4, 6, 7, 8, 10, 11]
+    assert mdl.live_rows(torch.as_tensor(m).cuda(), 3) is None and mdl.live_rows(None, 3) is None
