@@ -218,7 +218,10 @@ int s2vt_teacher_forced_fwd_steps(const s2vt_dims* d, const s2vt_params* p, cons
  * sample's first <eos> is masked (cider_evaluation.py:145-172): its logits feed nothing, its loss term and every gradient
  * contribution are exact zeros -- on a trained model's samples (8 of 20 positions live) the four vocabulary-sized kernels of a
  * step (logits, softmax, dWout, dO2: a third of it) shrink with the live fraction.  The recurrences are unchanged.
- * live_rows == NULL (n_live == 0): every row, as s2vt_teacher_forced_fwd_steps.  Pair it with s2vt_bptt_bwd_live on the same list. */
+ * live_rows == NULL (n_live == 0): every row, as s2vt_teacher_forced_fwd_steps.  Pair it with s2vt_bptt_bwd_live on the same list.
+ * The list must be closed towards earlier steps (t * N + n live => (t - 1) * N + n live), as masks up to a first <eos> are: the
+ * backward also leaves the dead rows out of LSTM2's weight- and input-gradient products, whose dZ2 rows are zeros only BEHIND
+ * a row's last live step. */
 int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t N,
                                  const int32_t* caption, int32_t caption_steps, const int32_t* live_rows, int32_t n_live, float keep,
                                  uint64_t seed, const int32_t* video_id, const int32_t* sample_id, float* logits_out,
@@ -266,7 +269,8 @@ int s2vt_bptt_bwd_steps(const s2vt_dims* d, const s2vt_params* p, const s2vt_par
                         s2vt_stream stream);
 
 /* The backward of s2vt_teacher_forced_fwd_live: dlogits is [n_live, V] (row r = unrolled row live_rows[r]); the vocabulary
- * gradients are reduced over the live rows, the gradient w.r.t. LSTM2's outputs is computed for them and is zero elsewhere. */
+ * gradients are reduced over the live rows, the gradient w.r.t. LSTM2's outputs is computed for them and is zero elsewhere;
+ * LSTM2's weight gradients and d[out1 ; embed] likewise take the Tv encode steps plus the live decode rows. */
 int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_params* grads, const float* video, int32_t B,
                        int32_t N, const float* dlogits, int32_t caption_steps, const int32_t* live_rows, int32_t n_live, float keep,
                        uint64_t seed, const int32_t* video_id, const int32_t* sample_id, void* workspace, size_t workspace_bytes,

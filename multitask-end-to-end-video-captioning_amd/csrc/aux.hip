@@ -516,6 +516,34 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(float* dst, const float*
     reinterpret_cast<f32x4*>(dst)[i] = acc;
 }
 
+// dst[r, :] = src[idx[r], :] (rows of 16-byte multiples) and dst[r] = src[idx[r]]: the packed copies the live-row backward works on
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* src, int ld, const int32_t* idx, int R, int C4, float* dst, int ldd)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)idx[r] * ld);
+    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)r * ldd);
+    for (int c = threadIdx.x & 63; c < C4; c += 64) d4[c] = s4[c];
+}
+__global__ void gather_i32_kernel(const int32_t* src, const int32_t* idx, int R, int32_t* dst)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) dst[r] = src[idx[r]];
+}
+hipError_t launch_gather_rows(const float* src, int ld, const int32_t* idx, int R, int C, float* dst, int ldd, hipStream_t st)
+{
+    if (R <= 0) return hipSuccess;
+    if ((C & 3) || (ld & 3) || (ldd & 3) || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, st, src, ld, idx, R, C / 4, dst, ldd);
+    return hipGetLastError();
+}
+hipError_t launch_gather_i32(const int32_t* src, const int32_t* idx, int R, int32_t* dst, hipStream_t st)
+{
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, st, src, idx, R, dst);
+    return hipGetLastError();
+}
+
 // Several buffers that must read as zeros when a pass starts (initial states, hand-off counters, fragment images), in ONE
 // launch: each hipMemsetAsync is a ~5 us kernel of its own, and a REINFORCE step had 19 of them.
 __global__ void zero_regions_kernel(const ZeroList z)

@@ -70,6 +70,8 @@ struct ZeroList {
     void add(void* ptr, size_t bytes) { if (ptr && bytes) { p[count] = static_cast<uint32_t*>(ptr); n[count] = bytes / 4; ++count; } }
 };
 hipError_t launch_zero_regions(const ZeroList& z, hipStream_t st);
+hipError_t launch_gather_rows(const float* src, int ld, const int32_t* idx, int R, int C, float* dst, int ldd, hipStream_t st);   // dst[r,:] = src[idx[r],:]
+hipError_t launch_gather_i32(const int32_t* src, const int32_t* idx, int R, int32_t* dst, hipStream_t st);
 hipError_t launch_scatter_add_rows(const float* dE, int ld, const int32_t* idx, int R, int E, float* dW, int ldw,
                                    hipStream_t st);
 hipError_t launch_transpose(const float* in, int ldi, float* out, int ldo, int R, int Cc, hipStream_t st);

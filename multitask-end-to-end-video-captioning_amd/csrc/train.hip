@@ -37,6 +37,9 @@ struct TrainWs {
     float* dO2s;         // split-K slabs of dO2 = dlogits @ Wout^T when it has few rows (NULL otherwise)
     size_t dO2s_rows;    // ... rows x slabs it holds
     float* dO2p;         // dO2 of the LIVE rows only (the *_live entry points), scattered into dO2
+    float *dZ2p, *dX2p;  // the live decode rows of dZ2 (packed copy) and of dX2 (computed packed, scattered into dX2)
+    int32_t* prevp;      // previous word of the live decode rows
+    size_t dXs_floats;   // capacity of dXs
     float* dXs;          // split-K slabs of dX2 / dX1 when they are short of tiles (NULL otherwise)
 };
 
@@ -123,6 +126,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.O2 = c.take<float>(T * n * H);
     w.dO2 = c.take<float>(Tc * n * H);
     w.dO2p = c.take<float>(Tc * n * H);
+    w.dZ2p = c.take<float>(Tc * n * 4 * H); w.dX2p = c.take<float>(Tc * n * (H + E)); w.prevp = c.take<int32_t>(Tc * n);
     w.dZ1 = c.take<float>(T * b * 4 * H); w.dZ2 = c.take<float>(T * n * 4 * H);
     w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * b * E); w.dH1 = c.take<float>(T * b * H);
     w.slab = c.take<float>((size_t)kMaxSlabs * n * H); w.dc = c.take<float>(n * H);
@@ -156,6 +160,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
         const size_t need1 = s1 > 1 ? (size_t)s1 * Tv * b * E : 0;
         if (need1 > need) need = need1;
         w.dXs = need ? c.take<float>(need) : nullptr;
+        w.dXs_floats = need;
     }
     if (out) *out = w;
     return c.off;
@@ -257,9 +262,11 @@ hipError_t lstm_recurrence_bwd(const float* W, int kw0, const float* gates, cons
 }
 
 // C = A @ Wt^T with the reduction cut into slabs when the output is short of tiles (dx_splits), the slabs summed into C
-hipError_t nn_bwd_slabs(const float* A, int lda, const float* Wt, int ldw, float* C, int ldc, int M, int N, int K, float* slabs, hipStream_t st)
+hipError_t nn_bwd_slabs(const float* A, int lda, const float* Wt, int ldw, float* C, int ldc, int M, int N, int K, float* slabs, hipStream_t st,
+                        size_t slab_floats = ~(size_t)0)
 {
-    const int s = slabs ? dx_splits(M, N, K) : 1;
+    int s = slabs ? dx_splits(M, N, K) : 1;
+    if ((size_t)s * M * N > slab_floats) s = 1;                                  // (a row count the carve did not see)
     if (s <= 1 || ldc != N) return nn_bwd(A, lda, Wt, ldw, C, ldc, M, N, K, 1, 0, st);
     const size_t stride = (size_t)M * N;
     hipError_t e = nn_bwd(A, lda, Wt, ldw, slabs, N, M, N, K, s, stride, st, kSlabTileCfg);
@@ -586,7 +593,7 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
     }
     // dZ2 is complete: LSTM2's weight gradients go to the side stream, beside dX2 and LSTM1's recurrence
     if (sd != st) HIP_TRY(fork_to(st, sd, ss.ev[1]));
-    {
+    if (!live_rows) {
         TnArgs a{w.O1, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W, 4 * H, T * N, H, 4 * H, 1};
         HIP_TRY(launch_gemm_tn(a, sd));
         TnArgs b{p->Wemb, w.prev, E, w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, grads->lstm2_W + (size_t)H * 4 * H, 4 * H, Tc * N, E,
@@ -596,11 +603,44 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         TnArgs e{w.H2, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, T * N, H, 4 * H, 1};
         e.colsum = grads->lstm2_b;
         HIP_TRY(launch_gemm_tn(e, sd));
+    } else {
+        // Live rows: behind its first <eos> a row's dZ2 is an exact zero at every later step (zero upstream gradient, zero carried
+        // dh / dc), so the weight gradients are reduced over the Tv encode steps (every row) plus the LIVE decode rows -- their
+        // dZ2 rows as a packed copy, the matching activation rows gathered through the same list.
+        const int R = n_live;
+        HIP_TRY(launch_gather_rows(w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, live_rows, R, 4 * H, w.dZ2p, 4 * H, sd));
+        HIP_TRY(launch_gather_i32(w.prev, live_rows, R, w.prevp, sd));
+        TnArgs a0{w.O1, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W, 4 * H, Tv * N, H, 4 * H, 1};
+        HIP_TRY(launch_gemm_tn(a0, sd));
+        TnArgs a1{w.O1 + (size_t)Tv * NH, live_rows, H, w.dZ2p, 4 * H, grads->lstm2_W, 4 * H, R, H, 4 * H, 1};
+        a1.gather_rows = Tc * N;
+        HIP_TRY(launch_gemm_tn(a1, sd));
+        TnArgs b{p->Wemb, w.prevp, E, w.dZ2p, 4 * H, grads->lstm2_W + (size_t)H * 4 * H, 4 * H, R, E, 4 * H, 1};
+        b.gather_rows = V;                                  // Wemb [V, E]
+        HIP_TRY(launch_gemm_tn(b, sd));
+        TnArgs e0{w.H2, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, Tv * N, H, 4 * H, 1};
+        e0.colsum = grads->lstm2_b;
+        HIP_TRY(launch_gemm_tn(e0, sd));
+        TnArgs e1{w.H2 + (size_t)Tv * NH, live_rows, H, w.dZ2p, 4 * H, grads->lstm2_W + (size_t)(H + E) * 4 * H, 4 * H, R, H, 4 * H, 1};
+        e1.gather_rows = Tc * N;
+        e1.colsum = grads->lstm2_b;
+        HIP_TRY(launch_gemm_tn(e1, sd));
     }
     }
     if (!do_rest) return S2VT_OK;
-    // d[out1 ; embed] for every step at once
-    HIP_TRY(nn_bwd_slabs(w.dZ2, 4 * H, p->lstm2_W, 4 * H, w.dX2, H + E, T * N, H + E, 4 * H, w.dXs, st));
+    // d[out1 ; embed] for every step at once -- with live rows: the encode steps, then the live decode rows (from the packed dZ2
+    // of the LSTM2 phase), scattered into the zeroed decode part
+    if (!live_rows) {
+        HIP_TRY(nn_bwd_slabs(w.dZ2, 4 * H, p->lstm2_W, 4 * H, w.dX2, H + E, T * N, H + E, 4 * H, w.dXs, st, w.dXs_floats));
+    } else {
+        HIP_TRY(nn_bwd_slabs(w.dZ2, 4 * H, p->lstm2_W, 4 * H, w.dX2, H + E, Tv * N, H + E, 4 * H, w.dXs, st, w.dXs_floats));
+        HIP_TRY(nn_bwd_slabs(w.dZ2p, 4 * H, p->lstm2_W, 4 * H, w.dX2p, H + E, n_live, H + E, 4 * H, w.dXs, st, w.dXs_floats));
+        float* const dec = w.dX2 + (size_t)Tv * N * (H + E);
+        ZeroList z;
+        z.add(dec, (size_t)Tc * N * (H + E) * 4);
+        HIP_TRY(launch_zero_regions(z, st));
+        HIP_TRY(launch_scatter_add_rows(w.dX2p, H + E, live_rows, n_live, H + E, dec, H + E, st));     // (distinct rows: an exact copy)
+    }
     // ---- LSTM1 back through time, on the B per-video rows: the gradient w.r.t. its dropped output is
     // first reduced over the rep sample rows of each video (with their dropout masks)
     const size_t BH = (size_t)B * H;
@@ -609,7 +649,7 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         BwdScratch sc{w.slab, w.dc, w.bimg, w.bex, w.bsync};
         HIP_TRY(lstm_recurrence_bwd(p->lstm1_W, E, w.G1, w.C1, w.dH1, BH, H, 0, w.dZ1, B, H, T, 1.0f, seed, 0u, nullptr, nullptr, sc, -1, st));
     }
-    HIP_TRY(nn_bwd_slabs(w.dZ1, 4 * H, p->lstm1_W, 4 * H, w.dX1, E, Tv * B, E, 4 * H, w.dXs, st));
+    HIP_TRY(nn_bwd_slabs(w.dZ1, 4 * H, p->lstm1_W, 4 * H, w.dX1, E, Tv * B, E, 4 * H, w.dXs, st, w.dXs_floats));
 
     // ---- remaining weight gradients: one contraction over all unrolled steps per weight block
     {
@@ -620,7 +660,8 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         g.colsum = grads->lstm1_b;
         HIP_TRY(launch_gemm_tn(g, st));
         // embedding rows (gradient of tf.nn.embedding_lookup): scatter-add of the embed slice of dX2
-        HIP_TRY(launch_scatter_add_rows(w.dX2 + (size_t)Tv * N * (H + E) + H, H + E, w.prev, Tc * N, E, grads->Wemb, E, st));
+        if (live_rows) HIP_TRY(launch_scatter_add_rows(w.dX2p + H, H + E, w.prevp, n_live, E, grads->Wemb, E, st));
+        else HIP_TRY(launch_scatter_add_rows(w.dX2 + (size_t)Tv * N * (H + E) + H, H + E, w.prev, Tc * N, E, grads->Wemb, E, st));
         // frame embedding
         TnArgs h{video, w.encidx, D, w.dX1, E, grads->encode_image_W, E, Tv * B, D, E, 1};
         h.gather_rows = Tv * B;

@@ -368,8 +368,9 @@ class Video_Caption_Generator:
     def live_rows(self, mask, steps):
         """int32 device tensor of the unmasked (step, row) pairs of the first `steps` decode steps -- time-major index t * N + n,
         ascending -- or None when the mask is not host-resident or so few positions are masked that packing them out would not
-        pay (> 85 % live).  The vocabulary-sized kernels of an update (logits, softmax, dWout, dO2) run on these rows only;
-        the others' loss terms and gradient contributions are exact zeros (ops.teacher_forced_fwd(live=))."""
+        pay (> 85 % live), or a row has an unmasked position behind a masked one.  The vocabulary-sized kernels of an update
+        (logits, softmax, dWout, dO2) and LSTM2's weight- and input-gradient products run on these rows only; the others' loss
+        terms and gradient contributions are exact zeros (ops.teacher_forced_fwd(live=))."""
         if isinstance(mask, torch.Tensor):
             if mask.is_cuda:
                 return None
@@ -379,8 +380,11 @@ class Video_Caption_Generator:
         m = np.asarray(mask)
         if m.ndim != 2 or m.size == 0:
             return None
-        tm = np.ascontiguousarray(m[:, :steps].T).reshape(-1)
-        live = np.flatnonzero(tm != 0).astype(np.int32)
+        on = m[:, :steps] != 0
+        if (on[:, 1:] & ~on[:, :-1]).any():                     # an unmasked position behind a masked one: the recurrence-side
+            return None                                         # products need every row's live positions to be a PREFIX of its steps
+        tm = np.ascontiguousarray(on.T).reshape(-1)
+        live = np.flatnonzero(tm).astype(np.int32)
         if live.size == 0 or live.size > 0.85 * tm.size:
             return None
         return torch.as_tensor(live).to(self.device)

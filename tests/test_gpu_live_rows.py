@@ -107,3 +107,5 @@ def test_live_rows_helper_thresholds():
     m[1, 1:] = 0
     assert mdl.live_rows(m, 3).tolist() == [0, 1, 2, 3, 4, 6, 7, 8, 10, 11]
     assert mdl.live_rows(torch.as_tensor(m).cuda(), 3) is None and mdl.live_rows(None, 3) is None
+    m[1, 2] = 1                                                       # a hole: row 1 is masked at step 1 and live again at step 2
+    assert mdl.live_rows(m, 3) is None                               # not a prefix per row: the dense pass
