@@ -48,6 +48,12 @@ WORKLOADS = {
                metric="sampled caption tokens/sec (REINFORCE step)",
                desc="reinforcement_multisampling K=5 self-critical REINFORCE step (BASELINE configs[2]): B=64 per GPU, "
                     "T_vid=5, T_cap=20, d=1536, E=500, H=1000, |V|=12000; synthetic rewards"),
+    "rl_msvd": dict(B=64, K=5, seqfwd=lambda B, K: (4 * K + 1) * B, tokens=lambda B, K: K * B * TC,
+                    metric="sampled caption tokens/sec (REINFORCE step, samples of MSVD-like lengths)",
+                    desc="the rl workload with a stand-in for a TRAINED policy's samples: the sampler runs as in rl (its ids are discarded -- "
+                         "a random-initialised model never emits <eos>), the update teacher-forces synthetic captions of MSVD-like lengths "
+                         "(1 + min(Poisson(6), 18) words + <eos>, ~40 % of the positions unmasked) with their mask on the host, as train_rl has it: "
+                         "padding steps are not unrolled, the vocabulary-sized and LSTM2-gradient products run on the unmasked positions (exact)"),
     "xe": dict(B=64, K=0, seqfwd=lambda B, K: 3 * B, tokens=lambda B, K: B * TC,
                metric="caption tokens/sec (XE train step)",
                desc="tf_s2vt XE train step (BASELINE configs[1]): B=64, T_vid=5, T_cap=20, d=1536, E=500, H=1000, |V|=12000; "
@@ -236,6 +242,24 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
             return mdl.reinforce_update(video, s, None, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,      # mask None: PG mask from the ids, in the library
                                         reuse_sampler_state=True)    # LSTM1 trajectory of the sampler pass (same videos, same weights)
         return step
+    if workload == "rl_msvd":
+        rng = np.random.default_rng(4321 + rank)
+        N = K * B
+        ln = 1 + np.minimum(rng.poisson(6, N), TC - 2)
+        cap = rng.integers(2, V, (N, TC)).astype(np.int32)
+        for j in range(N):
+            cap[j, ln[j]:] = 0
+        mask = (np.arange(TC)[None, :] <= ln[:, None]).astype(np.float32)          # words + the first <eos>, host-resident
+        capd = torch.as_tensor(cap).to(dev)
+        if info is not None:
+            info["active_steps"] = mdl.active_steps(mask)
+            info["live_fraction"] = round(float(mask.mean()), 3)
+
+        def step(i):
+            mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
+            return mdl.reinforce_update(video, capd, mask, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,
+                                        reuse_sampler_state=True)
+        return step
     # ground-truth captions: length 1 + min(Poisson(6), Tc - 2) words (MSVD mean 7.03), tokens U{2..V-1}, then <eos> = 0
     rng = np.random.default_rng(1234 + rank)
     ln = 1 + np.minimum(rng.poisson(6, B), TC - 2)
@@ -395,6 +419,8 @@ def main():
                                      "the roofline object describes this library's dominant kernel only")
         if "active_steps" in info:
             out["config"]["unrolled_caption_steps"] = info["active_steps"]      # of TC: behind the longest caption all is padding
+        if "live_fraction" in info:
+            out["config"]["unmasked_positions"] = info["live_fraction"]
         if world == 1 and not args.no_cpu_baseline and args.workload == "rl":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
