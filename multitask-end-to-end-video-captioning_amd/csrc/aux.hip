@@ -525,6 +525,22 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* src, int 
     float4* d4 = reinterpret_cast<float4*>(dst + (size_t)r * ldd);
     for (int c = threadIdx.x & 63; c < C4; c += 64) d4[c] = s4[c];
 }
+// dst[idx[r], :] = src[r, :]: packed rows back to their places (distinct indices)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* src, int ld, const int32_t* idx, int R, int C4, float* dst, int ldd)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)r * ld);
+    float4* d4 = reinterpret_cast<float4*>(dst + (size_t)idx[r] * ldd);
+    for (int c = threadIdx.x & 63; c < C4; c += 64) d4[c] = s4[c];
+}
+hipError_t launch_scatter_rows(const float* src, int ld, const int32_t* idx, int R, int C, float* dst, int ldd, hipStream_t st)
+{
+    if (R <= 0) return hipSuccess;
+    if ((C & 3) || (ld & 3) || (ldd & 3) || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, st, src, ld, idx, R, C / 4, dst, ldd);
+    return hipGetLastError();
+}
 __global__ void gather_i32_kernel(const int32_t* src, const int32_t* idx, int R, int32_t* dst)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;

@@ -71,6 +71,7 @@ struct ZeroList {
 };
 hipError_t launch_zero_regions(const ZeroList& z, hipStream_t st);
 hipError_t launch_gather_rows(const float* src, int ld, const int32_t* idx, int R, int C, float* dst, int ldd, hipStream_t st);   // dst[r,:] = src[idx[r],:]
+hipError_t launch_scatter_rows(const float* src, int ld, const int32_t* idx, int R, int C, float* dst, int ldd, hipStream_t st);  // dst[idx[r],:] = src[r,:]
 hipError_t launch_gather_i32(const int32_t* src, const int32_t* idx, int R, int32_t* dst, hipStream_t st);
 hipError_t launch_scatter_add_rows(const float* dE, int ld, const int32_t* idx, int R, int E, float* dW, int ldw,
                                    hipStream_t st);

@@ -363,6 +363,7 @@ int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
     if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     if (caption_steps < 1 || caption_steps > d->n_caption_lstm_step) return S2VT_E_BADARG;
+    if (live_rows && (n_live > caption_steps * N || ((d->lstm_dim | d->word_dim) & 3))) return S2VT_E_BADARG;     // (packed rows move as 16-byte pieces)
     // Tc / T below are the steps this call UNROLLS; every buffer is time-major, so a truncated unroll is the leading part
     // of the full one's layout (the workspace is carved by the model's dimensions whatever caption_steps says)
     const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = caption_steps;
@@ -420,15 +421,28 @@ int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const
     {
         ASeg se = make_seg(w.O1, H, H, 0);                                       // encode: the word slot is the zero padding (:122)
         HIP_TRY(store_call(&se, 1, p->lstm2_W, 4 * H, nullptr, w.G2, 4 * H, Tv * N, 4 * H, 0, -1, st));
-        ASeg sd[2] = {make_seg(w.O1 + (size_t)Tv * NH, H, H, 0), make_seg(p->Wemb, E, E, H, 0, w.prev)};   // decode (:143)
-        HIP_TRY(store_call(sd, 2, p->lstm2_W, 4 * H, nullptr, w.G2 + (size_t)Tv * 4 * NH, 4 * H, Tc * N, 4 * H, 0, -1, st));
+        if (!live_rows) {
+            ASeg sd[2] = {make_seg(w.O1 + (size_t)Tv * NH, H, H, 0), make_seg(p->Wemb, E, E, H, 0, w.prev)};   // decode (:143)
+            HIP_TRY(store_call(sd, 2, p->lstm2_W, 4 * H, nullptr, w.G2 + (size_t)Tv * 4 * NH, 4 * H, Tc * N, 4 * H, 0, -1, st));
+        } else {
+            // live rows: the partials of the unmasked positions only (both operands gathered through the list), packed, then
+            // scattered into the zeroed decode part -- a masked position's cell then steps from a zero partial: finite values
+            // that feed nothing (its logits are not computed, its gradients are zeros)
+            HIP_TRY(launch_gather_i32(w.prev, live_rows, n_live, w.prevp, st));
+            ASeg sd[2] = {make_seg(w.O1 + (size_t)Tv * NH, H, H, 0, 0, live_rows), make_seg(p->Wemb, E, E, H, 0, w.prevp)};
+            HIP_TRY(store_call(sd, 2, p->lstm2_W, 4 * H, nullptr, w.dZ2p, 4 * H, n_live, 4 * H, 0, -1, st));   // (dZ2p: free until the backward)
+            float* const dec = w.G2 + (size_t)Tv * 4 * NH;
+            ZeroList z;
+            z.add(dec, (size_t)Tc * N * 4 * H * 4);
+            HIP_TRY(launch_zero_regions(z, st));
+            HIP_TRY(launch_scatter_rows(w.dZ2p, 4 * H, live_rows, n_live, 4 * H, dec, 4 * H, st));
+        }
     }
     // the recurrence continues each chain from its partial in G2[t] and overwrites it with the activated gates
     HIP_TRY(lstm_recurrence(p->lstm2_W, H + E, p->lstm2_b, w.G2, (size_t)4 * NH, 4 * H, T, w.C2, w.H2, NH, w.G2, (size_t)4 * NH,
                             w.O2, NH, N, H, T, keep, ids, 512u, w.chain_abuf, w.chain_sync, st));
     // vocab logits for all Tc steps at once (tf_s2vt.py:153): rows t*N + n -- or only the LIVE ones (row r of the output is
     // row live_rows[r] of the unroll: a masked position's logits feed nothing, its loss term and gradient are exact zeros)
-    if (live_rows && n_live > Tc * N) return S2VT_E_BADARG;
     ASeg so = make_seg(w.O2 + (size_t)Tv * NH, H, H, 0, 0, live_rows);
     HIP_TRY(store_call(&so, 1, p->embed_word_W, V, p->embed_word_b, logits, V, live_rows ? n_live : Tc * N, V, 0, -1, st));
     return S2VT_OK;
@@ -535,6 +549,7 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
     if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     if (caption_steps < 1 || caption_steps > d->n_caption_lstm_step) return S2VT_E_BADARG;
+    if (live_rows && (n_live > caption_steps * N || ((d->lstm_dim | d->word_dim) & 3))) return S2VT_E_BADARG;
     // the steps the forward call unrolled (s2vt_teacher_forced_fwd_steps): later steps carry no gradient, so the
     // recurrences start from zero at step T - 1 and every contraction covers the leading T (Tc) steps only
     const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, D = d->dim_image, Tv = d->n_video_lstm_step,
@@ -562,7 +577,6 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         // [n_live, V], row r belonging to row live_rows[r] of the unroll; the masked rows' dlogits are exact zeros in the full
         // form, so leaving them out of the reductions changes nothing and their dO2 rows are the zeros written below)
         const int R = live_rows ? n_live : Tc * N;
-        if (live_rows && n_live > Tc * N) return S2VT_E_BADARG;
         TnArgs a{w.O2 + (size_t)Tv * NH, live_rows, H, dlogits, V, grads->embed_word_W, V, R, H, V, 1};
         a.gather_rows = live_rows ? Tc * N : 0;
         a.colsum = grads->embed_word_b;                     // the bias gradient rides in the same pass over dlogits
@@ -582,7 +596,7 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
             ZeroList z;
             z.add(w.dO2, (size_t)Tc * N * H * 4);
             HIP_TRY(launch_zero_regions(z, st));
-            HIP_TRY(launch_scatter_add_rows(w.dO2p, H, live_rows, R, H, w.dO2, H, st));      // (distinct rows: an exact copy)
+            HIP_TRY(launch_scatter_rows(w.dO2p, H, live_rows, R, H, w.dO2, H, st));
         }
     }
     if (do_l2) {
@@ -639,7 +653,7 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         ZeroList z;
         z.add(dec, (size_t)Tc * N * (H + E) * 4);
         HIP_TRY(launch_zero_regions(z, st));
-        HIP_TRY(launch_scatter_add_rows(w.dX2p, H + E, live_rows, n_live, H + E, dec, H + E, st));     // (distinct rows: an exact copy)
+        HIP_TRY(launch_scatter_rows(w.dX2p, H + E, live_rows, n_live, H + E, dec, H + E, st));
     }
     // ---- LSTM1 back through time, on the B per-video rows: the gradient w.r.t. its dropped output is
     // first reduced over the rep sample rows of each video (with their dropout masks)

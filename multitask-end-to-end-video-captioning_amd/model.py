@@ -375,7 +375,7 @@ class Video_Caption_Generator:
             if mask.is_cuda:
                 return None
             mask = mask.numpy()
-        if mask is None:
+        if mask is None or ((self.dims.lstm_dim | self.dims.word_dim) & 3):      # (packed rows move as 16-byte pieces)
             return None
         m = np.asarray(mask)
         if m.ndim != 2 or m.size == 0:

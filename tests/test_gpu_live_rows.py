@@ -97,8 +97,10 @@ def test_reinforce_update_on_live_rows(gpu, oracle, fused):
 def test_live_rows_helper_thresholds():
     from s2vt_amd.model import Video_Caption_Generator as G
     import torch
+    from s2vt_amd import ops
     mdl = G.__new__(G)
     mdl.device = torch.device("cuda")
+    mdl.dims = ops.make_dims(128, 260, 32, 64, 5, 6)
     m = np.ones((4, 6), np.float32)
     assert mdl.live_rows(m, 6) is None                              # nothing masked: not worth a gather
     m[:, 3:] = 0
