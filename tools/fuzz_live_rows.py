@@ -1,0 +1,33 @@
+"""Dev helper: reinforce_update with the padding steps and masked positions left out (active_steps / live rows) against the dense
+pass on random shapes: same loss, same gradients."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import s2vt_amd
+from s2vt_amd import model as M, hostglue
+rng = np.random.default_rng(0)
+bad = 0
+for trial in range(24):
+    B = int(rng.choice([1, 3, 4, 7, 16, 33])); rep = int(rng.choice([1, 2, 5])); Tc = int(rng.choice([4, 9, 20])); Tv = int(rng.choice([2, 5]))
+    H = int(rng.choice([20, 64, 100])); E = int(rng.choice([12, 32, 52])); V = int(rng.choice([50, 97, 260, 1000])); D = int(rng.choice([24, 128]))
+    N = B * rep
+    cap = rng.integers(1, V, (N, Tc)).astype(np.int32)
+    ln = rng.integers(0, Tc, N)
+    for n in range(N):
+        cap[n, ln[n]:] = 0
+    mask = hostglue.masks_from_ids(cap)
+    video = np.abs(rng.standard_normal((B, Tv, D))).astype(np.float32)
+    r = rng.random(N).astype(np.float32) * 2; b = np.tile(rng.random(B).astype(np.float32), rep)
+    outs = []
+    for live in (None, "auto"):
+        mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, Tv, Tc, dropout_rate=0.9, seed=trial)
+        st = mdl.reinforce_update(video, cap, mask, r, b, lr=0.0, active_steps=None if live is None else "auto", live_mask=live)
+        outs.append((float(st.loss), mdl.store.grad[:mdl.store.numel].clone(), mdl._ctx[8], None if mdl._ctx[9] is None else mdl._ctx[9].numel()))
+    g0, g1 = outs[0][1], outs[1][1]
+    scale = float(g0.abs().max()) + 1e-20
+    err = float((g0 - g1).abs().max()) / scale
+    dl = abs(outs[0][0] - outs[1][0]) / max(1.0, abs(outs[0][0]))
+    ok = err < 5e-5 and dl < 2e-6 and torch.isfinite(g1).all()
+    bad += not ok
+    print(trial, (B, rep, Tc, Tv, H, E, V), "steps", outs[1][2], "live", outs[1][3], "of", Tc * N, "grad err", f"{err:.1e}", "loss err", f"{dl:.1e}", "OK" if ok else "FAIL")
+print("failures", bad)
