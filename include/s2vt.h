@@ -333,6 +333,54 @@ int s2vt_attention_bwd(const float* hWa, const float* P, const float* Vt, const 
                        const float* dctx, float* de_scratch, float* dhWa, float* dP, float* dVt, float* dw, int32_t Tv,
                        int32_t B, int32_t H, s2vt_stream stream);
 
+/* ---- the temporal-attention captioner as a whole model (original_attention.py:53-251) -----------
+ * Variables of original_attention.py:55-86 in the reference's own layouts (names = the TF variable names; LSTM3 lives under
+ * s2vt/LSTM3/basic_lstm_cell).  The word embedding has dim_hidden columns (:65); s2vt_dims.word_dim is ignored here.
+ * Numeric contract: every pre-activation is one ascending-k fmaf chain over the rows of its matrix, the
+ * row blocks in order of availability -- LSTM3: current_embed [H:2H], h [2H:3H], atten [0:H]; output layer: current_embed
+ * [2H:3H], atten [H:2H], output1 [0:H]; forward activations, alphas, logits and greedy ids are bit-identical to
+ * oracle/s2vt_oracle.py::attention_forward.  n_video_lstm_step <= 64. */
+typedef struct s2vt_attn_params {
+    float* Wemb;            /* [V, H] */
+    float* encode_image_W;  /* [D, H] */
+    float* encode_image_b;  /* [H] */
+    float* embed_att_w;     /* [H] (TF shape [H, 1]) */
+    float* embed_att_Wa;    /* [H, H] */
+    float* embed_att_Ua;    /* [H, H] */
+    float* embed_att_ba;    /* [H] */
+    float* embed_word_W;    /* [H, V] */
+    float* embed_word_b;    /* [V] */
+    float* embed_nn_Wp;     /* [3H, H]  rows [output1 ; atten ; current_embed]  (:134) */
+    float* embed_nn_bp;     /* [H] */
+    float* lstm3_W;         /* [3H, 4H] rows [atten ; current_embed ; h], columns [i | j | f | o]  (:131) */
+    float* lstm3_b;         /* [4H] */
+} s2vt_attn_params;
+
+size_t s2vt_attn_workspace_bytes(const s2vt_dims* d, int32_t B);
+/* build_model's unroll (:88-143) on B rows with the DropoutWrapper on LSTM3's output (keep, Philox stream as the S2VT cells:
+ * code 768 + step): logits [caption_steps*B, V] time-major (row t*B + b); caption [B, Tc] int32 (the word fed at step t is
+ * caption[:, t-1], zeros at t = 0, :105,141-142).  caption_steps (1..Tc): unroll only the leading steps (every later position of
+ * the batch is masked).  alphas_out: optional [caption_steps][Tv][B].  Activations stay in the workspace for s2vt_attn_bptt_bwd. */
+int s2vt_attn_teacher_forced_fwd(const s2vt_dims* d, const s2vt_attn_params* p, const float* video, int32_t B, const int32_t* caption,
+                                 int32_t caption_steps, float keep, uint64_t seed, const int32_t* video_id, const int32_t* sample_id,
+                                 float* logits, float* alphas_out, void* workspace, size_t workspace_bytes, s2vt_stream stream);
+/* loss = (sum_r coef[r] * nll[r] + sum_r reg_coef[r] * max(0, reg_m - sum(alpha[0:8])[r])) / *mask_sum_local  (:144-149; reg_coef =
+ * beta * mask time-major or NULL, reg_m = m; the first-8-frames sums are the ones the forward left in the workspace);
+ * *gscale = 1 / *mask_sum_global; *sumsq = 0.  One launch, after s2vt_attn_teacher_forced_fwd on the same workspace. */
+int s2vt_attn_step_scalars(const float* coef, const float* nll, int64_t R, const float* reg_coef, float reg_m, const float* mask_sum_local,
+                           const float* mask_sum_global, float* loss, float* gscale, float* sumsq, const s2vt_dims* d, int32_t B,
+                           void* workspace, size_t workspace_bytes, s2vt_stream stream);
+/* tf.gradients of (sum coef * nll + sum regulariser) through the unroll the forward call left in the workspace: dlogits
+ * [caption_steps*B, V] = d/dlogits (s2vt_softmax_nll_fwd_bwd), reg_coef [caption_steps*B] = beta * mask[b, t] time-major or NULL.
+ * ACCUMULATES into `grads` (same layout as the variables; un-normalised: scale by 1 / sum(mask) afterwards).  lstm_dim % 4 == 0. */
+int s2vt_attn_bptt_bwd(const s2vt_dims* d, const s2vt_attn_params* p, const s2vt_attn_params* grads, const float* video, int32_t B,
+                       const float* dlogits, int32_t caption_steps, const float* reg_coef, float reg_m, float keep, uint64_t seed,
+                       const int32_t* video_id, const int32_t* sample_id, void* workspace, size_t workspace_bytes, s2vt_stream stream);
+/* build_generator / build_sampler (:155-251): greedy decode of B videos, the whole loop on the device (the picked word of step
+ * t-1 is the gather index of step t's embedding operand); ids_out [B, Tc] int32, alphas_out optional [Tc][Tv][B] (saved_alphas). */
+int s2vt_attn_decode_greedy(const s2vt_dims* d, const s2vt_attn_params* p, const float* video, int32_t B, int32_t video_base, int32_t* ids_out,
+                            float* alphas_out, void* workspace, size_t workspace_bytes, s2vt_stream stream);
+
 /* ---- multitask attribute head (reinforce_multitask_e2e_attribute_loss.py:375-380, 606-626) -----
  * mean_feat[b,:] = mean_t video[b,t,:]; z = mean_feat @ attr_W + attr_b;
  * bce = max(z,0) - z*y + log(1+exp(-|z|))  (tf.nn.sigmoid_cross_entropy_with_logits); labels/bce optional.

@@ -32,6 +32,15 @@ class Params(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in PARAM_FIELDS]
 
 
+ATTN_PARAM_FIELDS = ("Wemb", "encode_image_W", "encode_image_b", "embed_att_w", "embed_att_Wa", "embed_att_Ua", "embed_att_ba",
+                     "embed_word_W", "embed_word_b", "embed_nn_Wp", "embed_nn_bp", "lstm3_W", "lstm3_b")
+
+
+class AttnParams(C.Structure):
+    """s2vt_attn_params: the variables of original_attention.py:55-86 as device pointers."""
+    _fields_ = [(n, C.c_void_p) for n in ATTN_PARAM_FIELDS]
+
+
 class ProfRow(C.Structure):
     _fields_ = [("kernel_class", C.c_int32), ("tile_cfg", C.c_int32), ("launches", C.c_int64), ("total_ms", C.c_double),
                 ("total_flops", C.c_double), ("name", C.c_char * 32)]
@@ -48,6 +57,7 @@ def lib_path() -> str:
 
 _vp, _i32, _i64, _u32, _u64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_size_t
 _DP, _PP, _OP = C.POINTER(Dims), C.POINTER(Params), C.POINTER(Operand)
+_AP = C.POINTER(AttnParams)
 
 # name -> (restype, argtypes); every symbol include/s2vt.h declares
 SIGNATURES = {
@@ -89,6 +99,11 @@ SIGNATURES = {
     "s2vt_adam_tf": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _i64, _f32, _f32, _f32, _vp]),
     "s2vt_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "s2vt_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "s2vt_attn_workspace_bytes": (_sz, [_DP, _i32]),
+    "s2vt_attn_teacher_forced_fwd": (C.c_int, [_DP, _AP, _vp, _i32, _vp, _i32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "s2vt_attn_step_scalars": (C.c_int, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _DP, _i32, _vp, _sz, _vp]),
+    "s2vt_attn_bptt_bwd": (C.c_int, [_DP, _AP, _AP, _vp, _i32, _vp, _i32, _vp, _f32, _f32, _u64, _vp, _vp, _vp, _sz, _vp]),
+    "s2vt_attn_decode_greedy": (C.c_int, [_DP, _AP, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "s2vt_attr_head_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_attr_head_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "s2vt_create": (C.c_int, [_DP, _i32, _i32, C.POINTER(_vp)]),

@@ -1,185 +1,232 @@
-"""Temporal-attention captioner: the host-side mirror of original_attention.py's
-``Video_Caption_Generator`` (ctor :55-86, build_model :88-147, build_generator :176-251).
+"""Temporal-attention captioner: the host-side mirror of original_attention.py's ``Video_Caption_Generator``
+(ctor :55-86, build_model :88-150, build_generator :155-199, build_sampler :201-251, the train_op of train() :430-441).
 
-BASELINE.json names "attention_tf_s2vt score path"; attention_tf_s2vt.py itself holds no attention
-op (SURVEY note N1) -- the arithmetic restated here is original_attention.py:95-134.  The forward
-graph is composed from the C-ABI calls (s2vt_gemm for the projections, s2vt_attention_fwd for the
-score/softmax/context, s2vt_lstm_cell_fwd for LSTM3); every activation is bit-identical to
-oracle/s2vt_oracle.py::attention_forward.  ``xe_update`` is the training step of the variant
-(build_model's loss :136-147 + the train_op of its train(): Adam on the gradients): the backward graph is
-composed on the host from the library's order-free pieces (s2vt_attention_bwd, s2vt_lstm_cell_bwd, s2vt_gemm /
-s2vt_gemm_tn, s2vt_softmax_nll_fwd_bwd, ...), checked against float64 autograd of the torch restatement.
+BASELINE.json names "attention_tf_s2vt score path"; attention_tf_s2vt.py itself holds no attention op (SURVEY note N1) --
+the arithmetic restated here is original_attention.py:95-147.  The class keeps the reference constructor and the
+``build_*`` surface: the methods return the same tuples of placeholders / fetches, ``model.Session(m).run(fetches, feed)``
+evaluates them, and ``exponential_decay`` / ``minimize`` stand for the nodes the reference's train() adds (:430-441), so
+that loop translates statement by statement (tests/test_gpu_attention_model.py replays it).  All arithmetic is in
+libs2vt_hip.so (csrc/attn_model.hip: the whole unroll, its backward and the greedy decode loop are library calls; csrc/attn.hip:
+score -> softmax -> context in one launch per step); torch supplies device memory and streams.  No CPU fallback.
 """
 from __future__ import annotations
+
+import math
 
 import numpy as np
 import torch
 
+from . import dist as dp
 from . import ops
+from ._lib import ATTN_PARAM_FIELDS
+from .model import Output, ParamStore, Placeholder, Session, StepStats  # noqa: F401  (Session: re-exported for callers)
 
-NAMES = ("Wemb", "encode_image_W", "encode_image_b", "embed_att_w", "embed_att_Wa", "embed_att_Ua", "embed_att_ba",
-         "embed_word_W", "embed_word_b", "embed_nn_Wp", "embed_nn_bp", "lstm3_W", "lstm3_b")
+NAMES = ATTN_PARAM_FIELDS
+# TF-1.1 variable names (original_attention.py:64-86; the cell is created under scope "s2vt" / "LSTM3", :109,129)
 TF_NAMES = {n: n for n in NAMES}
 TF_NAMES.update({"lstm3_W": "s2vt/LSTM3/basic_lstm_cell/weights", "lstm3_b": "s2vt/LSTM3/basic_lstm_cell/biases"})
 
 
+def param_shapes(dim_image, n_words, dim_hidden):
+    H, V, D = dim_hidden, n_words, dim_image
+    return {"Wemb": (V, H), "encode_image_W": (D, H), "encode_image_b": (H,), "embed_att_w": (H, 1), "embed_att_Wa": (H, H),
+            "embed_att_Ua": (H, H), "embed_att_ba": (H,), "embed_word_W": (H, V), "embed_word_b": (V,), "embed_nn_Wp": (3 * H, H),
+            "embed_nn_bp": (H,), "lstm3_W": (3 * H, 4 * H), "lstm3_b": (4 * H,)}
+
+
 class Attention_Caption_Generator:
+    """original_attention.py's Video_Caption_Generator.  Same constructor (:55); `m` / `beta` are the script's module-level
+    regulariser constants (:299-300), `device` / `seed` additions."""
+
     def __init__(self, dim_image, n_words, dim_hidden, batch_size, n_video_lstm_steps, n_caption_lstm_steps, drop_out_rate,
-                 bias_init_vector=None, device="cuda", seed=1234):
+                 bias_init_vector=None, m=0.5, beta=10.0, device="cuda", seed=1234):
         self.dim_image, self.n_words, self.dim_hidden, self.batch_size = dim_image, n_words, dim_hidden, batch_size
         self.n_video_lstm_steps, self.n_caption_lstm_steps, self.drop_out_rate = n_video_lstm_steps, n_caption_lstm_steps, drop_out_rate
+        self.m, self.beta = float(m), float(beta)
         self.device = torch.device(device)
-        H, V, D = dim_hidden, n_words, dim_image
-        g = torch.Generator().manual_seed(seed)
-        u = lambda *s: ((torch.rand(*s, generator=g) * 2 - 1) * 0.1).to(self.device)
-        a = float(np.sqrt(6.0 / (3 * H + 4 * H)))
-        self.p = {
-            "Wemb": u(V, H), "encode_image_W": u(D, H), "encode_image_b": torch.zeros(H, device=self.device),
-            "embed_att_w": u(H, 1), "embed_att_Wa": u(H, H), "embed_att_Ua": u(H, H),
-            "embed_att_ba": torch.zeros(H, device=self.device), "embed_word_W": u(H, V),
-            "embed_word_b": torch.zeros(V, device=self.device), "embed_nn_Wp": u(3 * H, H),
-            "embed_nn_bp": torch.zeros(H, device=self.device),
-            "lstm3_W": ((torch.rand(3 * H, 4 * H, generator=g) * 2 - 1) * a).to(self.device),
-            "lstm3_b": torch.zeros(4 * H, device=self.device),
-        }
+        H = dim_hidden
+        self.dims = ops.make_dims(dim_image, n_words, H, H, n_video_lstm_steps, n_caption_lstm_steps)
+        self.store = ParamStore(param_shapes(dim_image, n_words, H), self.device, order=NAMES, tf_names=TF_NAMES,
+                                params_factory=ops.make_attn_params)
+        self.p, self.g = self.store.p, self.store.g
+        # the reference initialisers (:65-86): U(-0.1, 0.1), zero biases; TF-default Glorot-uniform for the BasicLSTMCell kernel
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        for n in NAMES:
+            shp = self.store.shapes[n]
+            if n.endswith("_b") or n in ("embed_att_ba", "embed_nn_bp"):
+                self.p[n].zero_()
+                continue
+            a = 0.1 if n != "lstm3_W" else math.sqrt(6.0 / (shp[0] + shp[1]))
+            self.p[n].copy_(((torch.rand(shp, generator=gen) * 2 - 1) * a).to(self.device))
         if bias_init_vector is not None:
-            self.p["embed_word_b"].copy_(torch.as_tensor(np.asarray(bias_init_vector, np.float32)))
+            self.p["embed_word_b"].copy_(torch.as_tensor(np.asarray(bias_init_vector, np.float32)).to(self.device))
+        self.global_step = 0
+        self.adam_t = 0
+        self.dropout_seed = seed + 1
+        self._gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+        self._row_ids_cache = {}
+
+    # ------------------------------------------------------------------------------------------ utilities
+    def _dev(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
+
+    def _row_ids(self, B, video_base=0):
+        key = (B, int(video_base))
+        hit = self._row_ids_cache.get(key)
+        if hit is None:
+            hit = self._row_ids_cache[key] = ((torch.arange(B, dtype=torch.int32, device=self.device) + video_base).contiguous(),
+                                              torch.zeros(B, dtype=torch.int32, device=self.device))
+        return hit
 
     def load(self, arrays):
+        """Variables by our names or by their TF checkpoint names."""
+        inv = {v: k for k, v in TF_NAMES.items()}
         for k, v in arrays.items():
+            k = inv.get(k, k)
             if k in self.p:
-                self.p[k].copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.device))
+                self.p[k].copy_(torch.as_tensor(np.asarray(v, np.float32)).reshape(self.p[k].shape).to(self.device))
 
-    def forward(self, video, caption=None, greedy=False, keep=1.0, seed=0):
-        """Teacher-forced logits [B,Tc,V] + alphas [Tc,Tv,B] (build_model, :95-147), or the greedy ids
-        (build_generator) when greedy=True.  LSTM3 output dropout as DropoutWrapper (:78) when keep<1."""
-        p = self.p
-        video = torch.as_tensor(video).to(self.device, torch.float32).contiguous()
-        B, Tv, D = video.shape
-        H, V, Tc = self.dim_hidden, self.n_words, self.n_caption_lstm_steps
-        op = ops.operand
-        emb = ops.gemm([op(video.view(B * Tv, D))], p["encode_image_W"], p["encode_image_b"], M=B * Tv)      # (b,t) rows
-        Vt = emb.view(B, Tv, H).transpose(0, 1).contiguous()                                                  # [Tv,B,H] (:98)
-        P = ops.gemm([op(Vt.view(Tv * B, H))], p["embed_att_Ua"], p["embed_att_ba"], M=Tv * B).view(Tv, B, H)  # (:107)
-        c = torch.zeros(B, H, device=self.device); h_prev = torch.zeros(B, H, device=self.device)
-        q_prev = torch.zeros(B, H, device=self.device)          # attention query: the previous DropoutWrapper output (:135)
-        cur = torch.zeros(B, H, device=self.device)                                                           # (:105)
-        w = p["embed_att_w"].view(-1).contiguous()
-        vid = torch.arange(B, dtype=torch.int32, device=self.device); sid = torch.zeros(B, dtype=torch.int32, device=self.device)
-        gsid = -torch.ones(B, dtype=torch.int32, device=self.device)
-        logits = torch.empty(B, Tc, V, device=self.device); alphas = torch.empty(Tc, Tv, B, device=self.device)
-        ids = torch.empty(B, Tc, dtype=torch.int32, device=self.device)
-        if caption is not None:
-            caption = torch.as_tensor(caption).to(self.device, torch.int32)
-        for t in range(Tc):
-            hWa = ops.gemm([op(q_prev)], p["embed_att_Wa"], None, M=B)
-            _, alpha, ctx = ops.attention_fwd(hWa, P, Vt, w)                                                  # (:113-128)
-            c, h, out, _ = ops.lstm_cell_fwd(op(ctx), op(cur), h_prev, c, p["lstm3_W"], p["lstm3_b"], B, keep=keep, seed=seed,
-                                             video_id=vid, sample_id=sid, drop_code=768 + t)                  # (:131-132)
-            y = ops.gemm([op(out), op(ctx), op(cur)], p["embed_nn_Wp"], p["embed_nn_bp"], M=B, act_tanh=True)  # (:134)
-            h_prev = h
-            q_prev = out
-            tok, lg, _ = ops.vocab_pick(y, p["embed_word_W"], p["embed_word_b"], vid, gsid, t, 0, want_logits=True)  # (:143)
-            logits[:, t] = lg
-            alphas[t] = alpha
-            ids[:, t] = tok
-            nxt = tok if greedy else caption[:, t]
-            cur = p["Wemb"][nxt.long()].contiguous()                                                          # (:141-142)
-        return logits, alphas, (ids if greedy else None)
+    def state_dict(self, with_optimizer=True):
+        return self.store.state_dict(self.global_step if with_optimizer else None, self.adam_t, step_name="Variable")
 
-    # ------------------------------------------------------------------------------------------ training
-    def xe_update(self, video, caption, caption_mask, lr, clip_norm=0.0, keep=None, seed=0, beta1=0.9, beta2=0.999, eps=1e-8):
-        """One training step of the attention captioner: loss = sum_{b,t} ce[b,t]*mask[b,t] / sum(mask)
-        (original_attention.py:136-147; the alpha regulariser beta*max(0, m - sum(alpha[:, :8])) with m = 0.5 is
-        identically zero while n_video_lstm_steps <= 8 -- asserted), gradients by BPTT through the unroll,
-        optional global-norm clip, TF-form Adam.  Returns (loss, grads dict)."""
-        p = self.p
-        assert self.n_video_lstm_steps <= 8, "the alpha regulariser (original_attention.py:123,146) is only zero for <= 8 frames"
+    def load_state_dict(self, sd):
+        loaded = self.store.load_state_dict(sd)
+        if self.store.restored_step is not None:
+            self.global_step = self.store.restored_step
+            self.adam_t = self.store.restored_adam_t if self.store.restored_adam_t is not None else self.global_step
+        return loaded
+
+    # ------------------------------------------------------------------------------------------ forward graphs
+    def forward(self, video, caption=None, greedy=False, keep=1.0, seed=0, video_base=0):
+        """Teacher-forced logits [B,Tc,V] + alphas [Tc,Tv,B] (build_model, :95-147), or the greedy ids + alphas
+        (build_sampler) when greedy=True.  LSTM3 output dropout as DropoutWrapper (:78) when keep < 1."""
+        video = self._dev(video, torch.float32)
+        B = video.shape[0]
+        if greedy:
+            ids, al = ops.attn_decode_greedy(self.dims, self.store.params, video, video_base, want_alphas=True)
+            return None, al, ids
+        cap = self._dev(caption, torch.int32)
+        vid, sid = self._row_ids(B, video_base)
+        logits, al, _ = ops.attn_teacher_forced_fwd(self.dims, self.store.params, video, cap, keep, seed, vid, sid, want_alphas=True)
+        return logits.view(self.n_caption_lstm_steps, B, -1).transpose(0, 1), al, None
+
+    @staticmethod
+    def _active_steps(mask, Tc):
+        """Leading decode steps at which any row is unmasked, read off a HOST mask (None for a device tensor: no sync)."""
+        if isinstance(mask, torch.Tensor):
+            if mask.is_cuda:
+                return None
+            mask = mask.numpy()
+        m = np.asarray(mask)
+        live = np.flatnonzero((m != 0).any(axis=0))
+        return max(1, min(Tc, int(live[-1]) + 1)) if live.size else 1
+
+    def _loss_forward(self, video, caption, caption_mask, keep, steps, video_base=0):
+        """The unroll + softmax-NLL forward/backward; leaves d/dlogits and the activations ready for the backward."""
+        video = self._dev(video, torch.float32)
+        cap = self._dev(caption, torch.int32)
+        mask = self._dev(caption_mask, torch.float32)
+        B, Tc = cap.shape
+        steps = Tc if steps is None else steps
+        R = steps * B
+        vid, sid = self._row_ids(B, video_base)
+        seed = self.dropout_seed + 104729 * self.global_step
+        logits, _, ws = ops.attn_teacher_forced_fwd(self.dims, self.store.params, video, cap, keep, seed, vid, sid, steps=steps)
+        coef = mask.t().contiguous().view(-1)[:R]                      # time-major: cross_entropy * caption_mask[:, i] (:145)
+        target = cap.t().contiguous().view(-1)[:R]
+        nll, _ = ops.softmax_nll_fwd_bwd(logits, target, coef, 0.0)    # logits <- coef * (softmax - onehot)
+        # regularizer = beta * max(0, m - sum(alphas[:, 0:8])) * caption_mask[:, i] (:123,144): zero while Tv <= 8 (the softmax sums to 1 > m)
+        reg = (coef * self.beta) if (self.n_video_lstm_steps > 8 and self.beta != 0.0) else None
+        msum = mask.sum().reshape(1)
+        return dict(video=video, B=B, steps=steps, dlogits=logits, ws=ws, coef=coef, nll=nll, reg=reg, msum=msum, keep=keep, seed=seed,
+                    vid=vid, sid=sid)
+
+    def loss(self, video, caption, caption_mask, keep=None):
+        """build_model's loss tensor (:149) evaluated (forward only)."""
         keep = self.drop_out_rate if keep is None else keep
-        dev = self.device
-        video = torch.as_tensor(video).to(dev, torch.float32).contiguous()
-        cap = torch.as_tensor(caption).to(dev, torch.int32).contiguous()
-        mask = torch.as_tensor(caption_mask).to(dev, torch.float32).contiguous()
-        B, Tv, D = video.shape
-        H, V, Tc = self.dim_hidden, self.n_words, self.n_caption_lstm_steps
-        op = ops.operand
-        vid = torch.arange(B, dtype=torch.int32, device=dev); sid = torch.zeros(B, dtype=torch.int32, device=dev)
-        # ---- forward, keeping what the backward needs
-        emb = ops.gemm([op(video.view(B * Tv, D))], p["encode_image_W"], p["encode_image_b"], M=B * Tv)
-        Vt = emb.view(B, Tv, H).transpose(0, 1).contiguous()
-        P = ops.gemm([op(Vt.view(Tv * B, H))], p["embed_att_Ua"], p["embed_att_ba"], M=Tv * B).view(Tv, B, H)
-        w = p["embed_att_w"].view(-1).contiguous()
-        z0 = torch.zeros(B, H, device=dev)
-        c, h_prev, q_prev, cur = z0, z0, z0, z0
-        sv = []
-        logits = torch.empty(Tc * B, V, device=dev)
-        for t in range(Tc):
-            hWa = ops.gemm([op(q_prev)], p["embed_att_Wa"], None, M=B)
-            _, alpha, ctx = ops.attention_fwd(hWa, P, Vt, w)
-            c_new, h, out, gates = ops.lstm_cell_fwd(op(ctx), op(cur), h_prev, c, p["lstm3_W"], p["lstm3_b"], B, keep=keep, seed=seed,
-                                                     video_id=vid, sample_id=sid, drop_code=768 + t, want_gates=True)
-            y = ops.gemm([op(out), op(ctx), op(cur)], p["embed_nn_Wp"], p["embed_nn_bp"], M=B, act_tanh=True)
-            ops.gemm([op(y)], p["embed_word_W"], p["embed_word_b"], M=B, out=logits[t * B:(t + 1) * B])
-            sv.append((hWa, alpha, ctx, c, c_new, gates, out, y, cur, q_prev, h_prev))
-            c, h_prev, q_prev = c_new, h, out
-            cur = p["Wemb"][cap[:, t].long()].contiguous()
-        msum = mask.sum()
-        coef = mask.t().contiguous().view(-1)                         # time-major [Tc*B]
-        nll, _ = ops.softmax_nll_fwd_bwd(logits, cap.t().contiguous().view(-1), coef, 0.0)      # logits <- d/dlogits (un-normalised)
-        loss = torch.dot(coef, nll) / msum
-        # ---- backward
-        g = {k: torch.zeros_like(v) for k, v in p.items()}
-        WoutT, WpT, W3T = ops.transpose(p["embed_word_W"]), ops.transpose(p["embed_nn_Wp"]), ops.transpose(p["lstm3_W"])
-        WaT, UaT = ops.transpose(p["embed_att_Wa"]), ops.transpose(p["embed_att_Ua"])
-        dP_tot = torch.zeros_like(P); dVt_tot = torch.zeros_like(Vt)
-        dw = torch.zeros(H, device=dev)
-        dq_next = torch.zeros(B, H, device=dev)       # gradient w.r.t. this step's dropped output from the NEXT step's attention query
-        dh_rec = torch.zeros(B, H, device=dev)        # ... w.r.t. this step's clean h from the next step's LSTM
-        dc = None
-        for t in range(Tc - 1, -1, -1):
-            hWa, alpha, ctx, c_prev, c_new, gates, out, y, cur, q_prev, h_prev = sv[t]
-            dl = logits[t * B:(t + 1) * B]
-            ops.gemm_tn(y, dl, g["embed_word_W"]); ops.colsum(dl, g["embed_word_b"])
-            dy = ops.gemm([op(dl)], WoutT, None, M=B)
-            dpre = ops.tanh_bwd(y, dy)
-            ops.gemm_tn(out, dpre, g["embed_nn_Wp"][:H]); ops.gemm_tn(ctx, dpre, g["embed_nn_Wp"][H:2 * H])
-            ops.gemm_tn(cur, dpre, g["embed_nn_Wp"][2 * H:]); ops.colsum(dpre, g["embed_nn_bp"])
-            dcat = ops.gemm([op(dpre)], WpT, None, M=B)                                   # d[out ; ctx ; cur]
-            dout = dcat[:, :H] + dq_next
-            dh = ops.dropout_bwd(dout.contiguous(), keep, seed, 768 + t, vid, sid) + dh_rec
-            dz, dc = ops.lstm_cell_bwd(gates, c_new, c_prev, dh.contiguous(), dc)
-            ops.gemm_tn(ctx, dz, g["lstm3_W"][:H]); ops.gemm_tn(cur, dz, g["lstm3_W"][H:2 * H])
-            ops.gemm_tn(h_prev, dz, g["lstm3_W"][2 * H:]); ops.colsum(dz, g["lstm3_b"])
-            dx = ops.gemm([op(dz)], W3T, None, M=B)                                       # d[ctx ; cur ; h_prev]
-            dh_rec = dx[:, 2 * H:].contiguous()
-            dctx = (dcat[:, H:2 * H] + dx[:, :H]).contiguous()
-            dcur = (dcat[:, 2 * H:] + dx[:, H:2 * H]).contiguous()
-            if t > 0:
-                ops.lib().s2vt_embed_scatter_add(ops._ptr(dcur), dcur.stride(0), ops._ptr(cap[:, t - 1].contiguous()), B, H,
-                                                 ops._ptr(g["Wemb"]), ops._stream())
-            dhWa, dP, dVt = ops.attention_bwd(hWa, P, Vt, w, alpha, dctx, dw)
-            dP_tot += dP; dVt_tot += dVt
-            ops.gemm_tn(q_prev, dhWa, g["embed_att_Wa"])
-            dq_next = ops.gemm([op(dhWa)], WaT, None, M=B)
-        g["embed_att_w"] += dw.view(H, 1)
-        dPf = dP_tot.view(Tv * B, H)
-        ops.gemm_tn(Vt.view(Tv * B, H), dPf, g["embed_att_Ua"]); ops.colsum(dPf, g["embed_att_ba"])
-        dVt_tot += ops.gemm([op(dPf)], UaT, None, M=Tv * B).view(Tv, B, H)
-        demb = dVt_tot.transpose(0, 1).contiguous().view(B * Tv, H)                       # back to (b, t) rows
-        ops.gemm_tn(video.view(B * Tv, D), demb, g["encode_image_W"]); ops.colsum(demb, g["encode_image_b"])
-        inv = (1.0 / msum)
-        for k in g:
-            g[k] *= inv
-        # ---- clip + TF-form Adam (same kernels as the S2VT trainer, one call per variable)
-        if not hasattr(self, "_m"):
-            self._m = {k: torch.zeros_like(v) for k, v in p.items()}
-            self._v = {k: torch.zeros_like(v) for k, v in p.items()}
-            self._step = 0
-        self._step += 1
-        sumsq = torch.zeros(1, device=dev)
-        for k in g:
-            sumsq += (g[k].double() ** 2).sum().float()
-        for k in p:
-            ops.adam_tf(p[k].view(-1), g[k].view(-1), self._m[k].view(-1), self._v[k].view(-1), sumsq, clip_norm, lr, self._step,
-                        beta1, beta2, eps)
-        return loss, g
+        c = self._loss_forward(video, caption, caption_mask, keep, None)
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        ops.attn_step_scalars(self.dims, c["B"], c["ws"], c["coef"], c["nll"], c["reg"], self.m, c["msum"], c["msum"], out, None, None)
+        return out[0]
+
+    def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, keep=None, active_steps="auto", video_base=0,
+                  beta1=0.9, beta2=0.999, eps=1e-8):
+        """One training step (:436-441): loss = (sum ce*mask + sum regulariser) / sum(mask), tf.gradients through the unroll,
+        clip_by_global_norm(10), TF-form Adam.  active_steps "auto": behind the batch's longest caption every position is
+        masked and adds exact zeros, so with a host-resident mask only the leading steps are unrolled (single process)."""
+        keep = self.drop_out_rate if keep is None else keep
+        Tc = self.n_caption_lstm_steps
+        steps = Tc
+        if active_steps == "auto":
+            s = self._active_steps(caption_mask, Tc) if not dp.active() else None
+            steps = Tc if s is None else s
+        elif active_steps:
+            steps = max(1, min(Tc, int(active_steps)))
+        c = self._loss_forward(video, caption, caption_mask, keep, steps, video_base)
+        st = self.store
+        st.grad.zero_()
+        ops.attn_bptt_bwd(self.dims, st.params, st.grads, c["video"], c["dlogits"], c["ws"], c["steps"], c["reg"], self.m, keep, c["seed"],
+                          c["vid"], c["sid"])
+        gsum = dp.allreduce_bucket(st.grad, st.numel, c["msum"])                 # RCCL: one flat bucket + sum(mask) in its tail
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        sumsq = torch.empty(1, dtype=torch.float32, device=self.device)
+        ops.attn_step_scalars(self.dims, c["B"], c["ws"], c["coef"], c["nll"], c["reg"], self.m, c["msum"], gsum, loss, self._gscale, sumsq)
+        ops.grad_finalize(st.grad[:st.numel], st.theta, self._gscale, 0.0, sumsq)
+        self.global_step += 1
+        self.adam_t += 1
+        ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, sumsq, clip_norm, lr, self.adam_t, beta1, beta2, eps)
+        return StepStats(loss[0], sumsq, c["msum"][0])
+
+    # ------------------------------------------------------------------------------------------ the reference surface
+    def build_model(self):
+        """(loss, video, caption, caption_mask) as original_attention.py:88-150."""
+        B, Tc = self.batch_size, self.n_caption_lstm_steps
+        video = Placeholder("video", (B, self.n_video_lstm_steps, self.dim_image), np.float32)
+        caption = Placeholder("caption", (B, Tc), np.int32)
+        caption_mask = Placeholder("caption_mask", (B, Tc), np.float32)
+
+        def fn(v, c, m):
+            return {"loss": float(self.loss(v, c, m))}
+        return Output("loss", fn, [video, caption, caption_mask]), video, caption, caption_mask
+
+    def build_generator(self):
+        """(video, generated_words) as :155-199: greedy words [B, Tc] int64 for a batch_size block of videos."""
+        video = Placeholder("video", (self.batch_size, self.n_video_lstm_steps, self.dim_image), np.float32)
+
+        def fn(v):
+            ids, _ = ops.attn_decode_greedy(self.dims, self.store.params, self._dev(v, torch.float32))
+            return {"generated_words": ids.cpu().numpy().astype(np.int64)}
+        return video, Output("generated_words", fn, [video])
+
+    def build_sampler(self):
+        """(sampled_captions, video, saved_alphas) as :201-251: dynamic batch; saved_alphas fetches as [Tc, Tv, B]
+        (`n_caption_steps x n x b`, :251)."""
+        video = Placeholder("video", (None, self.n_video_lstm_steps, self.dim_image), np.float32)
+
+        def fn(v):
+            ids, al = ops.attn_decode_greedy(self.dims, self.store.params, self._dev(v, torch.float32), want_alphas=True)
+            return {"sampled_captions": ids.cpu().numpy().astype(np.int64), "saved_alphas": al.cpu().numpy()}
+        return Output("sampled_captions", fn, [video]), video, Output("saved_alphas", fn, [video])
+
+    # ---- the nodes train() adds around the model's graph (:430-441)
+    def exponential_decay(self, start_learning_rate, decay_steps, decay_rate=0.5):
+        """tf.train.exponential_decay(start_learning_rate, global_step, 10000, 0.5, staircase=True) (:431-432)."""
+        def value():
+            return float(start_learning_rate) * float(decay_rate) ** (self.global_step // int(decay_steps))
+        out = Output("learning_rate", lambda: {"learning_rate": value()}, [])
+        out.value = value
+        return out
+
+    def minimize(self, build_model_outputs, learning_rate, clip_norm=10.0):
+        """train_op of :433-441: AdamOptimizer(learning_rate).compute_gradients(tf_loss) -> clip_by_global_norm(10) ->
+        apply_gradients(global_step).  sess.run([train_op, tf_loss], feed) is ONE update; the loss fetched beside it is the
+        one the update differentiated (pre-update weights, same dropout masks)."""
+        loss, video, caption, caption_mask = build_model_outputs[:4]
+        lr = learning_rate.value if hasattr(learning_rate, "value") else (lambda: float(learning_rate))
+
+        def fn(v, c, m):
+            st = self.xe_update(v, c, m, lr(), clip_norm=clip_norm)
+            return {"train_op": None, "loss": float(st.loss)}
+        return Output("train_op", fn, [video, caption, caption_mask], provides={loss: "loss"})

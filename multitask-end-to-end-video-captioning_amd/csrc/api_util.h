@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/s2vt.h"
@@ -118,6 +119,67 @@ inline hipError_t store_call(const ASeg* segs, int nseg, const float* W, int ldw
     a.C = C; a.ldc = ldc; a.act = act;
     return launch_gemm(a, w_transposed ? EPI_STORE_NT : (int)EPI_STORE, cfg, st);
 }
+
+// ---- order-free data-gradient products (W^T form) with optional split-K slabs: shared by train.hip and attn_model.hip
+// The same for the other two data-gradient products of the backward when they are short of tiles: dX2 = dZ2 @ W2[0:H+E]^T
+// ([T N, H+E], K = 4H) and dX1 = dZ1 @ W1[0:E]^T ([Tv B, E], K = 4H).  One slab buffer serves both (they run one after the other).
+constexpr int kDxSlabRows = 2048, kDxMaxSlabs = 12;
+// Tile and slab count of such a product, from a sweep over 384..1600 rows x {dO2, dX2} x six tiles x seven slab counts
+// (tools/tune_slabs.py): the 64x64 tile (four waves along the rows) wins or ties everywhere -- slabs of ~1500 reduction steps
+// spend a third of their time in prologue and epilogue, which many small co-resident workgroups overlap and two big ones
+// per CU cannot -- with slabs of ~1536 steps and at least ~768 workgroups: dX2 at 1216 rows 213 -> 142 us, at 640 rows
+// 130 -> 83; dO2 at 384 rows 169 -> 95, at 896 rows 216 -> 185.
+constexpr int kSlabTileCfg = 0;        // kStoreNT[0] = nt64x64(4x1)
+inline int slab_splits(int M, int N, int K, int max_slabs)
+{
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    long s = (K + 1535) / 1536;
+    const long fill = (768 + tiles - 1) / tiles;
+    if (fill > s) s = fill;
+    if (s > max_slabs) s = max_slabs;
+    while (s > 1 && K / s < 256) --s;                                            // keep >= 8 chunks per slab
+    return s < 1 ? 1 : (int)s;
+}
+inline int dx_splits(int M, int N, int K)
+{
+    static const bool off = [] { const char* e = getenv("S2VT_DX_SPLITS"); return e && e[0] == '0'; }();      // dev knob
+    if (off || M > kDxSlabRows || ((size_t)M * N & 3)) return 1;
+    return slab_splits(M, N, K, kDxMaxSlabs);
+}
+// order-free product for the backward data path: C[s] = A[:, Ks] @ Wt[:, Ks]^T with Wt = the FORWARD weight block as it
+// lies in memory ([N rows][K columns], row stride ldw) -- no transposed copies (split-K slabs when splits > 1)
+inline hipError_t nn_bwd(const float* A, int lda, const float* Wt, int ldw, float* C, int ldc, int M, int N, int K, int splits,
+                  size_t slab_stride, hipStream_t st, int tile_cfg = -1)
+{
+    GemmArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.seg[0] = make_seg(A, lda, K, 0);
+    a.nseg = 1;
+    a.W = Wt; a.ldw = ldw; a.M = M; a.N = N; a.C = C; a.ldc = ldc;
+    if (splits > 1) {
+        a.splits = splits;
+        a.kper = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+        a.splits = (K + a.kper - 1) / a.kper;
+        a.slab_stride = slab_stride;
+    }
+    static const int cfg_ = [] { const char* e = getenv("S2VT_SLAB_CFG"); return e ? atoi(e) : -1; }();     // dev knob
+    return launch_gemm(a, EPI_STORE_NT, tile_cfg >= 0 ? tile_cfg : (splits > 1 ? cfg_ : -1), st);
+}
+
+// C = A @ Wt^T with the reduction cut into slabs when the output is short of tiles (dx_splits), the slabs summed into C
+inline hipError_t nn_bwd_slabs(const float* A, int lda, const float* Wt, int ldw, float* C, int ldc, int M, int N, int K, float* slabs, hipStream_t st,
+                        size_t slab_floats = ~(size_t)0)
+{
+    int s = slabs ? dx_splits(M, N, K) : 1;
+    if ((size_t)s * M * N > slab_floats) s = 1;                                  // (a row count the carve did not see)
+    if (s <= 1 || ldc != N) return nn_bwd(A, lda, Wt, ldw, C, ldc, M, N, K, 1, 0, st);
+    const size_t stride = (size_t)M * N;
+    hipError_t e = nn_bwd(A, lda, Wt, ldw, slabs, N, M, N, K, s, stride, st, kSlabTileCfg);
+    if (e != hipSuccess) return e;
+    const int kper = ((K + s - 1) / s + BK - 1) / BK * BK;                     // what nn_bwd made of `splits`
+    return launch_sum_slabs(C, slabs, (K + kper - 1) / kper, stride, stride, st);
+}
+
 
 // ---- sampler halves (api.hip), shared with the session API (session.hip)
 struct SampleWs {

@@ -2,11 +2,14 @@
 // multitask attribute head (reinforce_multitask_e2e_attribute_loss.py:375-380), forward + backward.
 //
 // Forward numerics follow the contract: the score e[t,b] = sum_h tanh(hWa[b,h] + P[t,b,h]) * w[h] is an
-// ascending-h fmaf chain, evaluated on the matrix pipe (v_mfma_f32_16x16x4_f32 with the tanh computed
-// on the fly as the A fragment and w in column 0 of the B fragment) so it is bit-identical to the
-// oracle's sequential chain; exp / divide are the fixed sequences of detmath.h; the context is an
-// ascending-t fmaf chain.  Backward is order-free fp32.
+// ascending-h fmaf chain (one VALU lane per frame runs it: v_fma_f32 is the oracle's fmaf), exp / divide are the
+// fixed sequences of detmath.h, the context is an ascending-t fmaf chain: bit-identical to the oracle's
+// orc_attention_step.  One launch per decode step does score -> softmax -> context (one workgroup per batch row).
+// Backward is order-free fp32, one launch per step as well.  The whole-model entry points are in attn_model.hip.
 #include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
 
 #include "api_util.h"
 #include "detmath.h"
@@ -17,103 +20,177 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// one wave per 16 rows of the flattened [Tv*B] score vector (row = t*B + b)
-__global__ __launch_bounds__(64) void attn_score_kernel(const float* hWa, const float* P, const float* w, float* e, int TvB,
-                                                        int B, int H)
-{
-    const int lane = threadIdx.x, l15 = lane & 15, lq = lane >> 4;
-    const int row = blockIdx.x * 16 + l15;
-    const bool ok = row < TvB;
-    const int b = ok ? row % B : 0;
-    const float* hp = hWa + (size_t)b * H;
-    const float* pp = P + (size_t)(ok ? row : 0) * H;
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < H; k0 += 4) {
-        const int k = k0 + lq;
-        float a = 0.f, bw = 0.f;
-        if (k < H) {
-            if (ok) a = dm_tanhf(hp[k] + pp[k]);
-            if (l15 == 0) bw = w[k];
-        }
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc, 0, 0, 0);
-    }
-    // D[i][j]: j = lane & 15, i = 4*(lane>>4) + r  -> column 0 lives in lanes 0,16,32,48
-    if (l15 == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = blockIdx.x * 16 + lq * 4 + r;
-            if (rr < TvB) e[rr] = acc[r];
-        }
-    }
-}
+// ---- forward: one workgroup per batch row b does the whole step for that row -------------------------------------
+//   phase 1  T[t][h] = tanh(hWa[b,h] + P[t,b,h]) for up to RC frames at a time, all 256 threads, into LDS
+//   phase 2  e[t] = the ascending-h fmaf chain sum_h T[t][h] * w[h]: ONE lane per frame runs the 1000-long chain on the
+//            VALU (v_fma_f32 is the same fused multiply-add the oracle's fmaf is; a dependent VALU chain issues every
+//            ~4-5 cycles per link where the 16x16x4 MFMA form of round 3 took 40 cycles per four links and used 1/16 of
+//            each MFMA), frames spread over the four waves so that the four SIMDs run them side by side
+//   phase 3  alpha = exp(e) / (sum_t exp(e) (+1 if 0)) in ascending t, the first-8-frames sum of the regulariser
+//   phase 4  ctx[b,h] = ascending-t fmaf chain of alpha[t] * V[t,b,h]
+// Bit-identical to oracle/s2vt_oracle.c::orc_attention_step.
+constexpr int kAttnMaxTv = 64;
+constexpr int kAttnChunkRows = 32;       // frames whose tanh rows are resident in LDS at a time (32 x 1004 floats = 126 KB at H = 1000)
 
-// alpha = exp(e) / (sum_t exp(e) (+1 if 0)) ; ctx[b,h] = chain_t alpha[t,b] * V[t,b,h]
-__global__ __launch_bounds__(256) void attn_softmax_ctx_kernel(const float* e, const float* Vt, float* alpha, float* ctx,
-                                                               int Tv, int B, int H)
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * H) return;
-    const int b = i / H, h = i % H;
-    float den = 0.f;
-    for (int t = 0; t < Tv; ++t) den = den + dm_expf(e[t * B + b]);
-    if (den == 0.f) den = den + 1.0f;
-    float c = 0.f;
-    for (int t = 0; t < Tv; ++t) {
-        const float a = dm_expf(e[t * B + b]) / den;
-        if (h == 0) alpha[t * B + b] = a;
-        c = __builtin_fmaf(a, Vt[((size_t)t * B + b) * H + h], c);
+    extern __shared__ float sm[];
+    const int H = a.H, Tv = a.Tv, B = a.B, ldT = a.ldT;
+    float* Tt = sm;                                  // [RC][ldT]
+    float* wl = sm + (size_t)a.RC * ldT;             // [ldT] the score vector w
+    float* ev = wl + ldT;                            // [64] scores
+    float* xv = ev + kAttnMaxTv;                     // [64] exp(e), then alpha
+    float* sc = xv + kAttnMaxTv;                     // [4] scalars
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* hp = a.hWa ? a.hWa + (size_t)b * H : nullptr;
+    for (int h = tid; h < H; h += 256) wl[h] = a.w[h];
+    for (int c0 = 0; c0 < Tv; c0 += a.RC) {
+        const int nr = (Tv - c0) < a.RC ? (Tv - c0) : a.RC;
+        if (a.vec) {
+            const int H4 = H >> 2;
+            for (int i = tid; i < nr * H4; i += 256) {
+                const int r = i / H4, q = i - r * H4;
+                float4 hv = hp ? *reinterpret_cast<const float4*>(hp + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 pv = *reinterpret_cast<const float4*>(a.P + ((size_t)(c0 + r) * B + b) * H + 4 * q);
+                float4 t;
+                t.x = dm_tanhf(hv.x + pv.x); t.y = dm_tanhf(hv.y + pv.y); t.z = dm_tanhf(hv.z + pv.z); t.w = dm_tanhf(hv.w + pv.w);
+                *reinterpret_cast<float4*>(Tt + (size_t)r * ldT + 4 * q) = t;
+            }
+        } else {
+            for (int i = tid; i < nr * H; i += 256) {
+                const int r = i / H, h = i - r * H;
+                Tt[(size_t)r * ldT + h] = dm_tanhf((hp ? hp[h] : 0.f) + a.P[((size_t)(c0 + r) * B + b) * H + h]);
+            }
+        }
+        __syncthreads();
+        const int r = (tid & 63) * 4 + (tid >> 6);       // frame r of the chunk -> wave r & 3, lane r >> 2
+        if (r < nr) {
+            const float* tr = Tt + (size_t)r * ldT;
+            float e = 0.f;
+            int h = 0;
+#pragma unroll 4
+            for (; h + 4 <= H; h += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(tr + h);
+                const float4 ww = *reinterpret_cast<const float4*>(wl + h);
+                e = __builtin_fmaf(t.x, ww.x, e);
+                e = __builtin_fmaf(t.y, ww.y, e);
+                e = __builtin_fmaf(t.z, ww.z, e);
+                e = __builtin_fmaf(t.w, ww.w, e);
+            }
+            for (; h < H; ++h) e = __builtin_fmaf(tr[h], wl[h], e);
+            ev[c0 + r] = e;
+        }
+        __syncthreads();
     }
-    ctx[i] = c;
-}
-
-// ---- backward -------------------------------------------------------------------------------
-// per b: dalpha[t] = sum_h dctx[b,h]*V[t,b,h];  de[t] = alpha[t]*(dalpha[t] - sum_t' alpha[t']*dalpha[t'])
-__global__ __launch_bounds__(256) void attn_bwd_de_kernel(const float* dctx, const float* Vt, const float* alpha, float* de,
-                                                          int Tv, int B, int H)
-{
-    __shared__ float sh[4];
-    __shared__ float dal[64];
-    const int b = blockIdx.x;
-    for (int t = 0; t < Tv; ++t) {
-        float s = 0.f;
-        for (int h = threadIdx.x; h < H; h += 256) s += dctx[(size_t)b * H + h] * Vt[((size_t)t * B + b) * H + h];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) dal[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (tid < Tv) {
+        const float e = ev[tid];
+        if (a.scores) a.scores[tid * B + b] = e;
+        xv[tid] = dm_expf(e);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float dot = 0.f;
-        for (int t = 0; t < Tv; ++t) dot += alpha[t * B + b] * dal[t];
-        for (int t = 0; t < Tv; ++t) de[t * B + b] = alpha[t * B + b] * (dal[t] - dot);
+    if (tid == 0) {
+        float den = 0.f;
+        for (int t = 0; t < Tv; ++t) den = den + xv[t];
+        if (den == 0.f) den = den + 1.0f;
+        sc[0] = den;
+    }
+    __syncthreads();
+    if (tid < Tv) {
+        const float al = xv[tid] / sc[0];
+        a.alpha[tid * B + b] = al;
+        ev[tid] = al;
+    }
+    __syncthreads();
+    if (tid == 0 && a.asum) {
+        float s = 0.f;
+        const int n8 = Tv < 8 ? Tv : 8;
+        for (int t = 0; t < n8; ++t) s = s + ev[t];
+        a.asum[b] = s;
+    }
+    if (a.vec) {
+        for (int q = tid; q < (H >> 2); q += 256) {
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < Tv; ++t) {
+                const float al = ev[t];
+                const float4 v = *reinterpret_cast<const float4*>(a.Vt + ((size_t)t * B + b) * H + 4 * q);
+                c.x = __builtin_fmaf(al, v.x, c.x); c.y = __builtin_fmaf(al, v.y, c.y);
+                c.z = __builtin_fmaf(al, v.z, c.z); c.w = __builtin_fmaf(al, v.w, c.w);
+            }
+            *reinterpret_cast<float4*>(a.ctx + (size_t)b * H + 4 * q) = c;
+        }
+    } else {
+        for (int h = tid; h < H; h += 256) {
+            float c = 0.f;
+            for (int t = 0; t < Tv; ++t) c = __builtin_fmaf(ev[t], a.Vt[((size_t)t * B + b) * H + h], c);
+            a.ctx[(size_t)b * H + h] = c;
+        }
     }
 }
 
-// dS = de*w*(1-T^2) -> dP[t,b,h] ; dhWa[b,h] = sum_t dS ; dV[t,b,h] (+)= alpha*dctx ; dw[h] += sum de*T
-__global__ __launch_bounds__(256) void attn_bwd_main_kernel(const float* hWa, const float* P, const float* w, const float* alpha,
-                                                            const float* de, const float* dctx, float* dhWa, float* dP,
-                                                            float* dVt, float* dw, int Tv, int B, int H)
+// ---- backward (order-free fp32), one workgroup per batch row ----------------------------------------------------------
+//   dctx[h]   = dense part + sum of the split-K slabs the caller's product left (optional)
+//   dalpha[t] = sum_h dctx[h] * V[t,b,h]   (one wave per frame, shuffle reduction)
+//   regulariser beta * max(0, m - sum(alpha[0:8])) * mask (original_attention.py:123,144): dalpha[t < 8] -= reg_coef[b] while
+//               the hinge is open (m - asum[b] > 0)
+//   de[t]     = alpha[t] * (dalpha[t] - sum_t' alpha[t'] dalpha[t'])
+//   dS = de * w * (1 - T^2) -> dP[t,b,h] ; dhWa[b,h] = sum_t dS ; dV[t,b,h] = alpha * dctx ; dw[h] += sum_t de * T
+// dP / dV are accumulated in place over the decode steps when acc != 0 (the workgroup owns its rows).
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * H) return;
-    const int b = i / H, h = i % H;
-    float acc = 0.f, dwl = 0.f;
-    const float dc = dctx[i], wh = w[h], hv = hWa[i];
-    for (int t = 0; t < Tv; ++t) {
-        const size_t o = ((size_t)t * B + b) * H + h;
-        const float T = dm_tanhf(hv + P[o]);
-        const float d = de[t * B + b];
-        const float ds = d * wh * (1.f - T * T);
-        dP[o] = ds;
-        acc += ds;
-        dVt[o] = alpha[t * B + b] * dc;
-        dwl += d * T;
+    extern __shared__ float sm[];
+    const int H = a.H, Tv = a.Tv, B = a.B;
+    float* dc = sm;                      // [H]
+    float* dal = sm + ((H + 3) & ~3);    // [64]
+    float* de = dal + kAttnMaxTv;        // [64]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int h = tid; h < H; h += 256) {
+        float v = a.dctx ? a.dctx[(size_t)b * a.ld_dctx + h] : 0.f;
+        for (int s = 0; s < a.nslab; ++s) v += a.slabs[(size_t)s * a.slab_stride + (size_t)b * a.ld_slab + a.ctx_col0 + h];
+        dc[h] = v;
+        if (a.demb_out) {
+            float u = a.demb_dense ? a.demb_dense[(size_t)b * a.ld_demb + h] : 0.f;
+            for (int s = 0; s < a.nslab; ++s) u += a.slabs[(size_t)s * a.slab_stride + (size_t)b * a.ld_slab + a.emb_col0 + h];
+            a.demb_out[(size_t)b * H + h] = u;
+        }
     }
-    dhWa[i] = acc;
-    atomicAdd(dw + h, dwl);
+    __syncthreads();
+    for (int t = wv; t < Tv; t += 4) {
+        const float* vp = a.Vt + ((size_t)t * B + b) * H;
+        float s = 0.f;
+        for (int h = lane; h < H; h += 64) s += dc[h] * vp[h];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) dal[t] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (a.reg_coef && (a.reg_m - a.asum[b]) > 0.f) {
+            const int n8 = Tv < 8 ? Tv : 8;
+            const float rc = a.reg_coef[b];
+            for (int t = 0; t < n8; ++t) dal[t] -= rc;
+        }
+        float dot = 0.f;
+        for (int t = 0; t < Tv; ++t) dot += a.alpha[t * B + b] * dal[t];
+        for (int t = 0; t < Tv; ++t) de[t] = a.alpha[t * B + b] * (dal[t] - dot);
+    }
+    __syncthreads();
+    for (int h = tid; h < H; h += 256) {
+        const float hv = a.hWa ? a.hWa[(size_t)b * H + h] : 0.f, wh = a.w[h], dch = dc[h];
+        float acc = 0.f, dwl = 0.f;
+        for (int t = 0; t < Tv; ++t) {
+            const size_t o = ((size_t)t * B + b) * H + h;
+            const float T = dm_tanhf(hv + a.P[o]);
+            const float d = de[t];
+            const float ds = d * wh * (1.f - T * T);
+            const float dv = a.alpha[t * B + b] * dch;
+            if (a.acc) { a.dP[o] += ds; a.dVt[o] += dv; }
+            else { a.dP[o] = ds; a.dVt[o] = dv; }
+            acc += ds;
+            dwl += d * T;
+        }
+        if (a.dhWa) a.dhWa[(size_t)b * H + h] = acc;
+        atomicAdd(a.dw + h, dwl);
+    }
 }
 
 // ---- attribute head ---------------------------------------------------------------------------
@@ -141,16 +218,48 @@ __global__ void sigmoid_bce_kernel(const float* z, const float* y, float* bce, f
 
 }  // namespace
 
+namespace s2vt {
+
+hipError_t launch_attn_fwd(const AttnFwdArgs& a0, hipStream_t st)
+{
+    if (a0.Tv <= 0 || a0.Tv > kAttnMaxTv || a0.B <= 0 || a0.H <= 0) return hipErrorInvalidValue;
+    AttnFwdArgs a = a0;
+    a.RC = a.Tv < kAttnChunkRows ? a.Tv : kAttnChunkRows;
+    a.ldT = ((a.H + 3) & ~3) + 4;
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    a.vec = (!(a.H & 3) && al16(a.P) && al16(a.Vt) && al16(a.ctx) && (!a.hWa || al16(a.hWa))) ? 1 : 0;
+    const size_t lds = ((size_t)(a.RC + 1) * a.ldT + 2 * kAttnMaxTv + 4) * sizeof(float);
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) return attr_err;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.B), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st)
+{
+    if (a.Tv <= 0 || a.Tv > kAttnMaxTv || a.B <= 0 || a.H <= 0) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)((a.H + 3) & ~3) + 2 * kAttnMaxTv) * sizeof(float);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace s2vt
+
 extern "C" {
 
 int s2vt_attention_fwd(const float* hWa, const float* P, const float* Vt, const float* w, float* scores, float* alpha,
                        float* ctx, int32_t Tv, int32_t B, int32_t H, s2vt_stream stream)
 {
-    if (!hWa || !P || !Vt || !w || !scores || !alpha || !ctx || Tv <= 0 || Tv > 64 || B <= 0 || H <= 0) return S2VT_E_BADARG;
-    hipStream_t st = S(stream);
-    hipLaunchKernelGGL(attn_score_kernel, dim3((Tv * B + 15) / 16), dim3(64), 0, st, hWa, P, w, scores, Tv * B, B, H);
-    hipLaunchKernelGGL(attn_softmax_ctx_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, scores, Vt, alpha, ctx, Tv, B, H);
-    HIP_TRY(hipGetLastError());
+    if (!hWa || !P || !Vt || !w || !scores || !alpha || !ctx || Tv <= 0 || Tv > kAttnMaxTv || B <= 0 || H <= 0) return S2VT_E_BADARG;
+    AttnFwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.hWa = hWa; a.P = P; a.Vt = Vt; a.w = w; a.scores = scores; a.alpha = alpha; a.ctx = ctx; a.Tv = Tv; a.B = B; a.H = H;
+    HIP_TRY(launch_attn_fwd(a, S(stream)));
     return S2VT_OK;
 }
 
@@ -158,14 +267,14 @@ int s2vt_attention_bwd(const float* hWa, const float* P, const float* Vt, const 
                        const float* dctx, float* de_scratch, float* dhWa, float* dP, float* dVt, float* dw, int32_t Tv,
                        int32_t B, int32_t H, s2vt_stream stream)
 {
-    if (!hWa || !P || !Vt || !w || !alpha || !dctx || !de_scratch || !dhWa || !dP || !dVt || !dw || Tv <= 0 || Tv > 64 ||
+    if (!hWa || !P || !Vt || !w || !alpha || !dctx || !de_scratch || !dhWa || !dP || !dVt || !dw || Tv <= 0 || Tv > kAttnMaxTv ||
         B <= 0 || H <= 0)
         return S2VT_E_BADARG;
-    hipStream_t st = S(stream);
-    hipLaunchKernelGGL(attn_bwd_de_kernel, dim3(B), dim3(256), 0, st, dctx, Vt, alpha, de_scratch, Tv, B, H);
-    hipLaunchKernelGGL(attn_bwd_main_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, hWa, P, w, alpha, de_scratch, dctx,
-                       dhWa, dP, dVt, dw, Tv, B, H);
-    HIP_TRY(hipGetLastError());
+    AttnBwdArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.hWa = hWa; a.P = P; a.Vt = Vt; a.w = w; a.alpha = alpha; a.dctx = dctx; a.ld_dctx = H;
+    a.dhWa = dhWa; a.dP = dP; a.dVt = dVt; a.dw = dw; a.Tv = Tv; a.B = B; a.H = H;
+    HIP_TRY(launch_attn_bwd(a, S(stream)));
     return S2VT_OK;
 }
 

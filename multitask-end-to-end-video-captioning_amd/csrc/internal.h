@@ -163,6 +163,35 @@ struct DecLoopLaunch {
 bool decode_loop_eligible(int R, int H, int E, int V);
 hipError_t launch_decode_loop(const DecLoopLaunch& a, const Dec4Geom& q, hipStream_t st);
 
+// ---- temporal attention step (attn.hip): score -> softmax -> context, one workgroup per batch row
+struct AttnFwdArgs {
+    const float* hWa;            // [B, H] query projection h_prev @ Wa, or NULL = zeros (the first decode step)
+    const float* P;              // [Tv, B, H] hoisted image part V @ Ua + ba (original_attention.py:107)
+    const float* Vt;             // [Tv, B, H] frame embeddings, time-major (:98)
+    const float* w;              // [H]
+    float* scores;               // optional [Tv, B]
+    float* alpha;                // [Tv, B]
+    float* asum;                 // optional [B]: alpha[0] + ... + alpha[min(8, Tv) - 1] (the regulariser's first-8-frames sum, :118,123)
+    float* ctx;                  // [B, H]
+    int Tv, B, H;
+    int RC, ldT, vec;            // (set by the launcher) frames per LDS chunk, LDS row stride, 16-byte path
+};
+hipError_t launch_attn_fwd(const AttnFwdArgs& a, hipStream_t st);
+struct AttnBwdArgs {
+    const float* hWa; const float* P; const float* Vt; const float* w; const float* alpha;    // as the forward (hWa may be NULL = zeros)
+    const float* dctx; int ld_dctx;                    // dense part of d(ctx) [B, ld] or NULL
+    const float* slabs; int nslab; size_t slab_stride; int ld_slab;   // + sum_s slabs[s][b * ld_slab + col0 + h] (split-K slabs of a [B, ld_slab] product)
+    int ctx_col0, emb_col0;                            // column of the ctx / embedding block inside a slab row
+    const float* demb_dense; int ld_demb; float* demb_out;   // optional: demb_out[b, h] = demb_dense[b, h] + sum_s slabs[..emb_col0 + h]
+    const float* reg_coef;                             // optional [B]: beta * mask[b, t] of the alpha regulariser (:123), with ...
+    const float* asum; float reg_m;                    // ... the forward's first-8-frames sums [B] and the margin m
+    float* dhWa;                                       // [B, H] (optional)
+    float* dP; float* dVt; int acc;                    // [Tv, B, H]; acc != 0: += (accumulated over the decode steps)
+    float* dw;                                         // [H], atomicAdd
+    int Tv, B, H;
+};
+hipError_t launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st);
+
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.
 struct NnBwdArgs {

@@ -49,17 +49,27 @@ class ParamStore:
     """All variables in ONE flat fp32 buffer (+ same-shaped grad / Adam m / Adam v buffers), each
     tensor a 256-byte aligned view: the optimizer and the RCCL all-reduce run over one range."""
 
-    def __init__(self, shapes: dict, device):
+    def __init__(self, shapes: dict, device, order=None, tf_names=None, params_factory=None):
+        """order: the variables in bucket order (default: the S2VT layout -- weight-decayed variables first, the LSTM
+        `biases` last); tf_names: variable -> TF checkpoint name; params_factory: dict of views -> the C struct of device
+        pointers the library takes (default ops.make_params = s2vt_params)."""
         self.shapes = shapes
-        dec = [n for n in DECAYED if n in shapes]
-        self.names = dec + [n for n in UNDECAYED if n in shapes]
+        self.tf_names = TF_NAMES if tf_names is None else tf_names
+        if order is None:
+            dec = [n for n in DECAYED if n in shapes]
+            self.names = dec + [n for n in UNDECAYED if n in shapes]
+        else:
+            self.names = list(order)
         self.offsets = {}
         off = 0
+        self.n_decayed = None
         for n in self.names:
-            if n == UNDECAYED[0]:
+            if order is None and n == UNDECAYED[0]:
                 self.n_decayed = off
             self.offsets[n] = off
             off += (int(np.prod(shapes[n])) + 63) // 64 * 64
+        if self.n_decayed is None:
+            self.n_decayed = off
         self.numel = off
         # one spare slot block at the end of the gradient buffer carries sum(mask) through the all-reduce
         self.theta = torch.zeros(off, dtype=torch.float32, device=device)
@@ -69,8 +79,9 @@ class ParamStore:
         self.p = {n: self._view(self.theta, n) for n in self.names}
         self.g = {n: self._view(self.grad, n) for n in self.names}
         on_gpu = torch.device(device).type == "cuda"      # (a CPU store serves checkpoint conversion / tests: no kernel can take it)
-        self.params = ops.make_params(self.p) if on_gpu else None
-        self.grads = ops.make_params(self.g) if on_gpu else None
+        factory = ops.make_params if params_factory is None else params_factory
+        self.params = factory(self.p) if on_gpu else None
+        self.grads = factory(self.g) if on_gpu else None
 
     def _view(self, flat, n):
         k = int(np.prod(self.shapes[n]))
@@ -90,12 +101,12 @@ class ParamStore:
         REINFORCE script's name (:637), 'Variable' what the unnamed tf.Variable(0, trainable=False) of the other scripts gets
         (tf_s2vt.py:441) -- and under 'global_step'.  adam_t: Adam's own count of applied updates (what beta*_power encode);
         defaults to global_step."""
-        sd = {TF_NAMES[n]: self.p[n].detach().cpu().numpy() for n in self.names}
+        sd = {self.tf_names[n]: self.p[n].detach().cpu().numpy() for n in self.names}
         if global_step is not None:
             t = int(global_step if adam_t is None else adam_t)
             for n in self.names:
-                sd[TF_NAMES[n] + "/Adam"] = self._view(self.m, n).detach().cpu().numpy()
-                sd[TF_NAMES[n] + "/Adam_1"] = self._view(self.v, n).detach().cpu().numpy()
+                sd[self.tf_names[n] + "/Adam"] = self._view(self.m, n).detach().cpu().numpy()
+                sd[self.tf_names[n] + "/Adam_1"] = self._view(self.v, n).detach().cpu().numpy()
             sd["beta1_power"] = np.float32(0.9 ** (t + 1))      # TF keeps beta^(t+1) after t applied steps
             sd["beta2_power"] = np.float32(0.999 ** (t + 1))
             sd["global_step"] = np.int64(global_step)
@@ -108,7 +119,7 @@ class ParamStore:
         'g_step' -- reinforcement_multisampling_tf_s2vt.py:637 -- or 'Variable', the unnamed counter of tf_s2vt.py:441);
         `self.restored_adam_t` is Adam's count of applied updates decoded from `beta1_power` (= 0.9^(t+1)) or None: the two
         differ when a REINFORCE run starts from an XE checkpoint (slots and beta powers match by name, 'g_step' does not)."""
-        inv = {v: k for k, v in TF_NAMES.items()}
+        inv = {v: k for k, v in self.tf_names.items()}
         loaded = []
         self.restored_step = None
         self.restored_adam_t = None

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import Dims, Operand, Params, check, lib
+from ._lib import AttnParams, Dims, Operand, Params, check, lib
 
 
 def _stream():
@@ -417,6 +417,78 @@ def attention_bwd(hWa, P, Vt, w, alpha, dctx, dw):
     check(lib().s2vt_attention_bwd(_ptr(hWa), _ptr(P), _ptr(Vt), _ptr(w), _ptr(alpha), _ptr(dctx), _ptr(de), _ptr(dh), _ptr(dP),
                                    _ptr(dV), _ptr(dw), Tv, B, H, _stream()), "s2vt_attention_bwd")
     return dh, dP, dV
+
+
+# ---------------------------------------------------------------------------------------------
+# the temporal-attention captioner as a whole model (csrc/attn_model.hip)
+# ---------------------------------------------------------------------------------------------
+def make_attn_params(tensors: dict) -> AttnParams:
+    """tensors: name -> CUDA fp32 tensor for every name of _lib.ATTN_PARAM_FIELDS."""
+    p = AttnParams()
+    for n in _lib.ATTN_PARAM_FIELDS:
+        t = tensors[n]
+        _chk_f32(t)
+        assert t.is_contiguous()
+        setattr(p, n, t.data_ptr())
+    p._keep = tensors
+    return p
+
+
+def attn_workspace(dims: Dims, B: int, device):
+    nbytes = lib().s2vt_attn_workspace_bytes(C.byref(dims), B)
+    assert nbytes > 0, "bad dims / B (n_video_lstm_step <= 64)"
+    return workspace(nbytes, device, "attn")
+
+
+def attn_teacher_forced_fwd(dims: Dims, params: AttnParams, video, caption, keep=1.0, seed=0, video_id=None, sample_id=None, steps=None,
+                            ws=None, logits=None, want_alphas=False):
+    """build_model's unroll (original_attention.py:88-143).  Returns (time-major logits [steps*B, V], alphas [steps,Tv,B] | None, ws)."""
+    _chk_f32(video)
+    B = video.shape[0]
+    assert video.is_contiguous() and caption.is_cuda and caption.dtype == torch.int32 and caption.is_contiguous()
+    assert caption.shape == (B, dims.n_caption_lstm_step)
+    steps = dims.n_caption_lstm_step if steps is None else int(steps)
+    if ws is None:
+        ws = attn_workspace(dims, B, video.device)
+    if logits is None:
+        logits = torch.empty((steps * B, dims.n_words), dtype=torch.float32, device=video.device)
+    al = torch.empty((steps, dims.n_video_lstm_step, B), dtype=torch.float32, device=video.device) if want_alphas else None
+    check(lib().s2vt_attn_teacher_forced_fwd(C.byref(dims), C.byref(params), _ptr(video), B, _ptr(caption), steps, float(keep), seed,
+                                             _ptr(video_id), _ptr(sample_id), _ptr(logits), _ptr(al), _ptr(ws), ws.numel(), _stream()),
+          "s2vt_attn_teacher_forced_fwd")
+    return logits, al, ws
+
+
+def attn_step_scalars(dims: Dims, B: int, ws, coef, nll, reg_coef, reg_m, msum_local, gsum_global, loss, gscale, sumsq):
+    _chk_f32(coef, nll, reg_coef, msum_local, gsum_global, loss, gscale, sumsq)
+    check(lib().s2vt_attn_step_scalars(_ptr(coef), _ptr(nll), coef.numel(), _ptr(reg_coef), float(reg_m), _ptr(msum_local), _ptr(gsum_global),
+                                       _ptr(loss), _ptr(gscale), _ptr(sumsq), C.byref(dims), B, _ptr(ws), ws.numel(), _stream()),
+          "s2vt_attn_step_scalars")
+
+
+def attn_bptt_bwd(dims: Dims, params: AttnParams, grads: AttnParams, video, dlogits, ws, steps=None, reg_coef=None, reg_m=0.5, keep=1.0,
+                  seed=0, video_id=None, sample_id=None):
+    _chk_f32(video, dlogits, reg_coef)
+    B = video.shape[0]
+    steps = dims.n_caption_lstm_step if steps is None else int(steps)
+    assert dlogits.shape[0] == steps * B and (reg_coef is None or reg_coef.numel() == steps * B)
+    check(lib().s2vt_attn_bptt_bwd(C.byref(dims), C.byref(params), C.byref(grads), _ptr(video), B, _ptr(dlogits), steps, _ptr(reg_coef),
+                                   float(reg_m), float(keep), seed, _ptr(video_id), _ptr(sample_id), _ptr(ws), ws.numel(), _stream()),
+          "s2vt_attn_bptt_bwd")
+
+
+def attn_decode_greedy(dims: Dims, params: AttnParams, video, video_base=0, want_alphas=False, ws=None):
+    """build_generator / build_sampler (original_attention.py:155-251): (ids [B,Tc] int32, alphas [Tc,Tv,B] | None)."""
+    _chk_f32(video)
+    assert video.is_contiguous()
+    B = video.shape[0]
+    if ws is None:
+        ws = attn_workspace(dims, B, video.device)
+    ids = torch.empty((B, dims.n_caption_lstm_step), dtype=torch.int32, device=video.device)
+    al = torch.empty((dims.n_caption_lstm_step, dims.n_video_lstm_step, B), dtype=torch.float32, device=video.device) if want_alphas else None
+    check(lib().s2vt_attn_decode_greedy(C.byref(dims), C.byref(params), _ptr(video), B, int(video_base), _ptr(ids), _ptr(al), _ptr(ws),
+                                        ws.numel(), _stream()), "s2vt_attn_decode_greedy")
+    return ids, al
 
 
 def attr_head_fwd(video, attr_W, attr_b, labels=None):

@@ -385,8 +385,18 @@ def attention_step(hWa, P, Vemb, w):
 
 
 def attention_forward(p, d: Dims, video, caption, drop=None, keep=1.0, greedy=False):
-    """original_attention.py:95-147 (teacher-forced build_model) or the greedy generator loop
-    (:176-251) when greedy=True.  Returns logits [B,Tc,V], alphas [Tc,Tv,B] and (greedy) ids."""
+    """original_attention.py:95-147 (teacher-forced build_model) or the greedy sampler loop
+    (build_generator :155-199, build_sampler :201-251) when greedy=True.
+    Returns logits [B,Tc,V], alphas [Tc,Tv,B] and (greedy) ids.
+
+    Chain order (the numeric contract, DESIGN.md section 3 "order of availability"): a pre-activation is ONE
+    ascending-k fmaf chain per output over the rows of its weight matrix, the row BLOCKS taken in the order in which
+    their inputs exist within the step -- inputs known before the step (the previous word's embedding), then the
+    recurrent state, then what the step computes (the context, then the cell output):
+        LSTM3  concat([atten, current_embed, h])  @ W3  (:131):  rows [H:2H] (embed), [2H:3H] (h), [0:H] (atten)
+        output concat([output1, atten, current_embed]) @ Wp (:134):  rows [2H:3H] (embed), [H:2H] (atten), [0:H] (output1)
+    (TF evaluates each as one matmul whose internal summation order is Eigen's and unknowable here; any fixed order is an
+    equally faithful restatement, and this one lets the hoisted / early blocks run ahead of the recurrence.)"""
     B, Tv, D = video.shape
     H = d.lstm_dim
     Tc = d.n_caption_lstm_step
@@ -402,10 +412,10 @@ def attention_forward(p, d: Dims, video, caption, drop=None, keep=1.0, greedy=Fa
     for t in range(Tc):
         hWa = gemm_chain(q_prev, p["embed_att_Wa"])
         alpha, ctx = attention_step(hWa, P, Vt, p["embed_att_w"])            # (:113-128)
-        z = gemm_chain(ctx, W3[:H]); gemm_chain(emb, W3[H:2 * H], z); gemm_chain(h_prev, W3[2 * H:], z)
+        z = gemm_chain(emb, W3[H:2 * H]); gemm_chain(h_prev, W3[2 * H:], z); gemm_chain(ctx, W3[:H], z)
         bias_add(z, p["lstm3_b"])
         c, h, out, _ = lstm_pointwise(z, c, None if drop is None else drop[t], keep)  # (:131-132)
-        y = gemm_chain(out, Wp[:H]); gemm_chain(ctx, Wp[H:2 * H], y); gemm_chain(emb, Wp[2 * H:], y)
+        y = gemm_chain(emb, Wp[2 * H:]); gemm_chain(ctx, Wp[H:2 * H], y); gemm_chain(out, Wp[:H], y)
         bias_add(y, p["embed_nn_bp"])
         lib().orc_tanh_inplace(_fp(y), C.c_int64(y.size))                     # (:134)
         h_prev = h                                                            # the cell state carries the clean h (state_is_tuple=False)
@@ -419,6 +429,32 @@ def attention_forward(p, d: Dims, video, caption, drop=None, keep=1.0, greedy=Fa
             tok = _i32(caption[:, t])
         emb = np.ascontiguousarray(p["Wemb"][tok])                            # (:141-142)
     return logits, alphas, (ids if greedy else None)
+
+
+def attention_regulariser(alphas, mask, beta=10.0, m=0.5):
+    """regularizer = beta * max(0, m - reduce_sum(alphas_1, 1)) * caption_mask[:, i] with alphas_1 = alpha[:, 0:8]
+    (original_attention.py:118-123, 144; m = 0.5, beta = 10 at :299-300).  alphas [Tc,Tv,B], mask [B,Tc] -> reg [B,Tc]
+    (fp32, the sum over the first min(8, Tv) frames in ascending order).  Identically zero while Tv <= 8: the
+    unshifted softmax sums to 1 > m."""
+    Tc, Tv, B = alphas.shape
+    s = np.zeros((Tc, B), np.float32)
+    for f in range(min(8, Tv)):
+        s = (s + alphas[:, f, :]).astype(np.float32)
+    hinge = np.maximum(np.float32(0.0), np.float32(m) - s).astype(np.float32)
+    return (np.float32(beta) * hinge).T.astype(np.float32) * _f32(mask)
+
+
+def attention_xe_loss(logits, alphas, caption, mask, beta=10.0, m=0.5):
+    """build_model's loss (original_attention.py:136-150): sum_{b,t} (ce[b,t] * mask[b,t] + regularizer[b,t]) / sum(mask),
+    ce = tf.nn.softmax_cross_entropy_with_logits on one-hot labels (no label smoothing here).  float64 accumulation."""
+    B, Tc, V = logits.shape
+    mask = np.asarray(mask, np.float64)
+    tot = 0.0
+    for t in range(Tc):
+        nll, _, _ = row_losses(np.ascontiguousarray(logits[:, t]), caption[:, t], 0.0)
+        tot += (nll.astype(np.float64) * mask[:, t]).sum()
+    tot += attention_regulariser(alphas, mask, beta, m).astype(np.float64).sum()
+    return tot / mask.sum()
 
 
 # ------------------------------------------------------------------------------------------

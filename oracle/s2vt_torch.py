@@ -159,6 +159,20 @@ def attention_teacher_forced(p, video, caption, drop=None, keep=1.0):
     return torch.stack(out_logits, 1), torch.stack(alphas, 0)
 
 
+def attention_xe_loss(p, video, caption, mask, drop=None, keep=1.0, beta=10.0, m=0.5):
+    """build_model's loss of the attention captioner (original_attention.py:136-150), differentiable:
+        sum_{b,t} (ce[b,t] * mask[b,t] + beta * max(0, m - sum(alpha[t, 0:8, b])) * mask[b,t]) / sum(mask)
+    (m = 0.5, beta = 10 at :299-300; the hinge is identically zero while Tv <= 8).  Returns (loss, logits, alphas)."""
+    logits, alphas = attention_teacher_forced(p, video, caption, drop, keep)
+    dt = logits.dtype
+    mk = torch.as_tensor(mask).to(dt)
+    lp = torch.log_softmax(logits, -1)
+    ce = -lp.gather(2, torch.as_tensor(caption).long().unsqueeze(-1)).squeeze(-1)                 # [B,Tc]
+    s = alphas[:, :8, :].sum(1)                                                                    # [Tc,B]
+    reg = beta * torch.clamp(m - s, min=0.0).transpose(0, 1) * mk
+    return ((ce * mk).sum() + reg.sum()) / mk.sum(), logits, alphas
+
+
 # ------------------------------------------------------------------------------------------
 # cpu_baseline: the reference's REINFORCE step structure with torch-CPU fp32
 # (reinforcement_multisampling_tf_s2vt.py:743-753 sampling, :823-826 update)
