@@ -42,6 +42,12 @@ TC, TV, D, E, H, V = 20, 5, 1536, 500, 1000, 12000
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # SURVEY §8(d) algorithmic flops per sequence-forward: frame embed 7.68 + 5 encode steps x 28 + 20 decode steps x 52 MFLOP
 F_SEQ = 7.68e6 + 5 * 28e6 + 20 * 52e6
+# attention captioner (original_attention.py:95-147), per sequence-forward: frame embed to H dims 2 Tv d H + image part 2 Tv H H + per decode
+# step {query 2 H H, score + context 4 Tv H, LSTM3 2 (3H)(4H), output layer 2 (3H) H, logits 2 H V}
+def f_att_seq(tv):
+    return 2.0 * tv * D * H + 2.0 * tv * H * H + TC * (2.0 * H * H + 4.0 * tv * H + 24.0 * H * H + 6.0 * H * H + 2.0 * H * V)
+
+
 WORKLOADS = {
     # name: (B per GPU, K, sequence-forwards per step, tokens per step, metric, description)
     "rl": dict(B=64, K=5, seqfwd=lambda B, K: (4 * K + 1) * B, tokens=lambda B, K: K * B * TC,
@@ -58,6 +64,15 @@ WORKLOADS = {
                metric="caption tokens/sec (XE train step)",
                desc="tf_s2vt XE train step (BASELINE configs[1]): B=64, T_vid=5, T_cap=20, d=1536, E=500, H=1000, |V|=12000; "
                     "label smoothing 0.05, Q1 batch-mean CE, weight decay, clip 10; MSVD-like caption lengths"),
+    "attention": dict(B=64, K=0, tv=5, seqfwd=lambda B, K: 3 * B, tokens=lambda B, K: B * TC,
+                      metric="caption tokens/sec (temporal-attention XE train step)",
+                      desc="original_attention.py train step (soft temporal attention over the frame features + LSTM3 + tanh output layer): "
+                           "B=64, T_vid=5, T_cap=20, d=1536, H=1000, |V|=12000; dropout 0.9, clip 10, Adam; MSVD-like caption lengths, "
+                           "the padding behind the batch's longest caption is not unrolled"),
+    "attention32": dict(B=64, K=0, tv=32, seqfwd=lambda B, K: 3 * B, tokens=lambda B, K: B * TC,
+                        metric="caption tokens/sec (temporal-attention XE train step, 32 frames)",
+                        desc="original_attention.py train step, the script's '32img' model (:287-290): T_vid=32 -- the alpha regulariser "
+                             "beta*max(0, m - sum(alpha[:, :8])) is live; B=64, T_cap=20, d=1536, H=1000, |V|=12000"),
     "multitask": dict(B=32, K=1, seqfwd=lambda B, K: 8 * B, tokens=lambda B, K: K * B * TC,
                       metric="sampled caption tokens/sec (multitask REINFORCE step)",
                       desc="multitask attribute-FC + XE mix + REINFORCE step, per-GPU shape of BASELINE configs[3]: B=32 "
@@ -228,7 +243,8 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
     if workload.startswith("e2e"):
         return make_e2e_step(workload, mdl, dev, rank, B, K, info if info is not None else {})
     g = torch.Generator().manual_seed(1234 + rank)                                        # per-rank data shard
-    video = (torch.randn(B, TV, D, generator=g) * 0.5).abs().to(dev)                      # post-ReLU IRv2 pool features
+    tv = WORKLOADS[workload].get("tv", TV)
+    video = (torch.randn(B, tv, D, generator=g) * 0.5).abs().to(dev)                      # post-ReLU IRv2 pool features
     rewards = (torch.rand(max(K, 1) * B, generator=g) * 2).to(dev)
     baseline = (torch.rand(B, generator=g) * 2).repeat(max(K, 1)).to(dev)
 
@@ -268,6 +284,14 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
         cap[j, ln[j]:] = 0
     gt = torch.as_tensor(cap).to(dev)
     gt_mask = pg_mask(gt)
+    if workload.startswith("attention"):
+        mask_host = gt_mask.cpu().numpy()                    # host-resident, as the reference's loop has it (sentence_padding_toix)
+        if info is not None:
+            info["active_steps"] = mdl._active_steps(mask_host, TC)
+
+        def step(i):
+            return mdl.xe_update(video, gt, mask_host, lr=1e-4, clip_norm=10.0, video_base=rank * B)
+        return step
     if workload == "xe":
         # as train_xe does: the steps behind the longest caption of the GLOBAL batch (its <eos> included) are padding on
         # every rank and are not unrolled (exact: they add zeros); every rank re-draws the other ranks' lengths
@@ -319,8 +343,12 @@ def main():
     s2vt_amd.lib()                                   # no fallback: raises if the HIP library is missing
 
     multitask = args.workload == "multitask"
-    mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, device=dev, seed=1234, multisample=max(K, 1),
-                                    label_dim=400 if multitask else 0, alpha=0.05 if multitask else 0.0)   # identical replicas
+    if args.workload.startswith("attention"):
+        from s2vt_amd import attention as A
+        mdl = A.Attention_Caption_Generator(D, V, H, B, wl["tv"], TC, 0.9, device=dev, seed=1234)
+    else:
+        mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, device=dev, seed=1234, multisample=max(K, 1),
+                                        label_dim=400 if multitask else 0, alpha=0.05 if multitask else 0.0)   # identical replicas
     mdl.world_size, mdl.rank = world, rank
     info = {}
     step = make_step(args.workload, mdl, dev, rank, B, K, info)
@@ -373,14 +401,15 @@ def main():
         value = wl["tokens"](B, K) * world * args.steps / dt
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3) if per_step else None
-        flops_step = F_SEQ * wl["seqfwd"](B, K)
+        flops_step = (f_att_seq(wl["tv"]) if "tv" in wl else F_SEQ) * wl["seqfwd"](B, K)
         dom = max(rows, key=lambda r: r["total_ms"]) if rows else None
         roof = None
         if dom:
             ach = dom["total_flops"] / (dom["total_ms"] * 1e-3) / 1e12
             cls = {0: "contraction+store", 1: "fused LSTM cell (4-gate GEMM + pointwise epilogue)", 2: "vocab logits + Gumbel-max pick",
                    3: "weight-gradient TN contraction", 4: "contraction+store, W^T operand (backward data gradients)",
-                   5: "persistent LSTM recurrence", 6: "persistent LSTM backward recurrence"}.get(dom["kernel_class"], "?")
+                   5: "persistent LSTM recurrence", 6: "persistent LSTM backward recurrence", 7: "attention score + softmax + context",
+                   8: "attention backward"}.get(dom["kernel_class"], "?")
             traffic, traffic_src = stored_traffic(dom["kernel_class"], dom["name"])
             # flops the contraction kernels actually executed per step (hoisting, LSTM1 once per video and sampler-state
             # reuse execute fewer than the algorithmic count), from the warm-up table

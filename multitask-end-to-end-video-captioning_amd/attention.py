@@ -62,6 +62,7 @@ class Attention_Caption_Generator:
             self.p["embed_word_b"].copy_(torch.as_tensor(np.asarray(bias_init_vector, np.float32)).to(self.device))
         self.global_step = 0
         self.adam_t = 0
+        self.world_size, self.rank, self.dp_overlap = 1, 0, False        # data parallel: one all-reduce of the flat bucket (dist.py)
         self.dropout_seed = seed + 1
         self._gscale = torch.ones(1, dtype=torch.float32, device=self.device)
         self._row_ids_cache = {}

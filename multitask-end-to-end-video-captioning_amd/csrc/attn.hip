@@ -42,24 +42,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a)
     float* xv = ev + kAttnMaxTv;                     // [64] exp(e), then alpha
     float* sc = xv + kAttnMaxTv;                     // [4] scalars
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* hp = a.hWa ? a.hWa + (size_t)b * H : nullptr;
+    const float* __restrict__ hp = a.hWa ? a.hWa + (size_t)b * H : nullptr;
+    const float* __restrict__ Pp = a.P;
+    const float* __restrict__ Vp = a.Vt;
     for (int h = tid; h < H; h += 256) wl[h] = a.w[h];
     for (int c0 = 0; c0 < Tv; c0 += a.RC) {
         const int nr = (Tv - c0) < a.RC ? (Tv - c0) : a.RC;
         if (a.vec) {
-            const int H4 = H >> 2;
-            for (int i = tid; i < nr * H4; i += 256) {
-                const int r = i / H4, q = i - r * H4;
-                float4 hv = hp ? *reinterpret_cast<const float4*>(hp + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 pv = *reinterpret_cast<const float4*>(a.P + ((size_t)(c0 + r) * B + b) * H + 4 * q);
-                float4 t;
-                t.x = dm_tanhf(hv.x + pv.x); t.y = dm_tanhf(hv.y + pv.y); t.z = dm_tanhf(hv.z + pv.z); t.w = dm_tanhf(hv.w + pv.w);
-                *reinterpret_cast<float4*>(Tt + (size_t)r * ldT + 4 * q) = t;
+            // thread = one 16-byte column group, all frames of the chunk: the loads of up to 8 frames are issued together
+            // (global latency is paid once per 8 frames, not once per frame)
+            for (int q = tid; q < (H >> 2); q += 256) {
+                const float4 hv = hp ? *reinterpret_cast<const float4*>(hp + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int r0 = 0; r0 < nr; r0 += 8) {
+                    float4 pv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (r0 + j < nr) pv[j] = *reinterpret_cast<const float4*>(Pp + ((size_t)(c0 + r0 + j) * B + b) * H + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (r0 + j < nr) {
+                            float4 t;
+                            t.x = dm_tanhf(hv.x + pv[j].x); t.y = dm_tanhf(hv.y + pv[j].y); t.z = dm_tanhf(hv.z + pv[j].z); t.w = dm_tanhf(hv.w + pv[j].w);
+                            *reinterpret_cast<float4*>(Tt + (size_t)(r0 + j) * ldT + 4 * q) = t;
+                        }
+                }
             }
         } else {
             for (int i = tid; i < nr * H; i += 256) {
                 const int r = i / H, h = i - r * H;
-                Tt[(size_t)r * ldT + h] = dm_tanhf((hp ? hp[h] : 0.f) + a.P[((size_t)(c0 + r) * B + b) * H + h]);
+                Tt[(size_t)r * ldT + h] = dm_tanhf((hp ? hp[h] : 0.f) + Pp[((size_t)(c0 + r) * B + b) * H + h]);
             }
         }
         __syncthreads();
@@ -68,14 +79,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a)
             const float* tr = Tt + (size_t)r * ldT;
             float e = 0.f;
             int h = 0;
-#pragma unroll 4
-            for (; h + 4 <= H; h += 4) {
-                const float4 t = *reinterpret_cast<const float4*>(tr + h);
-                const float4 ww = *reinterpret_cast<const float4*>(wl + h);
-                e = __builtin_fmaf(t.x, ww.x, e);
-                e = __builtin_fmaf(t.y, ww.y, e);
-                e = __builtin_fmaf(t.z, ww.z, e);
-                e = __builtin_fmaf(t.w, ww.w, e);
+            if (H >= 16) {
+                // 16 links per round, the next round's operands already on their way from LDS while this round's chain runs
+                float4 t0[4], w0[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t0[j] = *reinterpret_cast<const float4*>(tr + 4 * j); w0[j] = *reinterpret_cast<const float4*>(wl + 4 * j); }
+                for (; h + 16 <= H; h += 16) {
+                    float4 t1[4], w1[4];
+                    const int hn = (h + 32 <= H) ? h + 16 : h;           // (last round: a harmless re-read)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { t1[j] = *reinterpret_cast<const float4*>(tr + hn + 4 * j); w1[j] = *reinterpret_cast<const float4*>(wl + hn + 4 * j); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        e = __builtin_fmaf(t0[j].x, w0[j].x, e);
+                        e = __builtin_fmaf(t0[j].y, w0[j].y, e);
+                        e = __builtin_fmaf(t0[j].z, w0[j].z, e);
+                        e = __builtin_fmaf(t0[j].w, w0[j].w, e);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { t0[j] = t1[j]; w0[j] = w1[j]; }
+                }
             }
             for (; h < H; ++h) e = __builtin_fmaf(tr[h], wl[h], e);
             ev[c0 + r] = e;
@@ -110,18 +133,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a)
     if (a.vec) {
         for (int q = tid; q < (H >> 2); q += 256) {
             float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int t = 0; t < Tv; ++t) {
-                const float al = ev[t];
-                const float4 v = *reinterpret_cast<const float4*>(a.Vt + ((size_t)t * B + b) * H + 4 * q);
-                c.x = __builtin_fmaf(al, v.x, c.x); c.y = __builtin_fmaf(al, v.y, c.y);
-                c.z = __builtin_fmaf(al, v.z, c.z); c.w = __builtin_fmaf(al, v.w, c.w);
+            for (int t0 = 0; t0 < Tv; t0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (t0 + j < Tv) v[j] = *reinterpret_cast<const float4*>(Vp + ((size_t)(t0 + j) * B + b) * H + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (t0 + j < Tv) {
+                        const float al = ev[t0 + j];
+                        c.x = __builtin_fmaf(al, v[j].x, c.x); c.y = __builtin_fmaf(al, v[j].y, c.y);
+                        c.z = __builtin_fmaf(al, v[j].z, c.z); c.w = __builtin_fmaf(al, v[j].w, c.w);
+                    }
             }
             *reinterpret_cast<float4*>(a.ctx + (size_t)b * H + 4 * q) = c;
         }
     } else {
         for (int h = tid; h < H; h += 256) {
             float c = 0.f;
-            for (int t = 0; t < Tv; ++t) c = __builtin_fmaf(ev[t], a.Vt[((size_t)t * B + b) * H + h], c);
+            for (int t = 0; t < Tv; ++t) c = __builtin_fmaf(ev[t], Vp[((size_t)t * B + b) * H + h], c);
             a.ctx[(size_t)b * H + h] = c;
         }
     }
@@ -142,22 +172,55 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a)
     float* dc = sm;                      // [H]
     float* dal = sm + ((H + 3) & ~3);    // [64]
     float* de = dal + kAttnMaxTv;        // [64]
+    float* al = de + kAttnMaxTv;         // [64]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int h = tid; h < H; h += 256) {
-        float v = a.dctx ? a.dctx[(size_t)b * a.ld_dctx + h] : 0.f;
-        for (int s = 0; s < a.nslab; ++s) v += a.slabs[(size_t)s * a.slab_stride + (size_t)b * a.ld_slab + a.ctx_col0 + h];
-        dc[h] = v;
-        if (a.demb_out) {
-            float u = a.demb_dense ? a.demb_dense[(size_t)b * a.ld_demb + h] : 0.f;
-            for (int s = 0; s < a.nslab; ++s) u += a.slabs[(size_t)s * a.slab_stride + (size_t)b * a.ld_slab + a.emb_col0 + h];
-            a.demb_out[(size_t)b * H + h] = u;
+    const float* __restrict__ Pp = a.P;
+    const float* __restrict__ Vp = a.Vt;
+    const float* __restrict__ sl = a.slabs;
+    float* __restrict__ dPp = a.dP;
+    float* __restrict__ dVp = a.dVt;
+    if (tid < Tv) al[tid] = a.alpha[tid * B + b];
+    // every load of a thread is issued before the first is used (no store in between: nothing forces the compiler to wait)
+    if (a.vec) {
+        for (int q = tid; q < (H >> 2); q += 256) {
+            float4 v = a.dctx ? *reinterpret_cast<const float4*>(a.dctx + (size_t)b * a.ld_dctx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 u = (a.demb_out && a.demb_dense) ? *reinterpret_cast<const float4*>(a.demb_dense + (size_t)b * a.ld_demb + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < a.nslab; ++s) {
+                const float* row = sl + (size_t)s * a.slab_stride + (size_t)b * a.ld_slab + 4 * q;
+                const float4 x = *reinterpret_cast<const float4*>(row + a.ctx_col0);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                if (a.demb_out) {
+                    const float4 y = *reinterpret_cast<const float4*>(row + a.emb_col0);
+                    u.x += y.x; u.y += y.y; u.z += y.z; u.w += y.w;
+                }
+            }
+            *reinterpret_cast<float4*>(dc + 4 * q) = v;
+            if (a.demb_out) *reinterpret_cast<float4*>(a.demb_out + (size_t)b * H + 4 * q) = u;
+        }
+    } else {
+        for (int h = tid; h < H; h += 256) {
+            float v = a.dctx ? a.dctx[(size_t)b * a.ld_dctx + h] : 0.f;
+            for (int s = 0; s < a.nslab; ++s) v += sl[(size_t)s * a.slab_stride + (size_t)b * a.ld_slab + a.ctx_col0 + h];
+            dc[h] = v;
+            if (a.demb_out) {
+                float u = a.demb_dense ? a.demb_dense[(size_t)b * a.ld_demb + h] : 0.f;
+                for (int s = 0; s < a.nslab; ++s) u += sl[(size_t)s * a.slab_stride + (size_t)b * a.ld_slab + a.emb_col0 + h];
+                a.demb_out[(size_t)b * H + h] = u;
+            }
         }
     }
     __syncthreads();
     for (int t = wv; t < Tv; t += 4) {
-        const float* vp = a.Vt + ((size_t)t * B + b) * H;
+        const float* vp = Vp + ((size_t)t * B + b) * H;
         float s = 0.f;
-        for (int h = lane; h < H; h += 64) s += dc[h] * vp[h];
+        if (a.vec) {
+            for (int q = lane; q < (H >> 2); q += 64) {
+                const float4 x = *reinterpret_cast<const float4*>(vp + 4 * q), d = *reinterpret_cast<const float4*>(dc + 4 * q);
+                s += d.x * x.x + d.y * x.y + d.z * x.z + d.w * x.w;
+            }
+        } else {
+            for (int h = lane; h < H; h += 64) s += dc[h] * vp[h];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) dal[t] = s;
@@ -170,26 +233,64 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdArgs a)
             for (int t = 0; t < n8; ++t) dal[t] -= rc;
         }
         float dot = 0.f;
-        for (int t = 0; t < Tv; ++t) dot += a.alpha[t * B + b] * dal[t];
-        for (int t = 0; t < Tv; ++t) de[t] = a.alpha[t * B + b] * (dal[t] - dot);
+        for (int t = 0; t < Tv; ++t) dot += al[t] * dal[t];
+        for (int t = 0; t < Tv; ++t) de[t] = al[t] * (dal[t] - dot);
     }
     __syncthreads();
-    for (int h = tid; h < H; h += 256) {
-        const float hv = a.hWa ? a.hWa[(size_t)b * H + h] : 0.f, wh = a.w[h], dch = dc[h];
-        float acc = 0.f, dwl = 0.f;
-        for (int t = 0; t < Tv; ++t) {
-            const size_t o = ((size_t)t * B + b) * H + h;
-            const float T = dm_tanhf(hv + a.P[o]);
-            const float d = de[t];
-            const float ds = d * wh * (1.f - T * T);
-            const float dv = a.alpha[t * B + b] * dch;
-            if (a.acc) { a.dP[o] += ds; a.dVt[o] += dv; }
-            else { a.dP[o] = ds; a.dVt[o] = dv; }
-            acc += ds;
-            dwl += d * T;
+    if (a.vec) {
+        for (int q = tid; q < (H >> 2); q += 256) {
+            const float4 hv = a.hWa ? *reinterpret_cast<const float4*>(a.hWa + (size_t)b * H + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 wh = *reinterpret_cast<const float4*>(a.w + 4 * q), dch = *reinterpret_cast<const float4*>(dc + 4 * q);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), dwl = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t0 = 0; t0 < Tv; t0 += 4) {
+                float4 pv[4], op[4], ov[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (t0 + j < Tv) {
+                        const size_t o = ((size_t)(t0 + j) * B + b) * H + 4 * q;
+                        pv[j] = *reinterpret_cast<const float4*>(Pp + o);
+                        if (a.acc) { op[j] = *reinterpret_cast<const float4*>(dPp + o); ov[j] = *reinterpret_cast<const float4*>(dVp + o); }
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (t0 + j < Tv) {
+                        const size_t o = ((size_t)(t0 + j) * B + b) * H + 4 * q;
+                        const float d = de[t0 + j], alt = al[t0 + j];
+                        const float T0 = dm_tanhf(hv.x + pv[j].x), T1 = dm_tanhf(hv.y + pv[j].y), T2 = dm_tanhf(hv.z + pv[j].z), T3 = dm_tanhf(hv.w + pv[j].w);
+                        float4 ds, dv;
+                        ds.x = d * wh.x * (1.f - T0 * T0); ds.y = d * wh.y * (1.f - T1 * T1); ds.z = d * wh.z * (1.f - T2 * T2); ds.w = d * wh.w * (1.f - T3 * T3);
+                        dv.x = alt * dch.x; dv.y = alt * dch.y; dv.z = alt * dch.z; dv.w = alt * dch.w;
+                        acc.x += ds.x; acc.y += ds.y; acc.z += ds.z; acc.w += ds.w;
+                        dwl.x += d * T0; dwl.y += d * T1; dwl.z += d * T2; dwl.w += d * T3;
+                        if (a.acc) {
+                            ds.x += op[j].x; ds.y += op[j].y; ds.z += op[j].z; ds.w += op[j].w;
+                            dv.x += ov[j].x; dv.y += ov[j].y; dv.z += ov[j].z; dv.w += ov[j].w;
+                        }
+                        *reinterpret_cast<float4*>(dPp + o) = ds;
+                        *reinterpret_cast<float4*>(dVp + o) = dv;
+                    }
+            }
+            if (a.dhWa) *reinterpret_cast<float4*>(a.dhWa + (size_t)b * H + 4 * q) = acc;
+            atomicAdd(a.dw + 4 * q, dwl.x); atomicAdd(a.dw + 4 * q + 1, dwl.y); atomicAdd(a.dw + 4 * q + 2, dwl.z); atomicAdd(a.dw + 4 * q + 3, dwl.w);
         }
-        if (a.dhWa) a.dhWa[(size_t)b * H + h] = acc;
-        atomicAdd(a.dw + h, dwl);
+    } else {
+        for (int h = tid; h < H; h += 256) {
+            const float hv = a.hWa ? a.hWa[(size_t)b * H + h] : 0.f, wh = a.w[h], dch = dc[h];
+            float acc = 0.f, dwl = 0.f;
+            for (int t = 0; t < Tv; ++t) {
+                const size_t o = ((size_t)t * B + b) * H + h;
+                const float T = dm_tanhf(hv + Pp[o]);
+                const float d = de[t];
+                const float ds = d * wh * (1.f - T * T);
+                const float dv = al[t] * dch;
+                if (a.acc) { dPp[o] += ds; dVp[o] += dv; }
+                else { dPp[o] = ds; dVp[o] = dv; }
+                acc += ds;
+                dwl += d * T;
+            }
+            if (a.dhWa) a.dhWa[(size_t)b * H + h] = acc;
+            atomicAdd(a.dw + h, dwl);
+        }
     }
 }
 
@@ -236,15 +337,45 @@ hipError_t launch_attn_fwd(const AttnFwdArgs& a0, hipStream_t st)
     });
     if (attr_err != hipSuccess) return attr_err;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    // launch profiler class 7: attention forward (flops = the score and context chains, 2 x 2 Tv B H; HBM-bound by P and V)
+    if (!prof_wants(7, 0)) {
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.B), dim3(256), lds, st, a);
+        return hipGetLastError();
+    }
+    hipEvent_t e0, e1;
+    hipError_t pe = prof_events(&e0, &e1);
+    if (pe != hipSuccess) return pe;
+    (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.B), dim3(256), lds, st, a);
+    (void)hipEventRecord(e1, st);
+    prof_record(7, 0, "attn_fwd(score+softmax+ctx)", 4.0 * a.Tv * a.B * (double)a.H, e0, e1);
     return hipGetLastError();
 }
 
-hipError_t launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st)
+hipError_t launch_attn_bwd(const AttnBwdArgs& a0, hipStream_t st)
 {
-    if (a.Tv <= 0 || a.Tv > kAttnMaxTv || a.B <= 0 || a.H <= 0) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)((a.H + 3) & ~3) + 2 * kAttnMaxTv) * sizeof(float);
+    if (a0.Tv <= 0 || a0.Tv > kAttnMaxTv || a0.B <= 0 || a0.H <= 0) return hipErrorInvalidValue;
+    AttnBwdArgs a = a0;
+    {
+        const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+        bool v = !(a.H & 3) && al16(a.P) && al16(a.Vt) && al16(a.w) && al16(a.dP) && al16(a.dVt) && al16(a.dw) && (!a.hWa || al16(a.hWa)) &&
+                 (!a.dhWa || al16(a.dhWa)) && (!a.dctx || (al16(a.dctx) && !(a.ld_dctx & 3)));
+        if (a.nslab > 0) v = v && al16(a.slabs) && !(a.slab_stride & 3) && !(a.ld_slab & 3) && !(a.ctx_col0 & 3) && !(a.emb_col0 & 3);
+        if (a.demb_out) v = v && al16(a.demb_out) && (!a.demb_dense || (al16(a.demb_dense) && !(a.ld_demb & 3)));
+        a.vec = v ? 1 : 0;
+    }
+    const size_t lds = ((size_t)((a.H + 3) & ~3) + 3 * kAttnMaxTv) * sizeof(float);
+    if (!prof_wants(8, 0)) {
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B), dim3(256), lds, st, a);
+        return hipGetLastError();
+    }
+    hipEvent_t e0, e1;
+    hipError_t pe = prof_events(&e0, &e1);
+    if (pe != hipSuccess) return pe;
+    (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(a.B), dim3(256), lds, st, a);
+    (void)hipEventRecord(e1, st);
+    prof_record(8, 0, "attn_bwd", 10.0 * a.Tv * a.B * (double)a.H, e0, e1);
     return hipGetLastError();
 }
 

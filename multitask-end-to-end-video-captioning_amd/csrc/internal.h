@@ -189,6 +189,7 @@ struct AttnBwdArgs {
     float* dP; float* dVt; int acc;                    // [Tv, B, H]; acc != 0: += (accumulated over the decode steps)
     float* dw;                                         // [H], atomicAdd
     int Tv, B, H;
+    int vec;                                           // (set by the launcher) 16-byte path
 };
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st);
 
