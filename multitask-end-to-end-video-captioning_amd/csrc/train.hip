@@ -546,6 +546,12 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         BwdScratch sc{w.slab, w.dc, w.bimg, w.bex, w.bsync};
         HIP_TRY(lstm_recurrence_bwd(p->lstm2_W, H + E, w.G2, w.C2, w.dO2, NH, H, Tv, w.dZ2, N, H, T, keep, seed, 512u, video_id, sample_id, sc, -1, st));
     }
+    // Live rows: the packed copies of the live dZ2 rows / previous words are read on BOTH streams (weight gradients on the side
+    // stream, dX2 and the embedding scatter on the caller's), so they are made on the caller's stream, ahead of the fork
+    if (live_rows) {
+        HIP_TRY(launch_gather_rows(w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, live_rows, n_live, 4 * H, w.dZ2p, 4 * H, st));
+        HIP_TRY(launch_gather_i32(w.prev, live_rows, n_live, w.prevp, st));
+    }
     // dZ2 is complete: LSTM2's weight gradients go to the side stream, beside dX2 and LSTM1's recurrence
     if (sd != st) HIP_TRY(fork_to(st, sd, ss.ev[1]));
     if (!live_rows) {
@@ -563,8 +569,6 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         // dh / dc), so the weight gradients are reduced over the Tv encode steps (every row) plus the LIVE decode rows -- their
         // dZ2 rows as a packed copy, the matching activation rows gathered through the same list.
         const int R = n_live;
-        HIP_TRY(launch_gather_rows(w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, live_rows, R, 4 * H, w.dZ2p, 4 * H, sd));
-        HIP_TRY(launch_gather_i32(w.prev, live_rows, R, w.prevp, sd));
         TnArgs a0{w.O1, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W, 4 * H, Tv * N, H, 4 * H, 1};
         HIP_TRY(launch_gemm_tn(a0, sd));
         TnArgs a1{w.O1 + (size_t)Tv * NH, live_rows, H, w.dZ2p, 4 * H, grads->lstm2_W, 4 * H, R, H, 4 * H, 1};

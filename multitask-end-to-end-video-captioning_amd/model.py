@@ -92,7 +92,7 @@ class ParamStore:
             if n in self.p:
                 self.p[n].copy_(torch.as_tensor(np.asarray(a)).to(self.p[n].device))
 
-    def state_dict(self, global_step=None, adam_t=None, step_name="g_step"):
+    def state_dict(self, global_step=None, adam_t=None, step_name="g_step", counter_dtype=np.int64):
         """Checkpoint with the reference's TF variable names.  With global_step given, also what a tf.train.Saver created
         AFTER the optimizer stores beside the variables (reinforcement_multisampling_tf_s2vt.py:661; the saver of
         tf_s2vt.py:440 is created before the optimizer and holds the model variables only): the Adam slots `<var>/Adam` (m),
@@ -110,7 +110,8 @@ class ParamStore:
             sd["beta1_power"] = np.float32(0.9 ** (t + 1))      # TF keeps beta^(t+1) after t applied steps
             sd["beta2_power"] = np.float32(0.999 ** (t + 1))
             sd["global_step"] = np.int64(global_step)
-            sd[step_name] = np.int64(global_step)
+            sd[step_name] = counter_dtype(global_step)       # (tf.Variable(0, trainable=False) is DT_INT32: the TF writers pass np.int32)
+            sd["adam_t"] = np.int64(t)                       # Adam's update count, stated (beta1_power = 0.9^(t+1) goes denormal past t ~ 800)
         return sd
 
     def load_state_dict(self, sd: dict):
@@ -123,6 +124,9 @@ class ParamStore:
         loaded = []
         self.restored_step = None
         self.restored_adam_t = None
+        explicit_t = "adam_t" in sd and np.ndim(sd["adam_t"]) == 0
+        if explicit_t:
+            self.restored_adam_t = int(sd["adam_t"])
 
         def put(dst, arr):
             dst.copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(dst.device))
@@ -140,9 +144,13 @@ class ParamStore:
                 if name == "global_step" or self.restored_step is None:
                     self.restored_step = int(arr)
                 loaded.append(name)
+            elif name == "adam_t" and np.ndim(arr) == 0:
+                self.restored_adam_t = int(arr)                  # stated outright: wins over the decoded beta1_power
+                explicit_t = True
+                loaded.append(name)
             elif name == "beta1_power" and np.ndim(arr) == 0:
                 b = float(arr)
-                if 0.0 < b < 1.0:
+                if 0.0 < b < 1.0 and not explicit_t:
                     self.restored_adam_t = max(0, int(round(math.log(b) / math.log(0.9))) - 1)
                 loaded.append(name)
         return loaded
@@ -286,15 +294,21 @@ class Video_Caption_Generator:
             hit = self._row_id_cache[key] = (vid.contiguous(), sid.contiguous())
         return hit
 
-    def _untile(self, v, N):
+    def _untile(self, v, N, host=None):
         """The reference feeds build_loss the feature block tiled K times, rows k*B+j = video j
         (reinforcement_multisampling_tf_s2vt.py:779-782).  Returns (the B distinct videos, B) when `v` is such a
-        tiling -- LSTM1 and the frame embedding then run once per video; any other [N, ...] block is N videos."""
+        tiling -- LSTM1 and the frame embedding then run once per video; any other [N, ...] block is N videos.
+        host: the feed as it arrived when it lives on the host (numpy / list, what Session.run receives): the K blocks are
+        compared THERE, before the copy to the device, and a feed that is not a tiling takes the N-video path.  A device
+        tensor is taken at the feed contract's word (comparing its copies would force a device-to-host synchronisation
+        into every step; S2VT_DEBUG_CHECKS=1 verifies it)."""
         K = self.multisample
         if v.shape[0] == N and K > 1 and N % K == 0:
-            # decided from the feed contract alone (build_loss's video placeholder IS the K-times tiled block, :228,:779):
-            # comparing the copies would force a device-to-host sync into every step.  S2VT_DEBUG_CHECKS=1 verifies it.
             B = N // K
+            if host is not None:
+                hb = np.asarray(host).reshape(K, B, -1)
+                if not all(np.array_equal(hb[0], hb[k]) for k in range(1, K)):
+                    return v.contiguous(), v.shape[0]
             blocks = v.view(K, B, *v.shape[1:])
             if self._debug_checks:
                 assert bool((blocks == blocks[0]).all()), "build_loss feed: rows k*B+j must repeat video j (np.tile of the feature block)"
@@ -811,9 +825,10 @@ class Video_Caption_Generator:
         lr = learning_rate.value if hasattr(learning_rate, "value") else (lambda: float(learning_rate))
 
         def fn(v, c, m, r, b):
+            vh = None if isinstance(v, torch.Tensor) else v
             v = self._dev(v, torch.float32)
             c = self._dev(c, torch.int32)
-            v, _ = self._untile(v, c.shape[0])
+            v, _ = self._untile(v, c.shape[0], host=vh)
             st = self.reinforce_update(v, c, m, np.asarray(r, np.float32).reshape(-1), np.asarray(b, np.float32).reshape(-1), lr(),
                                        clip_norm=clip_norm)
             return {"train_op": None, "sum_loss": float(st.loss)}
@@ -830,8 +845,9 @@ class Video_Caption_Generator:
         caption_mask = Placeholder("caption_mask", (N, Tc), np.float32)
 
         def fn(v, c, m):
+            vh = None if isinstance(v, torch.Tensor) else v
             v = self._dev(v, torch.float32); c = self._dev(c, torch.int32); m = self._dev(m, torch.float32)
-            v, B = self._untile(v, c.shape[0])
+            v, B = self._untile(v, c.shape[0], host=vh)
             vid, sid = self._row_ids(B, c.shape[0] // B, 0)
             seed = self.dropout_seed + 104729 * self.global_step
             logits, _ = ops.teacher_forced_fwd(self.dims, self.store.params, v, c, c.shape[0], self.dropout_rate, seed, vid, sid)

@@ -143,11 +143,19 @@ def run_step(model, fn, log=print, retries: int = 1, overlap=None):
     """One training step with the persistent-recurrence guard: fn() runs the step and returns its statistics; the host then
     reads the loss (the synchronisation point the reference's sess.run is) and checks the library's health.  On
     S2VTChainTimeout -- a persistent LSTM recurrence was starved of CUs, e.g. by another process on the GPU -- the
-    variables are intact (Adam launches behind the fault skip on the device): recover() rewinds the step counter to the
-    last applied update, switches to per-step launches, and the SAME batch is repeated.
+    variables of THIS process are intact (Adam launches behind the fault skip on the device).
+    Single process: recover() rewinds the step counter to the last applied update, switches to per-step launches, and the
+    SAME batch is repeated.
+    Data parallel (world > 1): the fault is local to one rank but the step is collective -- the faulting rank's garbage
+    gradients have already taken part in the all-reduce (the healthy ranks applied them) or, if the fault surfaced earlier,
+    its peers are waiting in a collective it will never join; repeating the batch on one rank would pair its all-reduces
+    with the peers' NEXT batch.  So no retry: the exception propagates, the process exits non-zero, torch.distributed.run
+    tears the job down, and the launcher restarts it from the last checkpoint (`--resume`; checkpoints are only written
+    after a collective health check, save_checkpoint_checked).
     overlap: host work that does not depend on this step's result (preparing the next batch, writing the previous step's
     log lines); it runs once, after the step has been queued on the GPU and before the host blocks on its loss."""
     from ._lib import S2VTChainTimeout
+    collective = getattr(model, "world_size", 1) > 1
     for attempt in range(retries + 1):
         try:
             st = fn()
@@ -158,12 +166,32 @@ def run_step(model, fn, log=print, retries: int = 1, overlap=None):
             model.check_health()
             return st, loss
         except S2VTChainTimeout as e:
+            if collective:
+                log(f"persistent recurrence timed out on rank {getattr(model, 'rank', '?')} of a data-parallel job ({e}); replicas can no "
+                    "longer be kept in step from here: exiting so that the launcher restarts from the last checkpoint")
+                raise
             if attempt == retries:
                 raise
             step, lost = model.recover()
             log(f"persistent recurrence timed out ({e}); variables intact at step {step} ({lost} update(s) skipped); "
                 "continuing with per-step launches and repeating the batch")
     raise AssertionError("unreachable")
+
+
+def all_ranks_healthy(model) -> bool:
+    """Collective (every rank must call it): True when NO rank has a persistent-recurrence fault pending.  One 1-element MAX
+    all-reduce; a plain local check in a single process."""
+    from . import ops
+    bad = 1.0 if ops.chain_fault() else 0.0
+    if getattr(model, "world_size", 1) > 1 and dp.active():
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([bad], dtype=torch.float32, device=model.device)
+        if t.is_cuda and dist.get_backend() == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        bad = float(t[0])
+    return bad == 0.0
 
 
 def greedy_eval(model, corpus: Corpus, ixtoword, scorer: "reward.CiderD | None", batch_size: int, par: "DataParallel | None" = None):
@@ -195,19 +223,34 @@ def save_checkpoint(model, cfg: Config, epoch: int, step_name: str = "g_step"):
     the optimizer (reinforcement_multisampling_tf_s2vt.py:661): Adam slots, beta powers, the step counter -- a resumed
     run continues the moments, the bias correction, the learning-rate staircase and the noise streams."""
     os.makedirs(cfg.model_path, exist_ok=True)
-    sd = model.store.state_dict(global_step=model.global_step, adam_t=model.adam_t, step_name=step_name)
-    if cfg.checkpoint_format == "tf":                      # the files tf.train.Saver.save(sess, path, global_step=epoch) leaves (:661)
+    tf_fmt = cfg.checkpoint_format in ("tf", "tf_v1")
+    sd = model.store.state_dict(global_step=model.global_step, adam_t=model.adam_t, step_name=step_name,
+                                counter_dtype=np.int32 if tf_fmt else np.int64)      # the graph's counter is tf.Variable(0): DT_INT32
+    if tf_fmt:                                             # the files tf.train.Saver.save(sess, path, global_step=epoch) leaves (:661)
         from . import tfckpt
         path = os.path.join(cfg.model_path, f"{cfg.model_name}-{epoch}")
         sd.pop("global_step", None)                        # (this repository's alias; the graph's counter is `step_name`)
-        tfckpt.write_checkpoint_v2(path, {k: np.asarray(v) for k, v in sd.items()})
+        arrays = {k: np.asarray(v) for k, v in sd.items()}
+        if cfg.checkpoint_format == "tf_v1":               # tf_s2vt.py:440: tf.train.Saver(write_version=1) -- ONE file, the V1 tensor-slice format
+            tfckpt.write_checkpoint_v1(path, arrays)
+        else:
+            tfckpt.write_checkpoint_v2(path, arrays)
         return path
     path = os.path.join(cfg.model_path, f"{cfg.model_name}-{epoch}.npz")
     np.savez(path, **sd)
     return path
 
 
-def optimistic_restore(model, path, restore_step: bool = True, step_names=("global_step", "g_step", "Variable")):
+def save_checkpoint_checked(model, cfg: Config, epoch: int, step_name: str = "g_step", chief: bool = True):
+    """save_checkpoint behind a COLLECTIVE health check (every rank calls this; the chief writes): a rank whose
+    persistent recurrence faulted has fed garbage into an all-reduce, so no replica's variables may be written out."""
+    if not all_ranks_healthy(model):
+        from ._lib import S2VTChainTimeout
+        raise S2VTChainTimeout("a rank of this data-parallel job has a persistent-recurrence fault pending: not writing a checkpoint")
+    return save_checkpoint(model, cfg, epoch, step_name) if chief else None
+
+
+def optimistic_restore(model, path, restore_step: bool = True, step_names=("global_step", "g_step", "Variable"), optimizer_state="auto"):
     """Load every variable whose name and shape match (reinforcement_multisampling_tf_s2vt.py:47-61) from an .npz dump or a
     TensorFlow checkpoint FILE (V2 `<prefix>.index` + data shards, or a V1 file: tfckpt.py) -- Adam slots and
     beta powers included, as there -- and position the model's counters: the step counter when the checkpoint holds one
@@ -216,6 +259,14 @@ def optimistic_restore(model, path, restore_step: bool = True, step_names=("glob
     from . import tfckpt
     raw = tfckpt.read_checkpoint(path)                     # .npz dump, TensorFlow V2 prefix (<path>.index) or V1 file
     sd = {k: v for k, v in raw.items() if k in step_names or k not in ("global_step", "g_step", "Variable")}
+    # optimizer_state "auto": Adam's slots / beta powers / update count are taken only from a checkpoint of a run whose graph
+    # had them under THIS run's counter -- i.e. one that carries a counter named in `step_names`.  The reference's XE saver
+    # (tf_s2vt.py:440) is created BEFORE the optimizer and holds the model variables only, so a REINFORCE run restored from an XE
+    # checkpoint starts Adam from zero moments (optimistic_restore finds no slots, :47-61); our XE checkpoints do carry the
+    # slots (for --resume), and loading them here would drive the first REINFORCE updates with XE-scale moments.
+    keep_opt = optimizer_state is True or (optimizer_state == "auto" and any(k in raw for k in step_names))
+    if not keep_opt:
+        sd = {k: v for k, v in sd.items() if not (k.endswith("/Adam") or k.endswith("/Adam_1") or k in ("beta1_power", "beta2_power", "adam_t"))}
     loaded = model.store.load_state_dict(sd)
     st = model.store
     if restore_step and (st.restored_step is not None or st.restored_adam_t is not None):

@@ -17,7 +17,7 @@ import time
 import numpy as np
 
 from . import data, hostglue
-from .train_common import Config, DataParallel, epoch_batches, learning_rate, optimistic_restore, run_step, save_checkpoint
+from .train_common import Config, DataParallel, epoch_batches, learning_rate, optimistic_restore, run_step, save_checkpoint, save_checkpoint_checked
 
 
 def e2e_config(**kw):
@@ -73,8 +73,9 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
                 f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None}
+        ck = save_checkpoint_checked(model, cfg, epoch, step_name="Variable", chief=par.chief)       # (collective health check first)
         if par.chief:
-            entry["checkpoint"] = save_checkpoint(model, cfg, epoch, step_name="Variable")
+            entry["checkpoint"] = ck
             entry["cnn_checkpoint"] = save_cnn(trainer, cfg, epoch)
         history.append(entry)
         log(f"Epoch {epoch} is done: {entry}")

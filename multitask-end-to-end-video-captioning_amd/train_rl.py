@@ -24,7 +24,7 @@ import numpy as np
 
 from . import hostglue, reward
 from .train_common import (Config, Corpus, DataParallel, StepLog, epoch_batches, greedy_eval, learning_rate, lookahead, optimistic_restore,
-                           run_step, save_checkpoint)
+                           run_step, save_checkpoint, save_checkpoint_checked)
 
 
 def rl_config(**kw):
@@ -119,8 +119,9 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None, "r_minus_b": float(np.mean(adv)) if adv else None}
         if test_corpus is not None:
             _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, test_scorer, B, par)
+        ck = save_checkpoint_checked(model, cfg, epoch, step_name="g_step", chief=par.chief)
         if par.chief:
-            entry["checkpoint"] = save_checkpoint(model, cfg, epoch, step_name="g_step")
+            entry["checkpoint"] = ck
         history.append(entry)
         steplog.write(kind="epoch", **entry)
         log(f"Epoch {epoch} is done: {entry}")

@@ -16,7 +16,7 @@ import torch
 
 from . import hostglue, reward
 from .train_common import (Config, Corpus, DataParallel, StepLog, epoch_batches, greedy_eval, learning_rate, lookahead, optimistic_restore,
-                           run_step, save_checkpoint)
+                           run_step, save_checkpoint, save_checkpoint_checked)
 
 
 def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, model=None, log=print, resume=None):
@@ -81,8 +81,9 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None}
         if test_corpus is not None:
             _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, scorer, B, par)
+        ck = save_checkpoint_checked(model, cfg, epoch, step_name="Variable", chief=par.chief)      # tf_s2vt.py:441: the unnamed counter
         if par.chief:
-            entry["checkpoint"] = save_checkpoint(model, cfg, epoch, step_name="Variable")      # tf_s2vt.py:441: the unnamed counter
+            entry["checkpoint"] = ck
         history.append(entry)
         steplog.write(kind="epoch", **entry)
         log(f"Epoch {epoch} is done: {entry}")

@@ -59,7 +59,7 @@ def test_checkpoint_keeps_tf_names_adam_slots_and_step():
     b = M.ParamStore(shapes, torch.device("cpu"))
     loaded = b.load_state_dict(sd)
     assert b.restored_step == 7 and b.restored_adam_t == 7
-    assert len(loaded) == 3 * len(a.names) + 3                          # + global_step, g_step (the REINFORCE script's name), beta1_power
+    assert len(loaded) == 3 * len(a.names) + 4                          # + global_step, g_step (the REINFORCE script's name), beta1_power, adam_t
     # a REINFORCE run started from an XE checkpoint: Adam's slots and beta powers match by name, the unnamed counter
     # ('Variable', tf_s2vt.py:441) is a different variable from 'g_step' (reinforcement_multisampling_tf_s2vt.py:637)
     sdx = a.state_dict(global_step=12, adam_t=12, step_name="Variable")
@@ -142,3 +142,110 @@ def test_active_steps_counts_the_live_leading_steps():
     assert G.active_steps(np.zeros((2, 5), np.float32)) == 1
     assert G.active_steps(np.ones((2, 5), np.float32)) == 5
     assert G.active_steps(None) is None
+
+
+def test_adam_count_is_stored_outright_and_survives_a_denormal_beta_power():
+    """beta1_power = 0.9^(t+1) underflows fp32 past t ~ 800; the checkpoint states Adam's update count as an integer."""
+    import s2vt_amd
+    from s2vt_amd import model as M
+    shapes = M.param_shapes(8, 11, 4, 4)
+    a = M.ParamStore(shapes, torch.device("cpu"))
+    sd = a.state_dict(global_step=5000, adam_t=4321)
+    assert int(sd["adam_t"]) == 4321 and float(sd["beta1_power"]) == 0.0
+    b = M.ParamStore(shapes, torch.device("cpu"))
+    b.load_state_dict(sd)
+    assert b.restored_step == 5000 and b.restored_adam_t == 4321
+    # a TF-format dump stores the graph's counter as DT_INT32 (tf.Variable(0, trainable=False))
+    sd32 = a.state_dict(global_step=9, step_name="Variable", counter_dtype=np.int32)
+    assert sd32["Variable"].dtype == np.int32
+
+
+def test_restore_into_reinforce_drops_the_xe_runs_adam_state(tmp_path):
+    """`train_rl --restore <XE checkpoint>` -- the reference's XE saver holds the model variables only
+    (tf_s2vt.py:440), so its REINFORCE run starts Adam from zero moments; our XE checkpoints carry the slots for --resume and
+    the restore path must not load them.  A checkpoint of the REINFORCE driver itself ('g_step') keeps them."""
+    import s2vt_amd
+    from s2vt_amd import model as M, train_common as TC
+
+    class Stub:
+        def __init__(self):
+            self.store = M.ParamStore(M.param_shapes(8, 11, 4, 4), torch.device("cpu"))
+            self.global_step = self.adam_t = 0
+
+        def set_step(self, g, t=None):
+            self.global_step, self.adam_t = int(g), int(g if t is None else t)
+
+    src = Stub()
+    M.init_reference(src.store, seed=2)
+    src.store.m.uniform_(-1, 1); src.store.v.uniform_(0, 1)
+    xe = tmp_path / "xe.npz"
+    np.savez(xe, **src.store.state_dict(global_step=37, adam_t=37, step_name="Variable"))
+    dst = Stub()
+    loaded = TC.optimistic_restore(dst, str(xe), step_names=("g_step",))
+    assert all(torch.equal(src.store.p[n], dst.store.p[n]) for n in src.store.names)
+    assert float(dst.store.m.abs().max()) == 0.0 and float(dst.store.v.abs().max()) == 0.0      # fresh Adam
+    assert dst.global_step == 0 and dst.adam_t == 0 and not any(k.endswith("/Adam") for k in loaded)
+    rl = tmp_path / "rl.npz"
+    np.savez(rl, **src.store.state_dict(global_step=12, adam_t=12, step_name="g_step"))
+    dst2 = Stub()
+    TC.optimistic_restore(dst2, str(rl), step_names=("g_step",))
+    same_m = lambda a, b: all(torch.equal(a.store._view(a.store.m, n), b.store._view(b.store.m, n)) for n in a.store.names)
+    assert same_m(dst2, src) and dst2.global_step == 12 and dst2.adam_t == 12
+    dst3 = Stub()                                                                                  # --resume of the XE driver keeps everything
+    TC.optimistic_restore(dst3, str(xe))
+    assert same_m(dst3, src) and dst3.global_step == 37
+
+
+def test_run_step_retries_alone_but_never_inside_a_data_parallel_job():
+    """a persistent-recurrence fault is local to one rank, the step is collective: under world > 1 the driver must not
+    repeat the batch on its own (its all-reduces would pair with the peers' next batch) -- the exception propagates."""
+    import pytest
+    import s2vt_amd
+    from s2vt_amd import train_common as TC
+    from s2vt_amd._lib import S2VTChainTimeout
+
+    class Fake:
+        def __init__(self, world):
+            self.world_size, self.rank, self.calls, self.recovered = world, 1, 0, 0
+
+        def check_health(self):
+            pass
+
+        def recover(self):
+            self.recovered += 1
+            return 0, 1
+
+    class St:
+        loss = 1.5
+
+    def step(m):
+        def fn():
+            m.calls += 1
+            if m.calls == 1:
+                raise S2VTChainTimeout("starved")
+            return St()
+        return fn
+    solo = Fake(1)
+    st, loss = TC.run_step(solo, step(solo), log=lambda *_: None)
+    assert loss == 1.5 and solo.calls == 2 and solo.recovered == 1
+    dp2 = Fake(2)
+    with pytest.raises(S2VTChainTimeout):
+        TC.run_step(dp2, step(dp2), log=lambda *_: None)
+    assert dp2.calls == 1 and dp2.recovered == 0
+
+
+def test_untile_checks_host_feeds_on_the_host():
+    """a [N, ...] feed whose K blocks are NOT copies of one another is N distinct videos, not a tiling."""
+    import s2vt_amd
+    from s2vt_amd import model as M
+    m = M.Video_Caption_Generator(6, 11, 4, 4, 2, 0, 3, 4, device="cpu", multisample=3)
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((2, 3, 6)).astype(np.float32)
+    tiled = np.tile(base, (3, 1, 1))
+    v, B = m._untile(torch.as_tensor(tiled), 6, host=tiled)
+    assert B == 2 and torch.equal(v, torch.as_tensor(base))
+    distinct = rng.standard_normal((6, 3, 6)).astype(np.float32)
+    v, B = m._untile(torch.as_tensor(distinct), 6, host=distinct)
+    assert B == 6 and v.shape[0] == 6
+    v, B = m._untile(torch.as_tensor(distinct), 6)               # a device feed is taken at the feed contract's word
+    assert B == 2

@@ -80,7 +80,9 @@ def test_v1_table_round_trip(tmp_path, compress):
 
 def test_optimistic_restore_from_tensorflow_files(tmp_path):
     """reinforcement_multisampling_tf_s2vt.py:667: optimistic_restore(sess, '<dir>/batch_size64..._model-10') -- a checkpoint
-    FILE, matched by name and shape; Adam's slots and beta powers come along, a foreign counter name does not."""
+    FILE, matched by name and shape.  An XE checkpoint restored into a REINFORCE graph brings the model variables only (the
+    reference's XE saver, tf_s2vt.py:440, is created before the optimizer and holds no slots: Adam starts fresh); a foreign
+    counter name does not match; optimizer_state=True takes the slots anyway."""
     import torch
     from s2vt_amd import model as M, train_common as tc
 
@@ -102,10 +104,15 @@ def test_optimistic_restore_from_tensorflow_files(tmp_path):
     for path in (v2, v1):
         b = Stub(M.ParamStore(shapes, torch.device("cpu")))
         loaded = tc.optimistic_restore(b, path, step_names=("g_step",))           # a REINFORCE graph: its counter is 'g_step'
-        assert "s2vt/LSTM2/basic_lstm_cell/weights/Adam_1" in loaded and "Variable" not in loaded
-        assert b.global_step == 0 and b.adam_t == 12
+        assert "s2vt/LSTM2/basic_lstm_cell/weights" in loaded and "s2vt/LSTM2/basic_lstm_cell/weights/Adam_1" not in loaded and "Variable" not in loaded
+        assert b.global_step == 0 and b.adam_t == 0 and float(b.store.m.abs().max()) == 0.0
         for n in a.names:
-            assert torch.equal(a.p[n], b.store.p[n]) and torch.equal(a._view(a.m, n), b.store._view(b.store.m, n))
+            assert torch.equal(a.p[n], b.store.p[n])
+        b2 = Stub(M.ParamStore(shapes, torch.device("cpu")))
+        loaded = tc.optimistic_restore(b2, path, step_names=("g_step",), optimizer_state=True)
+        assert "s2vt/LSTM2/basic_lstm_cell/weights/Adam_1" in loaded and b2.global_step == 0 and b2.adam_t == 12
+        for n in a.names:
+            assert torch.equal(a._view(a.m, n), b2.store._view(b2.store.m, n))
         c = Stub(M.ParamStore(shapes, torch.device("cpu")))
         tc.optimistic_restore(c, path)                                            # an XE graph resuming: counter restored too
         assert c.global_step == 12 and c.adam_t == 12
