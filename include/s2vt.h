@@ -75,6 +75,9 @@ typedef struct s2vt_params {
 /* ---- library info / errors --------------------------------------------------------------- */
 int s2vt_version(void);
 int s2vt_last_hip_error(void);
+/* Up to 8 device buffers set to zero by ONE launch (4-byte aligned, byte counts multiples of 4): the gradient bucket and the
+ * other buffers a step must find zeroed -- each hipMemsetAsync / tensor-library fill is a ~5-20 us launch of its own. */
+int s2vt_zero_regions(void* const* ptrs, const size_t* bytes, int32_t count, s2vt_stream stream);
 const char* s2vt_error_string(int code);
 
 /* ---- launch profiler (measurement only; bench.py's roofline leg) ---------------------------------

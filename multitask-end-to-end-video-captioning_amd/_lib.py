@@ -63,6 +63,7 @@ _AP = C.POINTER(AttnParams)
 SIGNATURES = {
     "s2vt_version": (C.c_int, []),
     "s2vt_last_hip_error": (C.c_int, []),
+    "s2vt_zero_regions": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i32, _vp]),
     "s2vt_error_string": (C.c_char_p, [C.c_int]),
     "s2vt_prof_enable": (C.c_int, [C.c_int]),
     "s2vt_prof_filter": (C.c_int, [C.c_int, C.c_int]),

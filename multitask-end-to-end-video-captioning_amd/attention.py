@@ -167,7 +167,7 @@ class Attention_Caption_Generator:
             steps = max(1, min(Tc, int(active_steps)))
         c = self._loss_forward(video, caption, caption_mask, keep, steps, video_base)
         st = self.store
-        st.grad.zero_()
+        ops.zero_(st.grad)
         ops.attn_bptt_bwd(self.dims, st.params, st.grads, c["video"], c["dlogits"], c["ws"], c["steps"], c["reg"], self.m, keep, c["seed"],
                           c["vid"], c["sid"])
         gsum = dp.allreduce_bucket(st.grad, st.numel, c["msum"])                 # RCCL: one flat bucket + sum(mask) in its tail

@@ -56,6 +56,19 @@ __global__ void unpack_ids_kernel(const unsigned long long* packed, int32_t* ids
 extern "C" {
 
 int s2vt_version(void) { return 100; }
+
+int s2vt_zero_regions(void* const* ptrs, const size_t* bytes, int32_t count, s2vt_stream stream)
+{
+    if (count < 0 || count > 8 || (count && (!ptrs || !bytes))) return S2VT_E_BADARG;
+    ZeroList z;
+    for (int i = 0; i < count; ++i) {
+        if (bytes[i] & 3u) return S2VT_E_BADARG;
+        if (ptrs[i] && (reinterpret_cast<uintptr_t>(ptrs[i]) & 3u)) return S2VT_E_ALIGN;
+        z.add(ptrs[i], bytes[i]);
+    }
+    HIP_TRY(launch_zero_regions(z, S(stream)));
+    return S2VT_OK;
+}
 int s2vt_last_hip_error(void) { return g_last_hip.load(); }
 
 const char* s2vt_error_string(int code)
@@ -321,7 +334,11 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
     const int R = (K + (with_greedy ? 1 : 0)) * B;
     hipStream_t st = S(stream);
     const size_t BH = (size_t)B * H;
-    HIP_TRY(hipMemsetAsync(w.packed, 0, (size_t)Tc * R * kPickStride * 8, st));
+    {
+        ZeroList z;
+        z.add(w.packed, (size_t)Tc * R * kPickStride * 8);
+        HIP_TRY(launch_zero_regions(z, st));
+    }
     hipLaunchKernelGGL(sampler_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.vid, w.sid, B, K, R, video_base);
     hipLaunchKernelGGL(fill_i32_kernel, dim3((R + 255) / 256), dim3(256), 0, st, w.bos, 1, R);   // <bos> = 1
     HIP_TRY(hipGetLastError());

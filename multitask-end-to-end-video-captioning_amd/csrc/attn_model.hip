@@ -279,7 +279,11 @@ int s2vt_attn_teacher_forced_fwd(const s2vt_dims* d, const s2vt_attn_params* p, 
     // vocabulary logits (:143), rows t*B + b
     ASeg so = make_seg(w.Y, H, H, 0);
     HIP_TRY(store_call(&so, 1, p->embed_word_W, V, p->embed_word_b, logits, V, Tc * B, V, 0, -1, st));
-    if (alphas_out) HIP_TRY(hipMemcpyAsync(alphas_out, w.alpha, (size_t)Tc * Tv * B * 4, hipMemcpyDeviceToDevice, st));
+    if (alphas_out) {
+        CopyList cl;
+        if (cl.add(alphas_out, w.alpha, (size_t)Tc * Tv * B * 4)) HIP_TRY(launch_copy_regions(cl, st));
+        else HIP_TRY(hipMemcpyAsync(alphas_out, w.alpha, (size_t)Tc * Tv * B * 4, hipMemcpyDeviceToDevice, st));
+    }
     return S2VT_OK;
 }
 
@@ -459,7 +463,11 @@ int s2vt_attn_decode_greedy(const s2vt_dims* d, const s2vt_attn_params* p, const
     }
     hipLaunchKernelGGL(attn_unpack_ids_kernel, dim3((B * Tc + 255) / 256), dim3(256), 0, st, w.packed, ids_out, B, Tc, kPickStride);
     HIP_TRY(hipGetLastError());
-    if (alphas_out) HIP_TRY(hipMemcpyAsync(alphas_out, w.alpha, (size_t)Tc * Tv * B * 4, hipMemcpyDeviceToDevice, st));
+    if (alphas_out) {
+        CopyList cl;
+        if (cl.add(alphas_out, w.alpha, (size_t)Tc * Tv * B * 4)) HIP_TRY(launch_copy_regions(cl, st));
+        else HIP_TRY(hipMemcpyAsync(alphas_out, w.alpha, (size_t)Tc * Tv * B * 4, hipMemcpyDeviceToDevice, st));
+    }
     return S2VT_OK;
 }
 

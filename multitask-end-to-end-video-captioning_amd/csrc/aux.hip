@@ -590,6 +590,30 @@ hipError_t launch_zero_regions(const ZeroList& z, hipStream_t st)
     return hipGetLastError();
 }
 
+// Several device-to-device copies in ONE launch of a library kernel (the teacher-forced pass taking LSTM1's trajectory from the
+// sampler pass was three hipMemcpyAsync = three runtime blit kernels per step).  16-byte aligned regions, sizes in 16-byte words.
+__global__ __launch_bounds__(256) void copy_regions_kernel(const CopyList c)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int r = 0; r < c.count; ++r) {
+        const uint4* __restrict__ s = c.src[r];
+        uint4* __restrict__ d = c.dst[r];
+        const size_t n = c.n16[r];
+        for (size_t i = first; i < n; i += stride) d[i] = s[i];
+    }
+}
+
+hipError_t launch_copy_regions(const CopyList& c, hipStream_t st)
+{
+    size_t most = 0;
+    for (int r = 0; r < c.count; ++r) most = c.n16[r] > most ? c.n16[r] : most;
+    if (c.count <= 0 || most == 0) return hipSuccess;
+    const size_t want = (most + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(copy_regions_kernel, dim3(blocks), dim3(256), 0, st, c);
+    return hipGetLastError();
+}
+
 hipError_t launch_sum_slabs(float* dst, const float* slabs, int nslab, size_t stride, size_t n, hipStream_t st)
 {
     if (n == 0 || nslab <= 0) return hipSuccess;

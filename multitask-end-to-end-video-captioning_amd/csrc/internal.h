@@ -70,6 +70,19 @@ struct ZeroList {
     void add(void* ptr, size_t bytes) { if (ptr && bytes) { p[count] = static_cast<uint32_t*>(ptr); n[count] = bytes / 4; ++count; } }
 };
 hipError_t launch_zero_regions(const ZeroList& z, hipStream_t st);
+// up to 4 device-to-device copies by one launch (16-byte aligned pointers, byte counts multiples of 16; anything else: false)
+struct CopyList {
+    uint4* dst[4]; const uint4* src[4]; size_t n16[4]; int count;
+    CopyList() : count(0) {}
+    bool add(void* d, const void* s, size_t bytes)
+    {
+        if (!bytes) return true;
+        if (count >= 4 || ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s) | bytes) & 15u)) return false;
+        dst[count] = static_cast<uint4*>(d); src[count] = static_cast<const uint4*>(s); n16[count] = bytes / 16; ++count;
+        return true;
+    }
+};
+hipError_t launch_copy_regions(const CopyList& c, hipStream_t st);
 hipError_t launch_gather_rows(const float* src, int ld, const int32_t* idx, int R, int C, float* dst, int ldd, hipStream_t st);   // dst[r,:] = src[idx[r],:]
 hipError_t launch_scatter_rows(const float* src, int ld, const int32_t* idx, int R, int C, float* dst, int ldd, hipStream_t st);  // dst[idx[r],:] = src[r,:]
 hipError_t launch_gather_i32(const int32_t* src, const int32_t* idx, int R, int32_t* dst, hipStream_t st);

@@ -343,9 +343,14 @@ int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const
         SampleWs sw;
         carve_sample(sc, d, B, sampler_rows, &sw);
         if (!sc.ok() || sampler_rows <= 0) return S2VT_E_WORKSPACE;
-        HIP_TRY(hipMemcpyAsync(w.C1, sw.c1, (size_t)(T + 1) * BH * 4, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(w.H1, sw.h1, (size_t)(T + 1) * BH * 4, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(w.G1, sw.G1, (size_t)T * 4 * BH * 4, hipMemcpyDeviceToDevice, st));
+        CopyList cl;
+        if (cl.add(w.C1, sw.c1, (size_t)(T + 1) * BH * 4) && cl.add(w.H1, sw.h1, (size_t)(T + 1) * BH * 4) && cl.add(w.G1, sw.G1, (size_t)T * 4 * BH * 4)) {
+            HIP_TRY(launch_copy_regions(cl, st));                                  // one library launch
+        } else {                                                                   // (B * H not a multiple of 4: the runtime's copies)
+            HIP_TRY(hipMemcpyAsync(w.C1, sw.c1, (size_t)(T + 1) * BH * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(w.H1, sw.h1, (size_t)(T + 1) * BH * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(w.G1, sw.G1, (size_t)T * 4 * BH * 4, hipMemcpyDeviceToDevice, st));
+        }
     } else {
         {
             ASeg sx = make_seg(w.emb, E, E, 0);

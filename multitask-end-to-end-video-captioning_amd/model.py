@@ -482,7 +482,7 @@ class Video_Caption_Generator:
         video, N, dlogits, ws, keep, seed, vid, sid, steps, live = self._ctx
         st = self.store
         if not accumulate:
-            (st.grad[:st.numel] if keep_tail else st.grad).zero_()     # keep_tail: sum(mask) already sits in the tail slot (ops.caption_mask)
+            ops.zero_(st.grad[:st.numel] if keep_tail else st.grad)    # keep_tail: sum(mask) already sits in the tail slot (ops.caption_mask)
         self._pending = []
         self._early = None
         if dp.active() and overlap:

@@ -200,6 +200,18 @@ def frame_embed_fwd(dims: Dims, params: Params, video):
     return emb
 
 
+def zero_(*tensors):
+    """Zero up to 8 device tensors (contiguous) with ONE library launch (s2vt_zero_regions)."""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    for i in range(0, len(ts), 8):
+        grp = ts[i:i + 8]
+        for t in grp:
+            assert t.is_cuda and t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0
+        ptrs = (C.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+        nb = (C.c_size_t * len(grp))(*[t.numel() * t.element_size() for t in grp])
+        check(lib().s2vt_zero_regions(ptrs, nb, len(grp), _stream()), "s2vt_zero_regions")
+
+
 _ws_cache = {}
 
 
