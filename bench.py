@@ -113,6 +113,8 @@ def launch_ranks(args):
            str(args.warmup), "--workload", args.workload]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.batch_per_gpu > 0:
+        cmd += ["--batch-per-gpu", str(args.batch_per_gpu)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in r.stdout.splitlines():
@@ -326,9 +328,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="rl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="functional tests only (several ranks on one GPU): overrides the workload's "
+                    "B per GPU; the line then carries config.batch_per_gpu_override and is NOT the BASELINE configuration")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     B, K = wl["B"], wl["K"]
+    if args.batch_per_gpu > 0:
+        B = args.batch_per_gpu
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -459,10 +465,20 @@ def main():
                 "allreduce_ms": round(ar_ms / max(args.steps, 1), 4),                            # per step, rank 0's stream, HIP events
                 "allreduce_brackets_per_step": round(ar_n / max(args.steps, 1), 2),
                 "gradient_bucket_bytes": int(mdl.store.grad.numel() * 4)})
+            # reading aids for the first real multi-GPU line: the rate the bucket moved at (algorithm bandwidth: bucket bytes / time the
+            # step's stream spent on or behind the exchange) and what the step would take with the exchange fully hidden behind the
+            # backward (S2VT_DP_OVERLAP=1 is the knob; this is a projection from THIS run's numbers, not a measurement)
+            ar_s = ar_ms / max(args.steps, 1) / 1e3
+            out["config"].update({
+                "allreduce_bytes_per_s": round(mdl.store.grad.numel() * 4 / ar_s, 1) if ar_s > 0 else None,
+                "ms_per_step_if_exchange_hidden": round(max(ms_step - ar_s * 1e3, ar_s * 1e3), 3),
+                "value_if_exchange_hidden": round(wl["tokens"](B, K) * world / (max(ms_step - ar_s * 1e3, ar_s * 1e3) / 1e3), 1)})
         if "cnn_params" in info:
             out["config"]["cnn_params"] = info["cnn_params"]
             out["config"]["note"] = ("CNN-bound step: the convolutions run on MIOpen through PyTorch (not a kernel of this library); "
                                      "the roofline object describes this library's dominant kernel only")
+        if args.batch_per_gpu > 0:
+            out["config"]["batch_per_gpu_override"] = B
         if "active_steps" in info:
             out["config"]["unrolled_caption_steps"] = info["active_steps"]      # of TC: behind the longest caption all is padding
         if "live_fraction" in info:

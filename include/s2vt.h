@@ -513,6 +513,11 @@ int s2vt_chain_timeouts(void);
  *     last applied update. */
 int s2vt_chain_fault(void);
 int s2vt_chain_ack(int disable_persistent);
+/* s2vt_chain_hold(1) ... s2vt_chain_hold(0) (nestable): while held, every recurrence whose form the library chooses takes its
+ * per-step launches (same bits, ~5 % slower) instead of the persistent grid.  For callers that have OTHER kernels in flight on
+ * the same GPU beside the library's stream -- an asynchronous RCCL all-reduce of a gradient slice (model.backward(overlap=True)):
+ * a persistent grid needs every workgroup co-resident and must not be started while part of the chip is taken. */
+int s2vt_chain_hold(int on);
 
 /* In-place SUM all-reduce of the flat gradient bucket over an existing RCCL communicator (ncclComm_t as
  * void*), on `stream` -- the exchange step of SURVEY.md section 8(e) for C/C++ hosts (Python hosts use

@@ -134,6 +134,7 @@ SIGNATURES = {
     "s2vt_chain_timeouts": (C.c_int, []),
     "s2vt_chain_fault": (C.c_int, []),
     "s2vt_chain_ack": (C.c_int, [C.c_int]),
+    "s2vt_chain_hold": (C.c_int, [C.c_int]),
     "s2vt_adam_tf_guarded": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _i64, _f32, _f32, _f32, _vp, _vp]),
     "s2vt_allreduce_grads": (C.c_int, [_vp, _i64, _vp, _vp]),
     "s2vt_set_rccl_allreduce": (C.c_int, [_vp]),

@@ -620,6 +620,7 @@ hipStream_t g_last_stream = nullptr;
 int g_last_device = -1;
 std::atomic<unsigned> g_acked{0};          // timeouts acknowledged so far (chain_ack)
 std::atomic<bool> g_disabled{false};       // chain_ack(disable): per-step launches from here on
+std::atomic<int> g_hold{0};                // chain_hold(): per-step launches while > 0 (a collective's kernels are in flight beside us)
 
 int chain_lds_bytes(const ChainCfg& c)
 {
@@ -715,7 +716,7 @@ static int chain_max_rows()
 bool chain_eligible(int M, int H)
 {
     static const bool off = [] { const char* e = getenv("S2VT_CHAIN"); return e && e[0] == '0'; }();
-    if (off || g_disabled.load(std::memory_order_relaxed)) return false;
+    if (off || chain_persistent_disabled()) return false;
     DevState* d = dev_state();
     if (!d || d->num_cus <= 0) return false;
     if (!(M >= 1 && M <= chain_max_rows() && H >= 4 && (H & 3) == 0 && H <= 1024 && H / 4 <= d->num_cus)) return false;
@@ -811,7 +812,8 @@ bool chain_host(ChainHost* out)
     out->num_cus = d->num_cus; out->device = dev; out->status_dev = g_status_dev; out->fault = d->fault; out->spin_limit = spin_limit();
     return d->num_cus > 0;
 }
-bool chain_persistent_disabled() { return g_disabled.load(std::memory_order_relaxed); }
+bool chain_persistent_disabled() { return g_disabled.load(std::memory_order_relaxed) || g_hold.load(std::memory_order_relaxed) > 0; }
+void chain_hold(bool on) { if (on) g_hold.fetch_add(1, std::memory_order_relaxed); else if (g_hold.load(std::memory_order_relaxed) > 0) g_hold.fetch_sub(1, std::memory_order_relaxed); }
 ChainLaunchOrder::ChainLaunchOrder() { g_launch_mu.lock(); }
 ChainLaunchOrder::~ChainLaunchOrder() { g_launch_mu.unlock(); }
 hipError_t ChainLaunchOrder::before(hipStream_t st, int dev)

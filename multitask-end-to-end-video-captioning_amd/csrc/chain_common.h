@@ -110,7 +110,8 @@ struct ChainHost {
     unsigned spin_limit;
 };
 bool chain_host(ChainHost* out);                 // false: unavailable (no device state) or switched off (S2VT_CHAIN=0 handled by the callers' own knobs; chain_ack(disable))
-bool chain_persistent_disabled();                // chain_ack(disable) has switched every persistent form off
+bool chain_persistent_disabled();                // chain_ack(disable) has switched every persistent form off, or a hold is in force
+void chain_hold(bool on);                        // nestable: while held, every auto-selected recurrence takes its per-step form (same bits)
 // One persistent grid at a time per process: lock, order `st` behind the previous persistent launch (other stream / device), and
 // after the launch record the event the next one will wait for.
 struct ChainLaunchOrder {

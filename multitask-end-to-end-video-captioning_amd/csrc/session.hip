@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include "api_util.h"
+#include "chain_common.h"
 
 using namespace s2vt_api;
 
@@ -289,6 +290,12 @@ int s2vt_lstm_recurrence_fwd(const float* W, int32_t kw0, const float* b, const 
 int s2vt_chain_timeouts(void) { return (int)chain_timeouts(); }
 
 int s2vt_chain_fault(void) { return chain_fault() ? 1 : 0; }
+
+int s2vt_chain_hold(int on)
+{
+    chain_hold(on != 0);
+    return S2VT_OK;
+}
 
 int s2vt_chain_ack(int disable_persistent)
 {

@@ -492,12 +492,16 @@ class Video_Caption_Generator:
             ops.bptt_bwd(*args, phase=1, steps=steps, live=live)
             lo1, hi1 = span("embed_word_W", "embed_word_b")
             self._pending.append(dp.allreduce_async(st.grad[lo1:hi1]))
-            ops.bptt_bwd(*args, phase=3, steps=steps, live=live)
-            lo2, hi2 = span("lstm2_W", "lstm2_W")
-            assert hi2 == lo1, "bucket layout: lstm2_W sits right below embed_word_W"
-            self._pending.append(dp.allreduce_async(st.grad[lo2:hi2]))
-            self._early = (lo2, hi1)                       # [lo2, hi1) is already on its way
-            ops.bptt_bwd(*args, phase=4, steps=steps, live=live)
+            # From here RCCL's kernels run on the communicator's stream beside ours.  A persistent recurrence needs ~every CU
+            # co-resident (csrc/chain.hip) and must not be started into a chip that is partly taken: while a slice is in
+            # flight the two backward recurrences take their per-step form (same bits; ops.chain_hold).
+            with ops.chain_hold():
+                ops.bptt_bwd(*args, phase=3, steps=steps, live=live)
+                lo2, hi2 = span("lstm2_W", "lstm2_W")
+                assert hi2 == lo1, "bucket layout: lstm2_W sits right below embed_word_W"
+                self._pending.append(dp.allreduce_async(st.grad[lo2:hi2]))
+                self._early = (lo2, hi1)                       # [lo2, hi1) is already on its way
+                ops.bptt_bwd(*args, phase=4, steps=steps, live=live)
         else:
             ops.bptt_bwd(self.dims, st.params, st.grads, video, N, dlogits, ws, keep, seed, vid, sid, steps=steps, live=live)
 

@@ -390,6 +390,19 @@ def chain_ack(disable_persistent: bool = True):
     check(lib().s2vt_chain_ack(1 if disable_persistent else 0), "s2vt_chain_ack")
 
 
+class chain_hold:
+    """Context manager: recurrences launched inside take their per-step form (s2vt_chain_hold) -- for the stretch of a step
+    during which another stream's kernels (an asynchronous all-reduce) share the GPU with the library's stream."""
+
+    def __enter__(self):
+        check(lib().s2vt_chain_hold(1), "s2vt_chain_hold")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().s2vt_chain_hold(0), "s2vt_chain_hold")
+        return False
+
+
 def prof_enable(on: bool):
     check(lib().s2vt_prof_enable(1 if on else 0), "s2vt_prof_enable")
 

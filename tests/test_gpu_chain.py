@@ -332,3 +332,42 @@ def test_two_part_form_above_256_rows_and_unaligned_weights(gpu):
     r = subprocess.run([sys.executable, "-c", CHILD_FORMS], env=dict(os.environ, S2VT_ROOT=root, S2VT_CHAIN4="0", S2VT_BCHAIN4="0"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "child ok" in r.stdout, f"rc={r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+
+
+def test_chain_hold_takes_the_per_step_form_and_the_same_bits(gpu):
+    """ops.chain_hold(): while another stream's kernels share the GPU (an asynchronous all-reduce of a gradient slice,
+    model.backward(overlap=True)), auto-selected recurrences must not start a persistent grid.  Inside the hold the launch profiler
+    sees no persistent kernel (classes 5 / 6), outside it does; states, gates and dZ are bit-identical / equal either way, also with a
+    second stream keeping the chip busy (standing in for RCCL's kernels)."""
+    import torch
+    ops = gpu
+    torch.manual_seed(3)
+    M_, H, T = 64, 1000, 6
+    W = (torch.rand(H + 8, 4 * H, device="cuda") * 2 - 1) * 0.1
+    b = torch.zeros(4 * H, device="cuda")
+    h0 = torch.zeros(M_, H, device="cuda"); c0 = torch.zeros(M_, H, device="cuda")
+    cin = (torch.rand(T, M_, 4 * H, device="cuda") * 2 - 1)
+
+    def run():
+        ops.prof_filter(-1, -1); ops.prof_enable(True)
+        Ch, Hh, gates, _ = ops.lstm_recurrence_fwd(W, 8, b, h0, c0, T, cinit=cin, cinit_steps=T)
+        dZ = ops.lstm_recurrence_bwd(W, 8, gates, Ch, dext=torch.ones(T, M_, H, device="cuda"))
+        torch.cuda.synchronize()
+        rows = ops.prof_collect(); ops.prof_enable(False)
+        return Ch, Hh, gates, dZ, {r["kernel_class"] for r in rows}
+    free = run()
+    hog = torch.cuda.Stream()
+    big = torch.rand(4096, 4096, device="cuda")
+    with ops.chain_hold():
+        with torch.cuda.stream(hog):
+            for _ in range(20):
+                big = (big @ big).clamp_(-1, 1)            # a few ms of every CU busy on another stream
+        held = run()
+    torch.cuda.synchronize()
+    again = run()
+    assert 5 in free[4] and 6 in free[4] and 5 in again[4], (free[4], again[4])      # the persistent forms, before and after
+    assert 5 not in held[4] and 6 not in held[4], held[4]                            # ... and not while held
+    for a, c in zip(free[:3], held[:3]):
+        assert torch.equal(a, c)
+    assert float((free[3] - held[3]).abs().max()) <= 2e-5 * float(free[3].abs().max())
+    assert ops.chain_timeouts() == 0

@@ -142,3 +142,108 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert cfg["replica_max_abs_diff"] == 0.0
     assert cfg["allreduce_ms"] > 0.0 and cfg["persistent_recurrence_timeouts"] == 0
     assert "cpu_baseline" not in out                       # rank 0 at N = 1 only
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world size 8 (the node the metric is quoted on), functionally, on ONE GPU over gloo: 8 ranks x 8 videos must land where
+# 1 rank x 64 videos does -- shard_range(64, r, 8), global video indices in the noise counters, Q1's per-step column sums
+# all-reduced, sum(mask) riding in the bucket's tail, identical clip + Adam on every rank.
+# ---------------------------------------------------------------------------------------------------------------------
+BG8 = 64
+
+
+def _problem8():
+    rng = np.random.default_rng(8)
+    video = np.abs(rng.standard_normal((BG8, 3, 24)) * 0.5).astype(np.float32)
+    cap = rng.integers(1, 97, (K, BG8, 6)).astype(np.int32)
+    ln = rng.integers(1, 6, (K, BG8))
+    for k in range(K):
+        for j in range(BG8):
+            cap[k, j, ln[k, j]:] = 0
+    r = rng.random((K, BG8)).astype(np.float32) * 2; b = rng.random(BG8).astype(np.float32) * 2
+    gt = rng.integers(1, 97, (BG8, 6)).astype(np.int32)
+    gl = rng.integers(1, 6, BG8)
+    for j in range(BG8):
+        gt[j, gl[j]:] = 0
+    return video, cap, r, b, gt
+
+
+def _run8(rank, world, port, out, kind):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import s2vt_amd
+    from s2vt_amd import dist as dp, hostglue, model as M
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), S2VT_CHAIN="0", S2VT_BCHAIN="0")   # ranks share the GPU: per-step launches
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    video, cap, r, b, gt = _problem8()
+    lo, hi = dp.shard_range(BG8, rank, world)
+    per = hi - lo
+    if kind == "attention":
+        from s2vt_amd import attention as A
+        mdl = A.Attention_Caption_Generator(24, 97, 20, per, 3, 6, 0.9, seed=9)
+        mdl.world_size, mdl.rank = world, rank
+        mask = hostglue.masks_from_ids(gt[lo:hi])
+        for step in range(2):
+            mdl.xe_update(video[lo:hi], gt[lo:hi], mask, lr=1e-2, video_base=lo, active_steps=None)
+    else:
+        mdl = M.Video_Caption_Generator(24, 97, 12, 20, per, 0, 3, 6, dropout_rate=0.9, seed=9)
+        mdl.world_size, mdl.rank = world, rank
+        c = cap[:, lo:hi].reshape(K * per, -1)
+        mask = hostglue.masks_from_ids(c)
+        for step in range(2):
+            if kind == "rl":
+                mdl.reinforce_update(video[lo:hi], c, mask, r[:, lo:hi].reshape(-1), np.tile(b[lo:hi], K), lr=1e-2, clip_norm=5.0, video_base=lo)
+            else:     # XE with Q1: the batch MEAN of a step's cross entropy is over the GLOBAL batch (column sums all-reduced)
+                mdl.xe_update(video[lo:hi], gt[lo:hi], hostglue.masks_from_ids(gt[lo:hi]), lr=1e-2, q1=True, video_base=lo, active_steps=None)
+    torch.cuda.synchronize()
+    drift = dp.replica_drift(mdl.store.theta)
+    assert drift == 0.0, drift
+    if rank == 0:
+        np.save(out, mdl.store.theta.cpu().numpy())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["rl", "xe_q1", "attention"])
+def test_eight_ranks_equal_one_rank(tmp_path, kind):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import torch.multiprocessing as mp
+    one, eight = str(tmp_path / "one.npy"), str(tmp_path / "eight.npy")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_run8, args=(0, 1, 0, one, kind)); p.start(); p.join(600); assert p.exitcode == 0
+    port = _free_port()
+    ps = [ctx.Process(target=_run8, args=(rk, 8, port, eight, kind)) for rk in range(8)]
+    [q.start() for q in ps]; [q.join(900) for q in ps]
+    assert all(q.exitcode == 0 for q in ps), [q.exitcode for q in ps]
+    a, b = np.load(one), np.load(eight)
+    assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max())
+
+
+def test_bench_gpus_8_functional_line():
+    """`python bench.py --gpus 8` end to end on one GPU (gloo, B = 8 per rank through the functional-test knob): 8 ranks started by
+    bench.py itself, n_gpus 8, global batch 64, replica drift exactly 0.0, the exchange timed, the reading aids of the N > 1 line."""
+    import json
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    nccl = torch.cuda.device_count() >= 8
+    env["S2VT_DIST_BACKEND"] = "nccl" if nccl else "gloo"
+    for wl, gb in (("rl", 64), ("xe", 64)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", wl,
+                            "--batch-per-gpu", "8"], env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        cfg = out["config"]
+        assert out["n_gpus"] == 8 and cfg["parallelism"] == "dp8" and cfg["global_batch"] == gb and cfg["batch_per_gpu_override"] == 8
+        assert cfg["replica_max_abs_diff"] == 0.0 and cfg["persistent_recurrence_timeouts"] == 0
+        assert cfg["allreduce_ms"] > 0.0 and cfg["allreduce_bytes_per_s"] > 0 and cfg["ms_per_step_if_exchange_hidden"] <= out["ms_per_step"]
+        assert np.isfinite(cfg["loss"])

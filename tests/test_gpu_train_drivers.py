@@ -129,10 +129,14 @@ def test_checkpoint_resume_continues_adam_and_counters(tmp_path):
     d.store.load_state_dict({k: v for k, v in b.store.state_dict().items()})
     step(d)
     assert np.abs(ta - d.store.theta.cpu().numpy()).max() > 1e-3
-    # a REINFORCE run started from this XE checkpoint: slots + Adam's count restored, the staircase starts at 0 (:637 'g_step')
+    # a REINFORCE run started from this XE checkpoint: the model variables only -- the reference's XE saver (tf_s2vt.py:440) holds no
+    # optimizer slots, so Adam starts fresh and the staircase at 0 (:637 'g_step'); optimizer_state=True takes the slots anyway
     e = make()
     tc.optimistic_restore(e, path, step_names=("g_step",))
-    assert e.global_step == 0 and e.adam_t == 2
+    assert e.global_step == 0 and e.adam_t == 0 and float(e.store.m.abs().max()) == 0.0 and torch.equal(e.store.theta, b.store.theta)
+    e2 = make()
+    tc.optimistic_restore(e2, path, step_names=("g_step",), optimizer_state=True)
+    assert e2.global_step == 0 and e2.adam_t == 2 and torch.equal(e2.store.m, b.store.m)
     # the same through TensorFlow checkpoint FILES (V2 bundle written by save_checkpoint(checkpoint_format="tf"), tfckpt.py)
     cfg_tf = tc.Config(model_path=str(tmp_path / "mtf"), model_name="ck", decay_steps=2, start_learning_rate=1e-2, checkpoint_format="tf")
     prefix = tc.save_checkpoint(b, cfg_tf, 0, step_name="Variable")
