@@ -143,6 +143,7 @@ struct AttnWs {
     float *dY, *dcat, *dZ3, *dxs, *dqs, *dc, *dhWa, *dEmb, *dPt, *dVtt, *dEv;
     float* bslab; size_t bslab_floats;    // split-K slabs of the batched data-gradient products
     unsigned long long* packed;    // greedy picks [Tc][B][kPickStride]
+    float* aimg; unsigned* async_; // persistent forward recurrence (attn_chain.hip): fragment images, hand-off counters
 };
 
 size_t carve_attn(Carver& c, const s2vt_dims* d, int B, AttnWs* out)
@@ -173,6 +174,7 @@ size_t carve_attn(Carver& c, const s2vt_dims* d, int B, AttnWs* out)
         w.bslab_floats = need;
     }
     w.packed = c.take<unsigned long long>(Tc * b * kPickStride);
+    w.aimg = c.take<float>(attn_chain_scratch_floats((int)H)); w.async_ = c.take<unsigned>(kAttnChainSyncBytes / 4);
     if (out) *out = w;
     return c.off;
 }
@@ -237,6 +239,7 @@ int s2vt_attn_teacher_forced_fwd(const s2vt_dims* d, const s2vt_attn_params* p, 
     if (!(keep > 0.0f) || (keep < 1.0f && (!video_id || !sample_id))) return S2VT_E_BADARG;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
     if (caption_steps < 1 || caption_steps > d->n_caption_lstm_step) return S2VT_E_BADARG;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
     const int H = d->lstm_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = caption_steps;
     Carver c(workspace, workspace_bytes);
     AttnWs w;
@@ -260,12 +263,28 @@ int s2vt_attn_teacher_forced_fwd(const s2vt_dims* d, const s2vt_attn_params* p, 
         HIP_TRY(store_call(&se, 1, p->lstm3_W, 4 * H, nullptr, w.G3 + 4 * BH, 4 * H, (Tc - 1) * B, 4 * H, 0, -1, st));
     }
     NoiseIds ids{video_id, sample_id, seed};
-    for (int t = 0; t < Tc; ++t) {
-        HIP_TRY(attn_step(p, w, t, Tv, B, H, w.O3 + t * BH, st));                                     // (:113-128)
-        // LSTM3 (:131): the chain continues from the hoisted partial with the recurrent rows, then the context rows
-        ASeg s3[2] = {make_seg(w.H3 + t * BH, H, H, 2 * H), make_seg(w.ctx + t * BH, H, H, 0)};
-        HIP_TRY(lstm_call(s3, 2, p->lstm3_W, p->lstm3_b, w.C3 + t * BH, 0, w.C3 + (t + 1) * BH, w.H3 + (t + 1) * BH, w.O3 + (t + 1) * BH,
-                          w.G3 + (size_t)t * 4 * BH, B, H, keep, ids, kDropCode3 + (uint32_t)t, -1, st, w.G3 + (size_t)t * 4 * BH, 4 * H, 0));
+    if (attn_chain_eligible(B, H, Tv) && !chain_fault() && !(reinterpret_cast<uintptr_t>(p->lstm3_W) & 15) && !(reinterpret_cast<uintptr_t>(p->embed_att_Wa) & 15)) {
+        // the whole recurrence -- query projection, score / softmax / context, LSTM3, all Tc steps -- in ONE persistent launch
+        AttnChainLaunch a;
+        std::memset(&a, 0, sizeof(a));
+        a.W3 = p->lstm3_W; a.ldw = 4 * H; a.b3 = p->lstm3_b;
+        a.cinit = w.G3; a.cinit_tstride = (size_t)4 * BH; a.ldcinit = 4 * H;
+        a.C = w.C3; a.Hh = w.H3; a.Out = w.O3; a.state_tstride = BH; a.gates = w.G3; a.gates_tstride = (size_t)4 * BH;
+        a.Wa = p->embed_att_Wa; a.ldwa = H; a.P = w.P; a.Vt = w.Vt; a.w = p->embed_att_w;
+        a.hWa = w.hWa; a.hwa_tstride = BH; a.alpha = w.alpha; a.asum = w.asum; a.ctx = w.ctx;
+        a.B = B; a.H = H; a.T = Tc; a.Tv = Tv;
+        a.keep = keep; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code0 = kDropCode3;
+        a.video_id = video_id; a.sample_id = sample_id;
+        a.img = w.aimg; a.sync = w.async_;
+        HIP_TRY(launch_attn_chain(a, st));
+    } else {
+        for (int t = 0; t < Tc; ++t) {
+            HIP_TRY(attn_step(p, w, t, Tv, B, H, w.O3 + t * BH, st));                                     // (:113-128)
+            // LSTM3 (:131): the chain continues from the hoisted partial with the recurrent rows, then the context rows
+            ASeg s3[2] = {make_seg(w.H3 + t * BH, H, H, 2 * H), make_seg(w.ctx + t * BH, H, H, 0)};
+            HIP_TRY(lstm_call(s3, 2, p->lstm3_W, p->lstm3_b, w.C3 + t * BH, 0, w.C3 + (t + 1) * BH, w.H3 + (t + 1) * BH, w.O3 + (t + 1) * BH,
+                              w.G3 + (size_t)t * 4 * BH, B, H, keep, ids, kDropCode3 + (uint32_t)t, -1, st, w.G3 + (size_t)t * 4 * BH, 4 * H, 0));
+        }
     }
     // output layer for all steps at once (:134): chain blocks [embed ; atten ; output1]; step 0 has no word
     {

@@ -206,6 +206,25 @@ struct AttnBwdArgs {
 };
 hipError_t launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st);
 
+// ---- the attention captioner's whole forward recurrence in one persistent launch (attn_chain.hip)
+struct AttnChainLaunch {
+    const float* W3; int ldw; const float* b3;          // LSTM3 [3H, 4H] (rows [0,H) context, [H,2H) embedding -- hoisted by the caller --, [2H,3H) h)
+    const float* cinit; size_t cinit_tstride; int ldcinit;   // the hoisted embedding partial of step t (NULL = none)
+    float* C; float* Hh; float* Out; size_t state_tstride;   // histories [T+1][B][H]: step t writes slot t + 1 (slot 0 = the zero state, not touched)
+    float* gates; size_t gates_tstride;                 // [T][B][4H] (may alias cinit)
+    const float* Wa; int ldwa; const float* P; const float* Vt; const float* w;
+    float* hWa; size_t hwa_tstride;                     // [T][B][H], slots 1 .. T-1 written
+    float* alpha; float* asum; float* ctx;              // [T][Tv][B], [T][B], [T][B][H]
+    int B, H, T, Tv;
+    float keep; uint32_t seed_lo, seed_hi, drop_code0; const int32_t* video_id; const int32_t* sample_id;
+    float* img;                                         // attn_chain_scratch_floats(H) floats, 16-byte aligned
+    unsigned* sync;                                     // kAttnChainSyncBytes
+};
+constexpr size_t kAttnChainSyncBytes = kChainSyncBytes + 256;
+bool attn_chain_eligible(int B, int H, int Tv);       // the persistent form serves this shape on this device (S2VT_ACHAIN != 0, no hold / fault)
+size_t attn_chain_scratch_floats(int H);
+hipError_t launch_attn_chain(const AttnChainLaunch& a, hipStream_t st);
+
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.
 struct NnBwdArgs {
