@@ -1,0 +1,450 @@
+// attn_chain_bwd.hip -- back-propagation through the temporal-attention captioner's recurrence (tf.gradients through
+// original_attention.py:109-135) in ONE persistent launch.  Iteration t = T-1 .. 0:
+//     (P) dout_t = d(output layer)[t] + dq_{t+1};  dh_t = dropout'(dout_t) + dh_rec;  BasicLSTMCell backward -> dz_t, dc
+//     (M) [dh_rec | dctx_t] = dz_t @ [W3[2H:3H] ; W3[0:H]]^T            (K = 4H: one gate's quarter per workgroup, 4-workgroup exchange)
+//     (A) attention backward of step t on dctx_t + d(output layer)'s context block -> dhWa_t, dP +=, dV +=, dw +=  (one batch row per workgroup)
+//     (Q) dq_t = dhWa_t @ Wa^T                                         (gradient w.r.t. out_{t-1} through step t's query)
+// As launches this was four kernels and ~70 us per step (a pointwise launch, two skinny split-K products, the attention
+// backward).  Here it is chain_bwd.hip's construction with the attention phases added:
+//   * workgroup (j, g) owns 16 hidden units and gate g's quarter of the reduction of BOTH blocks of (M): its [H x 16] slices
+//     W3[2H + 16j .., gH .. gH+H) and W3[16j .., gH .. gH+H) sit in LDS (2 x 64 KB) in B-fragment order; dz_t crosses the chip as
+//     four per-gate images in A-fragment order; the four gate partials of a unit group meet through an exchange among the four
+//     workgroups (j, 0..3); workgroup (j, g) then owns row tile g of its 16 units: dh_rec and dq stay in a register of the thread
+//     that finishes (row, unit), dc for all T steps;
+//   * the summed dctx_t goes out row-major; the B attention workgroups (one batch row each) run the arithmetic of
+//     attn.hip::attn_bwd_kernel and publish dhWa_t row-major (the history the batched dWa contraction reads) and as a
+//     fragment-order image;
+//   * (Q) is one 16 x 16 tile per workgroup -- its own row tile and units: the K = H reduction is cut over the four waves (order-
+//     free), each wave's quarter of Wa[16j .., :] in 4 NG / 4 registers per lane;
+//   * hand-offs per iteration: dz images (all, sharded counter), the 4-workgroup exchange (cluster counter), dctx (all, a second
+//     sharded counter), dhWa (attention workgroups); the sc1 form of chain_common.h.
+// The embedding block of dz @ W3^T does not feed the recurrence: the caller computes it for all steps at once afterwards.
+// Gradients are order-free fp32 (checked against float64 autograd, tests/test_gpu_attention_model.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "chain_common.h"
+
+namespace s2vt {
+
+namespace {
+
+constexpr int kABMaxTv = 64;
+
+struct AttnBwdChainKArgs {
+    const float* W3; int ldw;                          // [3H, 4H]
+    const float* Wa; int ldwa;                         // [H, H]
+    const float* gates; size_t gates_tstride;          // activated gates [T][B][4H]
+    const float* C; size_t state_tstride;              // cell states [T+1][B][H]
+    const float* dcat; size_t dcat_tstride; int ld_cat;   // d[out | ctx | emb] of the output layer [T][B][3H]
+    float* dZ; size_t dz_tstride;                      // [T][B][4H]
+    const float* hWa; size_t hwa_tstride;              // forward history [T][B][H] (slot 0 unused: zero query)
+    const float* P; const float* Vt; const float* w; const float* alpha;   // [Tv,B,H] x2, [H], [T][Tv][B]
+    const float* reg_coef; const float* asum; float reg_m;                 // alpha regulariser: [T*B] or NULL, [T][B], m
+    float* dhWa; size_t dhwa_tstride;                  // history [T][B][H], slots >= 1 written
+    float* dP; float* dVt; float* dw;                  // accumulated [Tv,B,H] x2, [H]
+    int B, H, T, Tv;
+    float keep; uint32_t seed_lo, seed_hi, drop_code0;
+    const int32_t* video_id; const int32_t* sample_id;
+    float* img;                                        // 2 parities x 4 gate images of dz, [4 row tiles][NG][256] each
+    float* ex;                                         // [unit groups][4 gates][8 tiles][256]
+    float* dctxs;                                      // [64][H] the recurrence's part of d(ctx_t), row-major
+    float* qimg;                                       // dhWa_t in A-fragment order [4][NG][256]
+    unsigned* sync;                                    // main counters | dctx counters (kChainSyncBytes each) | dhWa line | one line per unit group
+    unsigned* status; unsigned* fault; unsigned spin_limit;
+    int ncg;
+};
+
+template <int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_chain_kernel(const AttnBwdChainKArgs g)
+{
+    constexpr int ZS = 20;
+    constexpr int RING = NG < 16 ? NG : 16;
+    constexpr int QG = NG / 4;                                 // k-groups of the query product per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                          // [NG][2 blocks][64][4]: B fragments (block 0: h rows, block 1: context rows)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* zb = smem + NG * 2 * 256 + pwave * (16 * ZS);       // per-wave transpose tile
+    float* dzl = smem + NG * 2 * 256 + 4 * 16 * ZS;            // [4 gates][16 rows][17]
+    float* cq = dzl + 4 * 16 * 17;                             // [4 waves][256] partial tiles of the query product
+    float* dcl = cq + 4 * 256;                                 // [NG * 16] d(ctx) of the attention role's row
+    float* dal = dcl + NG * 16;                                // [64]
+    float* del = dal + kABMaxTv;                               // [64]
+    float* all_ = del + kABMaxTv;                              // [64]
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int H = g.H, M = g.B, T = g.T, Tv = g.Tv;
+    const int wg = (int)blockIdx.x;
+    const int gate = (wg >> 3) & 3;
+    const int jj = (wg >> 5) * 8 + (wg & 7);
+    if (jj >= g.ncg) return;                                   // (grid padded to whole groups of 8)
+    const int u0 = jj * 16;
+    const size_t img_floats = (size_t)4 * NG * 256;            // one gate image
+    const int lin = jj * 4 + gate;
+    const int brow = 4 * g.ncg - 1 - lin;                      // attention role: batch row
+    const bool roleA = brow < M;
+
+    // ---- this workgroup's two slices -> LDS, once.  B[k][n] = W3[base + u0 + n][gate * H + k]
+    for (int idx = tid; idx < 2 * 16 * NG * 4; idx += 256) {
+        const int blk = idx / (16 * NG * 4), rem = idx % (16 * NG * 4);
+        const int k4 = rem % (NG * 4), n = rem / (NG * 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (u0 + n < H && 4 * k4 < H) v = *reinterpret_cast<const f32x4*>(g.W3 + (size_t)((blk == 0 ? 2 * H : 0) + u0 + n) * g.ldw + (size_t)gate * H + 4 * k4);
+        const int grp = k4 >> 2, e = k4 & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Wl[(((grp * 2 + blk) * 64 + i * 16 + n) << 2) + e] = v[i];
+    }
+    // this wave's quarter of Wa[u0 + l15][:] -> registers: k-step s of the quarter holds Wa[u0 + l15][16 (QG w + s / 4) + 4 (s % 4) + lq]
+    float wa[4 * QG];
+#pragma unroll
+    for (int s = 0; s < 4 * QG; ++s) {
+        const int k = 16 * (QG * pwave + (s >> 2)) + 4 * (s & 3) + lq;
+        wa[s] = (u0 + l15 < H && k < H) ? g.Wa[(size_t)(u0 + l15) * g.ldwa + k] : 0.0f;
+    }
+
+    // ---- the (row, unit) this thread finishes at every step: row tile `gate`, 16 units
+    const int pr = tid >> 4, pn = tid & 15;
+    const int pm = gate * 16 + pr, pu = u0 + pn;
+    const bool pok = pm < M && pu < H;
+    float dc_reg = 0.0f;
+    float cnew = pok ? g.C[(size_t)T * g.state_tstride + (size_t)pm * H + pu] : 0.0f;       // c_{T-1}
+    const uint32_t vid = (g.keep < 1.0f && pok) ? (uint32_t)g.video_id[pm] : 0u;
+    const uint32_t sid = (g.keep < 1.0f && pok) ? (uint32_t)g.sample_id[pm] : 0u;
+    gu32* const base = (gu32*)g.sync;
+    gu32* const cntH = base + 2 * (kChainSyncBytes / 4);       // dhWa hand-off
+    gu32* const ccount = cntH + 32 + jj * 32;                  // the unit group's exchange counter
+    const __amdgpu_buffer_rsrc_t rsEx = __builtin_amdgcn_make_buffer_rsrc(g.ex, 0, g.ncg * 4 * 8 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(g.img, 0, (int)(8 * img_floats * 4), 0x00020000);
+    GridSync gs{base, g.status, g.fault, g.spin_limit, g.ncg, false, 4u};                       // dz images
+    GridSync gd{base + kChainSyncBytes / 4, g.status, g.fault, g.spin_limit, g.ncg, false, 4u};   // summed dctx
+    const bool wok = pwave * 16 < M;                           // MFMA side: this wave's row tile holds rows of the problem
+    const int voff = wok ? lane * 16 : (int)0x80000000u;
+    __syncthreads();
+
+    float sg[4], cprev, dxo;
+    auto load_step = [&](int t) __attribute__((always_inline)) {     // operands of step t's pointwise part (independent of the recurrence)
+        const float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)pm * 4 * H + pu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sg[q] = pok ? gp[(size_t)q * H] : 0.0f;
+        cprev = pok ? g.C[(size_t)t * g.state_tstride + (size_t)pm * H + pu] : 0.0f;
+        dxo = pok ? g.dcat[(size_t)t * g.dcat_tstride + (size_t)pm * g.ld_cat + pu] : 0.0f;
+    };
+    load_step(T - 1);
+
+    float dh_rec = 0.0f, dq = 0.0f;
+    unsigned it = 0;                                           // iterations done
+    for (int t = T - 1; t >= 0; --t, ++it) {
+        // ---- (P) BasicLSTMCell backward pointwise (the expressions of lstm_bwd_pointwise_kernel)
+        float dzv[4];
+        {
+            float d = dxo + dq;
+            if (g.keep < 1.0f) d = (d / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid, sid, g.drop_code0 + (uint32_t)t, (uint32_t)pu, g.keep);
+            const float dht = dh_rec + d;
+            const float si = sg[0], tj = sg[1], sf = sg[2], so = sg[3];
+            const float tc = dm_tanhf(cnew);
+            const float dc = dht * so * (1.f - tc * tc) + dc_reg;
+            dzv[0] = dc * tj * si * (1.f - si);
+            dzv[1] = dc * si * (1.f - tj * tj);
+            dzv[2] = dc * cprev * sf * (1.f - sf);
+            dzv[3] = dht * tc * so * (1.f - so);
+            dc_reg = dc * sf;
+            cnew = cprev;
+        }
+        // dz_t -> the four gate images (regrouped through LDS: every thread writes ONE 16-byte fragment slot), then the history
+        {
+            const size_t inext = (size_t)(t & 1) * 4 * img_floats;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dzl[(q * 16 + pr) * 17 + pn] = pok ? dzv[q] : 0.0f;
+            __syncthreads();
+            const int q = tid >> 6, L = tid & 63, r = L & 15, kq = L >> 4;
+            u32x4v wv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wv[e] = __float_as_uint(dzl[(q * 16 + r) * 17 + kq + 4 * e]);
+            const size_t dst = inext + (size_t)q * img_floats + ((size_t)(gate * NG + jj) * 64 + L) * 4;
+            bstore16_sc1(rsImg, wv, (int)(dst * 4), 0);
+            gs.arrive(tid);
+        }
+        if (pok) {
+            float* zp = g.dZ + (size_t)t * g.dz_tstride + (size_t)pm * 4 * H + pu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zp[(size_t)q * H] = dzv[q];
+        }
+        if (t > 0) load_step(t - 1);
+
+        // ---- (M) dz_t[:, gate block] @ [h rows ; context rows]^T for this wave's row tile
+        gs.wait_all(it, pwave, lane);
+        {
+            const float* acur = g.img + (size_t)(t & 1) * 4 * img_floats + (size_t)gate * img_floats + (size_t)pwave * NG * 256;
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur), 0, NG * 1024, 0x00020000);
+            f32x4 a[RING];
+            f32x4 acc[2][2];
+            acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            static_for<0, RING>([&](auto j_) { constexpr int j = decltype(j_)::value; a[j] = bload16_sc1(rsA, voff, j * 1024); });
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4* bl = reinterpret_cast<const f32x4*>(Wl) + lane;
+            constexpr int PB = NG < 4 ? NG : 4;
+            f32x4 b[PB][2];
+            static_for<0, PB>([&](auto j_) { constexpr int j = decltype(j_)::value; b[j][0] = bl[(j * 2) * 64]; b[j][1] = bl[(j * 2 + 1) * 64]; });
+            static_for<0, NG>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                const f32x4 b0 = b[j % PB][0], b1 = b[j % PB][1];
+                if constexpr (j + PB < NG) { b[j % PB][0] = bl[((j + PB) * 2) * 64]; b[j % PB][1] = bl[((j + PB) * 2 + 1) * 64]; }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    acc[e & 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][e], b0[e], acc[e & 1][0], 0, 0, 0);
+                    acc[e & 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j % RING][e], b1[e], acc[e & 1][1], 0, 0, 0);
+                });
+                if constexpr (j + RING < NG) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    a[j % RING] = bload16_sc1(rsA, voff, (j + RING) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            // partial tiles -> the unit group's exchange [gate][row tile][block] (row-major 16 x 16, one 16-byte store per lane)
+            const size_t exc = (size_t)jj * 4 * 8;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[0][c][r] + acc[1][c][r];
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 row = *reinterpret_cast<const f32x4*>(zb + (lane >> 2) * ZS + (lane & 3) * 4);
+                __builtin_amdgcn_wave_barrier();
+                bstore16_sc1(rsEx, __builtin_bit_cast(u32x4v, row), (int)(((exc + (size_t)gate * 8 + (size_t)pwave * 2 + c) * 256 + lane * 4) * 4), 0);
+            }
+            gs.arrive_one(ccount, tid);
+            gs.wait_one(ccount, 4u * (it + 1u), pwave, lane);
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s0 += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * 8 + gate * 2) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                s1 += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * 8 + gate * 2 + 1) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            dh_rec = s0;                                       // gradient w.r.t. h_{t-1} through step t's recurrent rows
+            if (pok) __hip_atomic_store((gu32*)(g.dctxs + (size_t)pm * H + pu), __float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gd.arrive(tid);
+        }
+        // ---- (A) attention backward of step t for batch row brow (attn.hip::attn_bwd_kernel's arithmetic)
+        if (roleA) {
+            const int q4 = tid;                                 // 16-byte column group (H <= 1024)
+            const bool qok = 4 * q4 < H;
+            const size_t rowoff = (size_t)brow * H + 4 * q4;
+            f32x4 dense = {0.f, 0.f, 0.f, 0.f}, hv = {0.f, 0.f, 0.f, 0.f}, wh = {0.f, 0.f, 0.f, 0.f};
+            if (qok) {                                          // (nothing here depends on this iteration's recurrence: issued before the wait)
+                dense = *reinterpret_cast<const f32x4*>(g.dcat + (size_t)t * g.dcat_tstride + (size_t)brow * g.ld_cat + H + 4 * q4);
+                if (t > 0) hv = *reinterpret_cast<const f32x4*>(g.hWa + (size_t)t * g.hwa_tstride + rowoff);
+                wh = *reinterpret_cast<const f32x4*>(g.w + 4 * q4);
+            }
+            if (tid < Tv) all_[tid] = g.alpha[((size_t)t * Tv + tid) * M + brow];
+            gd.wait_all(it, pwave, lane);
+            {
+                const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(g.dctxs + (size_t)brow * H, 0, H * 4, 0x00020000);
+                const f32x4 v = bload16_sc1(rsD, q4 * 16, 0);
+                dense[0] += v[0]; dense[1] += v[1]; dense[2] += v[2]; dense[3] += v[3];
+            }
+            if (qok) *reinterpret_cast<f32x4*>(dcl + 4 * q4) = dense;
+            __syncthreads();
+            for (int f = pwave; f < Tv; f += 4) {               // dalpha[f] = <dctx, V[f, b, :]>: one wave per frame
+                const float* vp = g.Vt + ((size_t)f * M + brow) * H;
+                float s = 0.f;
+                for (int q = lane; q < (H >> 2); q += 64) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(vp + 4 * q), d = *reinterpret_cast<const f32x4*>(dcl + 4 * q);
+                    s += d[0] * x[0] + d[1] * x[1] + d[2] * x[2] + d[3] * x[3];
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (lane == 0) dal[f] = s;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                if (g.reg_coef && (g.reg_m - g.asum[(size_t)t * M + brow]) > 0.f) {
+                    const int n8 = Tv < 8 ? Tv : 8;
+                    const float rc = g.reg_coef[(size_t)t * M + brow];
+                    for (int f = 0; f < n8; ++f) dal[f] -= rc;
+                }
+                float dot = 0.f;
+                for (int f = 0; f < Tv; ++f) dot += all_[f] * dal[f];
+                for (int f = 0; f < Tv; ++f) del[f] = all_[f] * (dal[f] - dot);
+            }
+            __syncthreads();
+            if (qok) {
+                f32x4 accq = {0.f, 0.f, 0.f, 0.f}, dwl = {0.f, 0.f, 0.f, 0.f};
+                for (int f0 = 0; f0 < Tv; f0 += 4) {
+                    f32x4 pv[4], op[4], ov[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (f0 + j < Tv) {
+                            const size_t o = (size_t)(f0 + j) * M * H + rowoff;
+                            pv[j] = *reinterpret_cast<const f32x4*>(g.P + o);
+                            op[j] = *reinterpret_cast<const f32x4*>(g.dP + o);
+                            ov[j] = *reinterpret_cast<const f32x4*>(g.dVt + o);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (f0 + j < Tv) {
+                            const size_t o = (size_t)(f0 + j) * M * H + rowoff;
+                            const float d = del[f0 + j], alt = all_[f0 + j];
+                            f32x4 ds, dv;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float Tn = dm_tanhf(hv[i] + pv[j][i]);
+                                const float s_ = d * wh[i] * (1.f - Tn * Tn);
+                                accq[i] += s_;
+                                dwl[i] += d * Tn;
+                                ds[i] = s_ + op[j][i];
+                                dv[i] = alt * dense[i] + ov[j][i];
+                            }
+                            *reinterpret_cast<f32x4*>(g.dP + o) = ds;
+                            *reinterpret_cast<f32x4*>(g.dVt + o) = dv;
+                        }
+                }
+                if (t > 0) {
+                    // dhWa_t: the fragment-order image first (everybody's query product waits for it), then the row-major history
+                    const int tile = brow >> 4, rr = brow & 15;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = 4 * q4 + i;
+                        const size_t off = ((size_t)(tile * NG + (k >> 4)) * 64 + (size_t)((k & 3) * 16 + rr)) * 4 + ((k & 15) >> 2);
+                        __hip_atomic_store((gu32*)(g.qimg + off), __float_as_uint(accq[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    *reinterpret_cast<f32x4*>(g.dhWa + (size_t)t * g.dhwa_tstride + rowoff) = accq;
+                }
+                atomicAdd(g.dw + 4 * q4, dwl[0]); atomicAdd(g.dw + 4 * q4 + 1, dwl[1]); atomicAdd(g.dw + 4 * q4 + 2, dwl[2]); atomicAdd(g.dw + 4 * q4 + 3, dwl[3]);
+            }
+            if (t > 0) gs.arrive_one(cntH, tid);
+        }
+        // ---- (Q) dq_t = dhWa_t @ Wa^T for this workgroup's own tile (row tile `gate`, its 16 units): K cut over the four waves
+        if (t > 0) {
+            gs.wait_one(cntH, (unsigned)(M * (int)(it + 1u)), pwave, lane);
+            const float* qt = g.qimg + (size_t)gate * NG * 256 + (size_t)(QG * pwave) * 256;
+            const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qt), 0, QG * 1024, 0x00020000);
+            const int vq = gate * 16 < M ? lane * 16 : (int)0x80000000u;
+            f32x4 aq[QG];
+            static_for<0, QG>([&](auto j_) { constexpr int j = decltype(j_)::value; aq[j] = bload16_sc1(rsQ, vq, j * 1024); });
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            static_for<0, QG>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][0], wa[4 * j + 0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][1], wa[4 * j + 1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][2], wa[4 * j + 2], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][3], wa[4 * j + 3], c1, 0, 0, 0);
+            });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cq[pwave * 256 + (lq * 4 + r) * 16 + l15] = c0[r] + c1[r];
+            __syncthreads();
+            dq = (cq[tid] + cq[256 + tid]) + (cq[512 + tid] + cq[768 + tid]);
+        }
+    }
+}
+
+struct ABCfg { int ng; void (*fn)(const AttnBwdChainKArgs); const char* name; };
+const ABCfg kABCfg[] = {{8, attn_bwd_chain_kernel<8>, "attn_bchain(ng8)"}, {64, attn_bwd_chain_kernel<64>, "attn_bchain(ng64)"}};
+constexpr int kNumABCfg = 2;
+int ab_lds_bytes(int ng) { return (ng * 2 * 256 + 4 * 16 * 20 + 4 * 16 * 17 + 4 * 256 + ng * 16 + 3 * kABMaxTv) * 4; }
+
+struct ABDev {
+    std::once_flag once;
+    bool ok = false;
+    int per_cu[kNumABCfg] = {};
+};
+constexpr int kMaxDev = 32;
+ABDev g_abdev[kMaxDev];
+ABDev* abdev_state()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    ABDev& d = g_abdev[dev];
+    std::call_once(d.once, [&d] {
+        bool ok = true;
+        for (int i = 0; ok && i < kNumABCfg; ++i) {
+            const int lds = ab_lds_bytes(kABCfg[i].ng);
+            ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kABCfg[i].fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+            int n = 0;
+            if (ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kABCfg[i].fn), 256, lds) == hipSuccess) d.per_cu[i] = n;
+        }
+        d.ok = ok;
+    });
+    return &d;
+}
+int ab_cfg(int H) { return (H + 15) / 16 <= 8 ? 0 : 1; }
+
+}  // namespace
+
+bool attn_bwd_chain_eligible(int B, int H, int Tv)
+{
+    static const bool off = [] { const char* e = getenv("S2VT_ABCHAIN"); return e && e[0] == '0'; }();     // dev / test knob: per-step launches
+    if (off || chain_persistent_disabled()) return false;
+    ChainHost hst;
+    ABDev* d = abdev_state();
+    if (!chain_host(&hst) || !d || !d->ok) return false;
+    if (!(B >= 1 && B <= 64 && H >= 16 && (H & 3) == 0 && H <= 1024 && Tv >= 1 && Tv <= kABMaxTv)) return false;
+    const int ncg = (H + 15) / 16;
+    if (B > 4 * ncg) return false;                               // a batch row per attention workgroup
+    return (long)d->per_cu[ab_cfg(H)] * hst.num_cus >= 4L * ncg; // every ACTIVE workgroup resident at once
+}
+
+void attn_bwd_chain_scratch(int H, size_t* img_floats, size_t* ex_floats, size_t* row_floats, size_t* sync_bytes)
+{
+    const int ng = kABCfg[ab_cfg(H)].ng, ncg = (H + 15) / 16;
+    *img_floats = (size_t)(8 + 1) * 4 * ng * 256;               // 2 parities x 4 gate images of dz + the dhWa image
+    *ex_floats = (size_t)ncg * 4 * 8 * 256;
+    *row_floats = (size_t)64 * H;
+    *sync_bytes = 2 * kChainSyncBytes + 128 + (size_t)ncg * 128;
+}
+
+hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st)
+{
+    if (!attn_bwd_chain_eligible(a.B, a.H, a.Tv)) return hipErrorInvalidValue;
+    if (a.T <= 0) return hipSuccess;
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (!al16(a.W3) || (a.ldw & 3) || !al16(a.Wa) || !al16(a.P) || !al16(a.Vt) || !al16(a.w) || !al16(a.hWa) || !al16(a.dhWa) || !al16(a.dP) || !al16(a.dVt) ||
+        !al16(a.dcat) || (a.ld_cat & 3) || (a.dcat_tstride & 3) || !al16(a.img) || !al16(a.ex) || !al16(a.dctxs) || (a.hwa_tstride & 3) || (a.dhwa_tstride & 3))
+        return hipErrorInvalidValue;
+    ChainHost hst;
+    if (!chain_host(&hst)) return hipErrorInvalidValue;
+    const int ci = ab_cfg(a.H), ng = kABCfg[ci].ng, ncg = (a.H + 15) / 16;
+    AttnBwdChainKArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.W3 = a.W3; k.ldw = a.ldw; k.Wa = a.Wa; k.ldwa = a.ldwa; k.gates = a.gates; k.gates_tstride = a.gates_tstride; k.C = a.C; k.state_tstride = a.state_tstride;
+    k.dcat = a.dcat; k.dcat_tstride = a.dcat_tstride; k.ld_cat = a.ld_cat; k.dZ = a.dZ; k.dz_tstride = a.dz_tstride;
+    k.hWa = a.hWa; k.hwa_tstride = a.hwa_tstride; k.P = a.P; k.Vt = a.Vt; k.w = a.w; k.alpha = a.alpha;
+    k.reg_coef = a.reg_coef; k.asum = a.asum; k.reg_m = a.reg_m; k.dhWa = a.dhWa; k.dhwa_tstride = a.dhwa_tstride; k.dP = a.dP; k.dVt = a.dVt; k.dw = a.dw;
+    k.B = a.B; k.H = a.H; k.T = a.T; k.Tv = a.Tv;
+    k.keep = a.keep; k.seed_lo = a.seed_lo; k.seed_hi = a.seed_hi; k.drop_code0 = a.drop_code0; k.video_id = a.video_id; k.sample_id = a.sample_id;
+    size_t imgf, exf, rowf, syncb;
+    attn_bwd_chain_scratch(a.H, &imgf, &exf, &rowf, &syncb);
+    k.img = a.img; k.qimg = a.img + (size_t)8 * 4 * ng * 256; k.ex = a.ex; k.dctxs = a.dctxs; k.sync = a.sync;
+    k.status = hst.status_dev; k.fault = hst.fault; k.spin_limit = hst.spin_limit; k.ncg = ncg;
+    ChainLaunchOrder order;                                    // one persistent grid at a time per process
+    {
+        hipError_t we = order.before(st, hst.device);
+        if (we != hipSuccess) return we;
+    }
+    ZeroList z;
+    z.add(a.sync, syncb); z.add(a.img, imgf * 4);              // (rows >= B and k >= H of the images must read as zeros)
+    hipError_t e = launch_zero_regions(z, st);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((ncg + 7) / 8 * 32));
+    const double flops = (2.0 * a.B * (double)(2 * a.H) * 4.0 * a.H + 2.0 * a.B * (double)a.H * a.H) * a.T;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = prof_wants(10, ci);
+    if (prof) {
+        hipError_t pe = prof_events(&e0, &e1);
+        if (pe != hipSuccess) return pe;
+        (void)hipEventRecord(e0, st);
+    }
+    hipLaunchKernelGGL(kABCfg[ci].fn, grid, dim3(256), ab_lds_bytes(ng), st, k);
+    if (prof) {
+        (void)hipEventRecord(e1, st);
+        prof_record(10, ci, kABCfg[ci].name, flops, e0, e1);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return order.after(st, hst.device);
+}
+
+}  // namespace s2vt

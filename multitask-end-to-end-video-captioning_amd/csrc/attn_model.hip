@@ -144,6 +144,7 @@ struct AttnWs {
     float* bslab; size_t bslab_floats;    // split-K slabs of the batched data-gradient products
     unsigned long long* packed;    // greedy picks [Tc][B][kPickStride]
     float* aimg; unsigned* async_; // persistent forward recurrence (attn_chain.hip): fragment images, hand-off counters
+    float *bimg, *bex, *brow_; unsigned* bsync;   // persistent backward recurrence (attn_chain_bwd.hip)
 };
 
 size_t carve_attn(Carver& c, const s2vt_dims* d, int B, AttnWs* out)
@@ -175,6 +176,11 @@ size_t carve_attn(Carver& c, const s2vt_dims* d, int B, AttnWs* out)
     }
     w.packed = c.take<unsigned long long>(Tc * b * kPickStride);
     w.aimg = c.take<float>(attn_chain_scratch_floats((int)H)); w.async_ = c.take<unsigned>(kAttnChainSyncBytes / 4);
+    {
+        size_t imgf, exf, rowf, syncb;
+        attn_bwd_chain_scratch((int)H, &imgf, &exf, &rowf, &syncb);
+        w.bimg = c.take<float>(imgf); w.bex = c.take<float>(exf); w.brow_ = c.take<float>(rowf); w.bsync = c.take<unsigned>(syncb / 4);
+    }
     if (out) *out = w;
     return c.off;
 }
@@ -369,42 +375,64 @@ int s2vt_attn_bptt_bwd(const s2vt_dims* d, const s2vt_attn_params* p, const s2vt
         HIP_TRY(launch_zero_regions(z, st));
     }
     // ---- the recurrence, back through time
-    // split-K plans of the two per-step data-gradient products (order-free): enough slabs for >= ~512 workgroups
-    int sx = (512 + ((3 * H + 63) / 64) - 1) / ((3 * H + 63) / 64) / ((B + 63) / 64);
-    if (sx < 1) sx = 1;
-    if (sx > kXSlabs) sx = kXSlabs;
-    const int kperx = ((4 * H + sx - 1) / sx + BK - 1) / BK * BK, nx = (4 * H + kperx - 1) / kperx;
-    int sq = kQSlabs;
-    while (sq > 1 && H / sq < 128) --sq;
-    const int kperq = ((H + sq - 1) / sq + BK - 1) / BK * BK, nq = (H + kperq - 1) / kperq;
-    for (int t = Tc - 1; t >= 0; --t) {
-        const bool last = t == Tc - 1;
-        AttnCellBwdArgs a;
+    if (attn_bwd_chain_eligible(B, H, Tv) && !chain_fault() && !(reinterpret_cast<uintptr_t>(p->lstm3_W) & 15) && !(reinterpret_cast<uintptr_t>(p->embed_att_Wa) & 15)) {
+        // ONE persistent launch: cell backward, dz @ [W3 h rows ; W3 context rows]^T, attention backward, dhWa @ Wa^T, all Tc steps
+        AttnBwdChainLaunch a;
         std::memset(&a, 0, sizeof(a));
-        a.gates = w.G3 + (size_t)t * 4 * BH; a.c_new = w.C3 + (t + 1) * BH; a.c_prev = w.C3 + t * BH;
-        a.dcat = w.dcat + (size_t)t * 3 * BH; a.ld_cat = 3 * H;
-        a.dqs = last ? nullptr : w.dqs; a.nq = nq; a.q_stride = BH;
-        a.dxs = last ? nullptr : w.dxs; a.nx = nx; a.x_stride = 3 * BH; a.ld_x = 3 * H; a.x_col0 = 2 * H;
-        a.dc_in = last ? nullptr : w.dc; a.dc_out = w.dc; a.dz = w.dZ3 + (size_t)t * 4 * BH;
-        a.M = B; a.H = H; a.keep = keep; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code = kDropCode3 + (uint32_t)t;
+        a.W3 = p->lstm3_W; a.ldw = 4 * H; a.Wa = p->embed_att_Wa; a.ldwa = H;
+        a.gates = w.G3; a.gates_tstride = (size_t)4 * BH; a.C = w.C3; a.state_tstride = BH;
+        a.dcat = w.dcat; a.dcat_tstride = (size_t)3 * BH; a.ld_cat = 3 * H; a.dZ = w.dZ3; a.dz_tstride = (size_t)4 * BH;
+        a.hWa = w.hWa; a.hwa_tstride = BH; a.P = w.P; a.Vt = w.Vt; a.w = p->embed_att_w; a.alpha = w.alpha;
+        a.reg_coef = reg_coef; a.asum = w.asum; a.reg_m = reg_m;
+        a.dhWa = w.dhWa; a.dhwa_tstride = BH; a.dP = w.dPt; a.dVt = w.dVtt; a.dw = grads->embed_att_w;
+        a.B = B; a.H = H; a.T = Tc; a.Tv = Tv;
+        a.keep = keep; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code0 = kDropCode3;
         a.video_id = video_id; a.sample_id = sample_id;
-        hipLaunchKernelGGL(attn_cell_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, a);
-        HIP_TRY(hipGetLastError());
-        // d[ctx | emb | h_prev] = dz @ W3^T as split-K slabs: the attention backward sums the ctx and emb blocks, the next
-        // (earlier) step's cell backward the h block
-        HIP_TRY(nn_bwd(w.dZ3 + (size_t)t * 4 * BH, 4 * H, p->lstm3_W, 4 * H, w.dxs, 3 * H, B, 3 * H, 4 * H, sx, 3 * BH, st, sx > 1 ? kSlabTileCfg : -1));
-        AttnBwdArgs g;
-        std::memset(&g, 0, sizeof(g));
-        g.hWa = t > 0 ? w.hWa + t * BH : nullptr; g.P = w.P; g.Vt = w.Vt; g.w = p->embed_att_w; g.alpha = w.alpha + (size_t)t * Tv * B;
-        g.dctx = w.dcat + (size_t)t * 3 * BH + H; g.ld_dctx = 3 * H;
-        g.slabs = w.dxs; g.nslab = nx; g.slab_stride = 3 * BH; g.ld_slab = 3 * H; g.ctx_col0 = 0; g.emb_col0 = H;
-        if (t > 0) { g.demb_dense = w.dcat + (size_t)t * 3 * BH + 2 * H; g.ld_demb = 3 * H; g.demb_out = w.dEmb + t * BH; }
-        if (reg_coef) { g.reg_coef = reg_coef + (size_t)t * B; g.asum = w.asum + (size_t)t * B; g.reg_m = reg_m; }
-        g.dhWa = t > 0 ? w.dhWa + t * BH : nullptr; g.dP = w.dPt; g.dVt = w.dVtt; g.acc = 1; g.dw = grads->embed_att_w;
-        g.Tv = Tv; g.B = B; g.H = H;
-        HIP_TRY(launch_attn_bwd(g, st));
-        // gradient w.r.t. the previous step's dropped output through this step's query: dhWa @ Wa^T (slabs, summed by the cell backward)
-        if (t > 0) HIP_TRY(nn_bwd(w.dhWa + t * BH, H, p->embed_att_Wa, H, w.dqs, H, B, H, H, sq, BH, st, sq > 1 ? kSlabTileCfg : -1));
+        a.img = w.bimg; a.ex = w.bex; a.dctxs = w.brow_; a.sync = w.bsync;
+        HIP_TRY(launch_attn_bwd_chain(a, st));
+        // the embedding block of dz @ W3^T does not feed the recurrence: all steps >= 1 at once, on top of the output layer's block
+        if (Tc > 1) {
+            ASeg sz = make_seg(w.dZ3 + 4 * BH, 4 * H, 4 * H, 0);
+            HIP_TRY(store_call(&sz, 1, p->lstm3_W + (size_t)H * 4 * H, 4 * H, nullptr, w.dEmb + BH, H, R1, H, 0, -1, st, w.dcat + 3 * BH + 2 * H, 3 * H, true));
+        }
+    } else {
+        // split-K plans of the two per-step data-gradient products (order-free): enough slabs for >= ~512 workgroups
+        int sx = (512 + ((3 * H + 63) / 64) - 1) / ((3 * H + 63) / 64) / ((B + 63) / 64);
+        if (sx < 1) sx = 1;
+        if (sx > kXSlabs) sx = kXSlabs;
+        const int kperx = ((4 * H + sx - 1) / sx + BK - 1) / BK * BK, nx = (4 * H + kperx - 1) / kperx;
+        int sq = kQSlabs;
+        while (sq > 1 && H / sq < 128) --sq;
+        const int kperq = ((H + sq - 1) / sq + BK - 1) / BK * BK, nq = (H + kperq - 1) / kperq;
+        for (int t = Tc - 1; t >= 0; --t) {
+            const bool last = t == Tc - 1;
+            AttnCellBwdArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.gates = w.G3 + (size_t)t * 4 * BH; a.c_new = w.C3 + (t + 1) * BH; a.c_prev = w.C3 + t * BH;
+            a.dcat = w.dcat + (size_t)t * 3 * BH; a.ld_cat = 3 * H;
+            a.dqs = last ? nullptr : w.dqs; a.nq = nq; a.q_stride = BH;
+            a.dxs = last ? nullptr : w.dxs; a.nx = nx; a.x_stride = 3 * BH; a.ld_x = 3 * H; a.x_col0 = 2 * H;
+            a.dc_in = last ? nullptr : w.dc; a.dc_out = w.dc; a.dz = w.dZ3 + (size_t)t * 4 * BH;
+            a.M = B; a.H = H; a.keep = keep; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code = kDropCode3 + (uint32_t)t;
+            a.video_id = video_id; a.sample_id = sample_id;
+            hipLaunchKernelGGL(attn_cell_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, a);
+            HIP_TRY(hipGetLastError());
+            // d[ctx | emb | h_prev] = dz @ W3^T as split-K slabs: the attention backward sums the ctx and emb blocks, the next
+            // (earlier) step's cell backward the h block
+            HIP_TRY(nn_bwd(w.dZ3 + (size_t)t * 4 * BH, 4 * H, p->lstm3_W, 4 * H, w.dxs, 3 * H, B, 3 * H, 4 * H, sx, 3 * BH, st, sx > 1 ? kSlabTileCfg : -1));
+            AttnBwdArgs g;
+            std::memset(&g, 0, sizeof(g));
+            g.hWa = t > 0 ? w.hWa + t * BH : nullptr; g.P = w.P; g.Vt = w.Vt; g.w = p->embed_att_w; g.alpha = w.alpha + (size_t)t * Tv * B;
+            g.dctx = w.dcat + (size_t)t * 3 * BH + H; g.ld_dctx = 3 * H;
+            g.slabs = w.dxs; g.nslab = nx; g.slab_stride = 3 * BH; g.ld_slab = 3 * H; g.ctx_col0 = 0; g.emb_col0 = H;
+            if (t > 0) { g.demb_dense = w.dcat + (size_t)t * 3 * BH + 2 * H; g.ld_demb = 3 * H; g.demb_out = w.dEmb + t * BH; }
+            if (reg_coef) { g.reg_coef = reg_coef + (size_t)t * B; g.asum = w.asum + (size_t)t * B; g.reg_m = reg_m; }
+            g.dhWa = t > 0 ? w.dhWa + t * BH : nullptr; g.dP = w.dPt; g.dVt = w.dVtt; g.acc = 1; g.dw = grads->embed_att_w;
+            g.Tv = Tv; g.B = B; g.H = H;
+            HIP_TRY(launch_attn_bwd(g, st));
+            // gradient w.r.t. the previous step's dropped output through this step's query: dhWa @ Wa^T (slabs, summed by the cell backward)
+            if (t > 0) HIP_TRY(nn_bwd(w.dhWa + t * BH, H, p->embed_att_Wa, H, w.dqs, H, B, H, H, sq, BH, st, sq > 1 ? kSlabTileCfg : -1));
+        }
     }
     // ---- weight gradients of the recurrence, one contraction over all unrolled steps per block
     {

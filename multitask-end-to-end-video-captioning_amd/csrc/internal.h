@@ -225,6 +225,24 @@ bool attn_chain_eligible(int B, int H, int Tv);       // the persistent form ser
 size_t attn_chain_scratch_floats(int H);
 hipError_t launch_attn_chain(const AttnChainLaunch& a, hipStream_t st);
 
+// ---- ... and its backward recurrence (attn_chain_bwd.hip)
+struct AttnBwdChainLaunch {
+    const float* W3; int ldw; const float* Wa; int ldwa;
+    const float* gates; size_t gates_tstride; const float* C; size_t state_tstride;      // forward histories
+    const float* dcat; size_t dcat_tstride; int ld_cat;     // d[out | ctx | emb] of the output layer, [T][B][3H]
+    float* dZ; size_t dz_tstride;                           // [T][B][4H]
+    const float* hWa; size_t hwa_tstride; const float* P; const float* Vt; const float* w; const float* alpha;
+    const float* reg_coef; const float* asum; float reg_m;  // alpha regulariser (reg_coef NULL = none)
+    float* dhWa; size_t dhwa_tstride;                       // [T][B][H], slots >= 1 written
+    float* dP; float* dVt; float* dw;                       // accumulated (zeroed / owned by the caller)
+    int B, H, T, Tv;
+    float keep; uint32_t seed_lo, seed_hi, drop_code0; const int32_t* video_id; const int32_t* sample_id;
+    float* img; float* ex; float* dctxs; unsigned* sync;    // scratch, sizes from attn_bwd_chain_scratch (16-byte aligned)
+};
+bool attn_bwd_chain_eligible(int B, int H, int Tv);
+void attn_bwd_chain_scratch(int H, size_t* img_floats, size_t* ex_floats, size_t* row_floats, size_t* sync_bytes);
+hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st);
+
 // order-free NN contraction for the backward data path with optional split-K slabs:
 // slab s (blockIdx.y) holds the partial over its K range at C + s * slab_stride.
 struct NnBwdArgs {
