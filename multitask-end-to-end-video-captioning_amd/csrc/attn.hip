@@ -12,6 +12,7 @@
 #include <mutex>
 
 #include "api_util.h"
+#include "attn_score.h"
 #include "detmath.h"
 
 using namespace s2vt_api;
@@ -45,7 +46,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a)
     const float* __restrict__ hp = a.hWa ? a.hWa + (size_t)b * H : nullptr;
     const float* __restrict__ Pp = a.P;
     const float* __restrict__ Vp = a.Vt;
-    for (int h = tid; h < H; h += 256) wl[h] = a.w[h];
+    const int Hp = (H + 15) & ~15;
+    for (int h = tid; h < Hp; h += 256) wl[h] = h < H ? a.w[h] : 0.f;
+    for (int i = tid; i < a.RC * (Hp - H); i += 256) Tt[(size_t)(i / (Hp - H)) * ldT + H + i % (Hp - H)] = 0.f;     // pad columns (never written again)
     for (int c0 = 0; c0 < Tv; c0 += a.RC) {
         const int nr = (Tv - c0) < a.RC ? (Tv - c0) : a.RC;
         if (a.vec) {
@@ -75,34 +78,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a)
         }
         __syncthreads();
         const int r = (tid & 63) * 4 + (tid >> 6);       // frame r of the chunk -> wave r & 3, lane r >> 2
-        if (r < nr) {
-            const float* tr = Tt + (size_t)r * ldT;
-            float e = 0.f;
-            int h = 0;
-            if (H >= 16) {
-                // 16 links per round, the next round's operands already on their way from LDS while this round's chain runs
-                float4 t0[4], w0[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { t0[j] = *reinterpret_cast<const float4*>(tr + 4 * j); w0[j] = *reinterpret_cast<const float4*>(wl + 4 * j); }
-                for (; h + 16 <= H; h += 16) {
-                    float4 t1[4], w1[4];
-                    const int hn = (h + 32 <= H) ? h + 16 : h;           // (last round: a harmless re-read)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { t1[j] = *reinterpret_cast<const float4*>(tr + hn + 4 * j); w1[j] = *reinterpret_cast<const float4*>(wl + hn + 4 * j); }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        e = __builtin_fmaf(t0[j].x, w0[j].x, e);
-                        e = __builtin_fmaf(t0[j].y, w0[j].y, e);
-                        e = __builtin_fmaf(t0[j].z, w0[j].z, e);
-                        e = __builtin_fmaf(t0[j].w, w0[j].w, e);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { t0[j] = t1[j]; w0[j] = w1[j]; }
-                }
-            }
-            for (; h < H; ++h) e = __builtin_fmaf(tr[h], wl[h], e);
-            ev[c0 + r] = e;
-        }
+        if (r < nr) ev[c0 + r] = score_chain(Tt + (size_t)r * ldT, wl, (H + 15) >> 4);     // (rows zero-padded to a multiple of 16: attn_score.h)
         __syncthreads();
     }
     if (tid < Tv) {
@@ -326,7 +302,7 @@ hipError_t launch_attn_fwd(const AttnFwdArgs& a0, hipStream_t st)
     if (a0.Tv <= 0 || a0.Tv > kAttnMaxTv || a0.B <= 0 || a0.H <= 0) return hipErrorInvalidValue;
     AttnFwdArgs a = a0;
     a.RC = a.Tv < kAttnChunkRows ? a.Tv : kAttnChunkRows;
-    a.ldT = ((a.H + 3) & ~3) + 4;
+    a.ldT = ((a.H + 15) & ~15) + 4;                          // rows padded to whole 16-link phases of the score chain (+4: bank spread)
     const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     a.vec = (!(a.H & 3) && al16(a.P) && al16(a.Vt) && al16(a.ctx) && (!a.hWa || al16(a.hWa))) ? 1 : 0;
     const size_t lds = ((size_t)(a.RC + 1) * a.ldT + 2 * kAttnMaxTv + 4) * sizeof(float);

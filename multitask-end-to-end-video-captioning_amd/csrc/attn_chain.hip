@@ -30,6 +30,7 @@
 #include <cstring>
 #include <mutex>
 
+#include "attn_score.h"
 #include "chain_common.h"
 
 namespace s2vt {
@@ -54,10 +55,13 @@ struct AttnChainKArgs {
     float keep; uint32_t seed_lo, seed_hi, drop_code0;
     const int32_t* video_id; const int32_t* sample_id;
     float* himg; float* qimg; float* cimg; // fragment images: h and dropped-out double-buffered [2][4][NG][256] (qimg == himg when keep >= 1), ctx [4][NG][256]
-    unsigned* sync;                        // kChainSyncBytes + two more counter lines (hWa, ctx)
+    unsigned* sync;                        // three sharded counter sets (end of step, hWa, ctx): 3 x kChainSyncBytes
     unsigned* status; unsigned* fault; unsigned spin_limit;
 };
 
+#ifdef S2VT_AC_STAMP
+__device__ unsigned long long ac_stamp_acc[3 * 16];          // dev build: per-phase clock sums of three workgroups (query role, plain, attention role)
+#endif
 template <int NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_chain_kernel(const AttnChainKArgs g)
 {
@@ -107,8 +111,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int uu = 0; uu < 4; ++uu) Wq[((j * 64 + kq * 16 + c4 * 4 + uu) << 2) + e] = v[uu];
         }
     }
-    if (roleA)
+    if (roleA) {
         for (int h = tid; h < KP; h += 256) wl[h] = h < H ? g.w[h] : 0.f;
+        for (int i = tid; i < kACRows * (KP - H); i += 256) Tt[(size_t)(i / (KP - H)) * LDT + H + i % (KP - H)] = 0.f;     // pad columns: zeros for good
+    }
     // context rows W3[0:H] of this workgroup's 16 gate columns -> registers: k-step s of group j holds W3[16 j + 4 e + lq][column of l15]
     const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);          // W / cinit column of tile column l15 (gate l15 % 4, unit u0 + l15 / 4)
     float breg[4 * NG];
@@ -131,18 +137,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool drops = g.keep < 1.0f;
 
     GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, nwg, false};
-    gu32* const cntQ = (gu32*)g.sync + (kShards + 1) * 32;     // hWa hand-off: query workgroups arrive
-    gu32* const cntC = cntQ + 32;                              // ctx hand-off: attention workgroups arrive
+    // the two role hand-offs have their own SHARDED counters as well: with one word each, ~250 pollers hammered the L2 line the
+    // 63 / 64 arrivals had to get through, and a hand-off took ~6 us instead of ~2 (s_memtime stamps)
+    GridSync gq{(gu32*)g.sync + kChainSyncBytes / 4, g.status, g.fault, g.spin_limit, nq, false};        // hWa: the query workgroups arrive
+    GridSync gc{(gu32*)g.sync + 2 * (kChainSyncBytes / 4), g.status, g.fault, g.spin_limit, M, false};    // ctx: the attention workgroups arrive
 
-    float ci[4];
-    auto load_cinit = [&](int t) __attribute__((always_inline)) {
+    float ci[4], cn[4];
+    auto load_cinit = [&](int t, float* dst) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = wave * 16 + lq * 4 + r;
-            ci[r] = (g.cinit && tok && m < M) ? g.cinit[(size_t)t * g.cinit_tstride + (size_t)m * g.ldcinit + ccol] : 0.0f;
+            dst[r] = (g.cinit && tok && m < M) ? g.cinit[(size_t)t * g.cinit_tstride + (size_t)m * g.ldcinit + ccol] : 0.0f;
         }
     };
-    load_cinit(0);
+    load_cinit(0, ci);
     const int voff = tok ? lane * 16 : (int)0x80000000u;       // a wave without rows reads zeros (out of range)
 
     // one row tile x 16 columns over the whole reduction, A fragments from a fragment image (sc1 loads into a register ring),
@@ -194,11 +202,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         return acc;
     };
 
+#ifdef S2VT_AC_STAMP
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#define AC_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[i] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define AC_STAMP(i) do { } while (0)
+#endif
     for (int t = 0; t < T; ++t) {
         f32x4 acc = {ci[0], ci[1], ci[2], ci[3]};
         asm volatile("" : "+v"(acc));
+        AC_STAMP(0);                                           // carried partial in registers
+        // the NEXT step's carried partial is requested now (it is not touched by this step: the gates of step t go to slot t) and
+        // lands under the step's hand-offs -- waited for at the top of a step it cost 1.5 us
+        if (t + 1 < T) load_cinit(t + 1, cn);
         if (t > 0) {
             gs.wait_all((unsigned)(t - 1), pwave, lane);       // h_{t-1} and out_{t-1} of every workgroup are in the images
+            AC_STAMP(1);                                       // end-of-step hand-off wait
             const float* hcur = g.himg + (size_t)(t & 1) * img_floats + (size_t)wave * NG * 256;
             if (roleQ) {
                 // ---- query projection of this step: out_{t-1} @ Wa[:, tile], published first -- the attention role waits for it
@@ -215,10 +234,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                gs.arrive_one(cntQ, tid);
+                gq.arrive_as((int)blockIdx.x, tid);
+                AC_STAMP(2);                                   // query projection + publish
             }
             // ---- the recurrent block of the chain (needs nothing of this step)
             acc = pass_lds(hcur, Wl, acc);
+            asm volatile("" : "+v"(acc));
+            AC_STAMP(3);                                       // h block
         }
         if (roleA) {
             // ---- score / softmax / context of batch row brow (the arithmetic of attn.hip::attn_fwd_kernel)
@@ -236,10 +258,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             f32x4 hv = {0.f, 0.f, 0.f, 0.f};
             if (t > 0) {
-                gs.wait_one(cntQ, (unsigned)(nq * t), pwave, lane);
+                gq.wait_all((unsigned)(t - 1), pwave, lane);
                 const __amdgpu_buffer_rsrc_t rsH =
                     __builtin_amdgcn_make_buffer_rsrc(g.hWa + (size_t)t * g.hwa_tstride + (size_t)brow * H, 0, H * 4, 0x00020000);
                 hv = bload16_sc1(rsH, q * 16, 0);               // (columns >= H: out of range, zeros)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                AC_STAMP(4);                                   // wait for hWa + its load (and P / V)
             }
             for (int c0 = 0; c0 < Tv; c0 += kACRows) {
                 const int nr = (Tv - c0) < kACRows ? (Tv - c0) : kACRows;
@@ -260,35 +284,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 __syncthreads();
                 const int r = (tid & 63) * 4 + (tid >> 6);      // frame r of the chunk -> wave r & 3, lane r >> 2
-                if (r < nr) {
-                    const float* tr = Tt + (size_t)r * LDT;
-                    float e = 0.f;
-                    int h = 0;
-                    if (H >= 16) {
-                        f32x4 t0[4], w0[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { t0[j] = *reinterpret_cast<const f32x4*>(tr + 4 * j); w0[j] = *reinterpret_cast<const f32x4*>(wl + 4 * j); }
-                        for (; h + 16 <= H; h += 16) {
-                            f32x4 t1[4], w1[4];
-                            const int hn = (h + 32 <= H) ? h + 16 : h;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { t1[j] = *reinterpret_cast<const f32x4*>(tr + hn + 4 * j); w1[j] = *reinterpret_cast<const f32x4*>(wl + hn + 4 * j); }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                e = __builtin_fmaf(t0[j][0], w0[j][0], e);
-                                e = __builtin_fmaf(t0[j][1], w0[j][1], e);
-                                e = __builtin_fmaf(t0[j][2], w0[j][2], e);
-                                e = __builtin_fmaf(t0[j][3], w0[j][3], e);
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { t0[j] = t1[j]; w0[j] = w1[j]; }
-                        }
-                    }
-                    for (; h < H; ++h) e = __builtin_fmaf(tr[h], wl[h], e);
-                    ev[c0 + r] = e;
-                }
+                if (r < nr) ev[c0 + r] = score_chain(Tt + (size_t)r * LDT, wl, NG);      // (rows zero-padded to NG * 16: attn_score.h)
                 __syncthreads();
             }
+            AC_STAMP(5);                                       // tanh rows + score chains
             if (tid < Tv) xv[tid] = dm_expf(ev[tid]);
             __syncthreads();
             if (tid == 0) {
@@ -327,21 +326,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             c4[2] = __builtin_fmaf(al, vv[j][2], c4[2]); c4[3] = __builtin_fmaf(al, vv[j][3], c4[3]);
                         }
                 }
-                // the fragment-order image first (what everybody waits for), then the row-major history
-                const int tile = brow >> 4, rr = brow & 15;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = 4 * q + i;
-                    const size_t off = ((size_t)(tile * NG + (k >> 4)) * 64 + (size_t)((k & 3) * 16 + rr)) * 4 + ((k & 15) >> 2);
-                    __hip_atomic_store((gu32*)(g.cimg + off), __float_as_uint(c4[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                *reinterpret_cast<f32x4*>(g.ctx + (size_t)t * M * H + rowoff) = c4;
+                *reinterpret_cast<f32x4*>(Tt + 4 * q) = c4;              // staged (the tanh rows are free): regrouped into fragment slots below
+                *reinterpret_cast<f32x4*>(g.ctx + (size_t)t * M * H + rowoff) = c4;      // the row-major history
             }
-            gs.arrive_one(cntC, tid);
+            {
+                // ctx_t -> the fragment-order image as whole 16-byte slots: thread (group j = tid / 4, kq = tid % 4) takes k = 16 j + 4 e + kq
+                __syncthreads();
+                const int j = tid >> 2, kq = tid & 3;
+                if (16 * j < H) {
+                    u32x4v wv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wv[e] = __float_as_uint(16 * j + 4 * e + kq < H ? Tt[16 * j + 4 * e + kq] : 0.0f);
+                    const __amdgpu_buffer_rsrc_t rsCi = __builtin_amdgcn_make_buffer_rsrc(g.cimg, 0, 4 * NG * 1024, 0x00020000);
+                    bstore16_sc1(rsCi, wv, (int)((((size_t)((brow >> 4) * NG + j) * 64 + (size_t)(kq * 16 + (brow & 15))) * 4) * 4), 0);
+                }
+            }
+            gc.arrive_as(brow, tid);
+            AC_STAMP(6);                                       // softmax + context + publish
         }
-        gs.wait_one(cntC, (unsigned)(M * (t + 1)), pwave, lane);
+        gc.wait_all((unsigned)t, pwave, lane);
+        AC_STAMP(7);                                           // wait for the context
         // ---- the context block of the chain, then BasicLSTMCell pointwise (gate order i, j, f, o; forget_bias 1.0): EPI_LSTM's expressions
         acc = pass_reg(g.cimg + (size_t)wave * NG * 256, acc);
+        asm volatile("" : "+v"(acc));
+        AC_STAMP(8);                                           // context block
 #pragma unroll
         for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[r];
         __builtin_amdgcn_wave_barrier();
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             gs.arrive(tid);
         }
+        AC_STAMP(9);                                           // pointwise + image stores + arrive
         if (rok) {
             const size_t o = (size_t)row * H + u;
             g.C[(size_t)(t + 1) * g.state_tstride + o] = c_reg;
@@ -377,8 +386,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 gp[0] = si; gp[H] = tj; gp[2 * H] = sf; gp[3 * H] = so;
             }
         }
-        if (t + 1 < T) load_cinit(t + 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ci[r] = cn[r];
+        AC_STAMP(10);                                          // history stores issued, next partial requested
     }
+#ifdef S2VT_AC_STAMP
+    if (tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == nwg / 2 || (int)blockIdx.x == nwg - 1)) {
+        const int slot = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == nwg - 1 ? 2 : 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(&ac_stamp_acc[slot * 16 + i], st_acc[i]);
+    }
+#endif
 }
 
 struct ACfg { int ng; void (*fn)(const AttnChainKArgs); const char* name; };
@@ -485,3 +503,14 @@ hipError_t launch_attn_chain(const AttnChainLaunch& a, hipStream_t st)
 }
 
 }  // namespace s2vt
+
+#ifdef S2VT_AC_STAMP
+// dev build only: per-phase clock sums of attn_chain_kernel (3 workgroups x 16 phases), read and reset (tools/ac_stamp.py)
+extern "C" int s2vt_ac_stamp_read(unsigned long long* out48)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(s2vt::ac_stamp_acc), 48 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    unsigned long long z[48] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(s2vt::ac_stamp_acc), z, sizeof(z)) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -53,11 +53,14 @@ struct AttnBwdChainKArgs {
     float* ex;                                         // [unit groups][4 gates][8 tiles][256]
     float* dctxs;                                      // [64][H] the recurrence's part of d(ctx_t), row-major
     float* qimg;                                       // dhWa_t in A-fragment order [4][NG][256]
-    unsigned* sync;                                    // main counters | dctx counters (kChainSyncBytes each) | dhWa line | one line per unit group
+    unsigned* sync;                                    // dz | dctx | dhWa counter sets (kChainSyncBytes each) | one line per unit group
     unsigned* status; unsigned* fault; unsigned spin_limit;
     int ncg;
 };
 
+#ifdef S2VT_AC_STAMP
+__device__ unsigned long long ab_stamp_acc[3 * 16];          // dev build: per-phase clock sums of three workgroups
+#endif
 template <int NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_chain_kernel(const AttnBwdChainKArgs g)
 {
@@ -114,12 +117,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint32_t vid = (g.keep < 1.0f && pok) ? (uint32_t)g.video_id[pm] : 0u;
     const uint32_t sid = (g.keep < 1.0f && pok) ? (uint32_t)g.sample_id[pm] : 0u;
     gu32* const base = (gu32*)g.sync;
-    gu32* const cntH = base + 2 * (kChainSyncBytes / 4);       // dhWa hand-off
-    gu32* const ccount = cntH + 32 + jj * 32;                  // the unit group's exchange counter
+    gu32* const ccount = base + 3 * (kChainSyncBytes / 4) + jj * 32;      // the unit group's exchange counter
     const __amdgpu_buffer_rsrc_t rsEx = __builtin_amdgcn_make_buffer_rsrc(g.ex, 0, g.ncg * 4 * 8 * 1024, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(g.img, 0, (int)(8 * img_floats * 4), 0x00020000);
     GridSync gs{base, g.status, g.fault, g.spin_limit, g.ncg, false, 4u};                       // dz images
     GridSync gd{base + kChainSyncBytes / 4, g.status, g.fault, g.spin_limit, g.ncg, false, 4u};   // summed dctx
+    GridSync gh{base + 2 * (kChainSyncBytes / 4), g.status, g.fault, g.spin_limit, M, false};      // dhWa: the attention workgroups arrive (sharded:
+                                                                                                   // one word polled by every workgroup starves its own arrivals)
     const bool wok = pwave * 16 < M;                           // MFMA side: this wave's row tile holds rows of the problem
     const int voff = wok ? lane * 16 : (int)0x80000000u;
     __syncthreads();
@@ -134,8 +138,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     load_step(T - 1);
 
+    // attention role with few frames (the script's default 5): the row's P and V, and the accumulators of dP and dV, live in REGISTERS
+    // for the whole launch (4 columns x Tv frames each per thread) -- as global read-modify-writes per iteration they were 7 us of it
+    constexpr int TVR = 5;
+    const bool aregs = roleA && Tv <= TVR;
+    const bool aqok = 4 * tid < H;
+    f32x4 pR[TVR], vR[TVR], dPR[TVR], dVR[TVR];
+#pragma unroll
+    for (int f = 0; f < TVR; ++f) {
+        pR[f] = vR[f] = dPR[f] = dVR[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (aregs && aqok && f < Tv) {
+            pR[f] = *reinterpret_cast<const f32x4*>(g.P + ((size_t)f * M + brow) * H + 4 * tid);
+            vR[f] = *reinterpret_cast<const f32x4*>(g.Vt + ((size_t)f * M + brow) * H + 4 * tid);
+        }
+    }
+    f32x4 dwR = {0.f, 0.f, 0.f, 0.f};                          // d(score vector) of this thread's four columns, summed over the iterations (one
+                                                               // atomicAdd per column at the END: 64 workgroups x 1000 contended atomics per iteration cost ~5 us of it)
     float dh_rec = 0.0f, dq = 0.0f;
     unsigned it = 0;                                           // iterations done
+#ifdef S2VT_AC_STAMP
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#define AB_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[i] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define AB_STAMP(i) do { } while (0)
+#endif
     for (int t = T - 1; t >= 0; --t, ++it) {
         // ---- (P) BasicLSTMCell backward pointwise (the expressions of lstm_bwd_pointwise_kernel)
         float dzv[4];
@@ -168,15 +194,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             bstore16_sc1(rsImg, wv, (int)(dst * 4), 0);
             gs.arrive(tid);
         }
+        AB_STAMP(0);                                           // pointwise + dz images + arrive
         if (pok) {
             float* zp = g.dZ + (size_t)t * g.dz_tstride + (size_t)pm * 4 * H + pu;
 #pragma unroll
             for (int q = 0; q < 4; ++q) zp[(size_t)q * H] = dzv[q];
         }
         if (t > 0) load_step(t - 1);
+        AB_STAMP(1);                                           // history, next operands requested
 
         // ---- (M) dz_t[:, gate block] @ [h rows ; context rows]^T for this wave's row tile
         gs.wait_all(it, pwave, lane);
+        AB_STAMP(2);                                           // dz hand-off wait
         {
             const float* acur = g.img + (size_t)(t & 1) * 4 * img_floats + (size_t)gate * img_floats + (size_t)pwave * NG * 256;
             const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur), 0, NG * 1024, 0x00020000);
@@ -205,6 +234,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+            AB_STAMP(3);                                       // MFMAs
             // partial tiles -> the unit group's exchange [gate][row tile][block] (row-major 16 x 16, one 16-byte store per lane)
             const size_t exc = (size_t)jj * 4 * 8;
 #pragma unroll
@@ -224,9 +255,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 s0 += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * 8 + gate * 2) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 s1 += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * 8 + gate * 2 + 1) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
+            AB_STAMP(4);                                       // 4-workgroup exchange
             dh_rec = s0;                                       // gradient w.r.t. h_{t-1} through step t's recurrent rows
             if (pok) __hip_atomic_store((gu32*)(g.dctxs + (size_t)pm * H + pu), __float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             gd.arrive(tid);
+            AB_STAMP(5);                                       // dctx published
         }
         // ---- (A) attention backward of step t for batch row brow (attn.hip::attn_bwd_kernel's arithmetic)
         if (roleA) {
@@ -246,20 +279,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const f32x4 v = bload16_sc1(rsD, q4 * 16, 0);
                 dense[0] += v[0]; dense[1] += v[1]; dense[2] += v[2]; dense[3] += v[3];
             }
-            if (qok) *reinterpret_cast<f32x4*>(dcl + 4 * q4) = dense;
-            __syncthreads();
-            for (int f = pwave; f < Tv; f += 4) {               // dalpha[f] = <dctx, V[f, b, :]>: one wave per frame
-                const float* vp = g.Vt + ((size_t)f * M + brow) * H;
-                float s = 0.f;
-                for (int q = lane; q < (H >> 2); q += 64) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(vp + 4 * q), d = *reinterpret_cast<const f32x4*>(dcl + 4 * q);
-                    s += d[0] * x[0] + d[1] * x[1] + d[2] * x[2] + d[3] * x[3];
-                }
+            if (aregs) {
+                // dalpha[f] = <dctx, V[f, b, :]>: every thread's four columns of every frame, then one reduction over the workgroup
+                float part[TVR];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (lane == 0) dal[f] = s;
+                for (int f = 0; f < TVR; ++f) {
+                    float s = dense[0] * vR[f][0] + dense[1] * vR[f][1] + dense[2] * vR[f][2] + dense[3] * vR[f][3];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                    part[f] = s;
+                }
+                __syncthreads();                                // (cq: free between two query products)
+                if (lane == 0) {
+#pragma unroll
+                    for (int f = 0; f < TVR; ++f) cq[pwave * 8 + f] = part[f];
+                }
+                __syncthreads();
+                AB_STAMP(6);                                   // dctx wait + load
+                if (tid < Tv) dal[tid] = (cq[tid] + cq[8 + tid]) + (cq[16 + tid] + cq[24 + tid]);
+            } else {
+                if (qok) *reinterpret_cast<f32x4*>(dcl + 4 * q4) = dense;
+                __syncthreads();
+                AB_STAMP(6);                                   // dctx wait + load
+                for (int f = pwave; f < Tv; f += 4) {           // dalpha[f] = <dctx, V[f, b, :]>: one wave per frame
+                    const float* vp = g.Vt + ((size_t)f * M + brow) * H;
+                    float s = 0.f;
+                    for (int q = lane; q < (H >> 2); q += 64) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(vp + 4 * q), d = *reinterpret_cast<const f32x4*>(dcl + 4 * q);
+                        s += d[0] * x[0] + d[1] * x[1] + d[2] * x[2] + d[3] * x[3];
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                    if (lane == 0) dal[f] = s;
+                }
             }
             __syncthreads();
+            AB_STAMP(7);                                       // dalpha dots
             if (tid == 0) {
                 if (g.reg_coef && (g.reg_m - g.asum[(size_t)t * M + brow]) > 0.f) {
                     const int n8 = Tv < 8 ? Tv : 8;
@@ -271,8 +326,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int f = 0; f < Tv; ++f) del[f] = all_[f] * (dal[f] - dot);
             }
             __syncthreads();
+            AB_STAMP(8);                                       // de
             if (qok) {
                 f32x4 accq = {0.f, 0.f, 0.f, 0.f}, dwl = {0.f, 0.f, 0.f, 0.f};
+                if (aregs) {
+#pragma unroll
+                    for (int f = 0; f < TVR; ++f)
+                        if (f < Tv) {
+                            const float d = del[f], alt = all_[f];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float Tn = dm_tanhf(hv[i] + pR[f][i]);
+                                const float s_ = d * wh[i] * (1.f - Tn * Tn);
+                                accq[i] += s_;
+                                dwl[i] += d * Tn;
+                                dPR[f][i] += s_;
+                                dVR[f][i] += alt * dense[i];
+                            }
+                        }
+                } else
                 for (int f0 = 0; f0 < Tv; f0 += 4) {
                     f32x4 pv[4], op[4], ov[4];
 #pragma unroll
@@ -303,28 +375,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         }
                 }
                 if (t > 0) {
-                    // dhWa_t: the fragment-order image first (everybody's query product waits for it), then the row-major history
-                    const int tile = brow >> 4, rr = brow & 15;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int k = 4 * q4 + i;
-                        const size_t off = ((size_t)(tile * NG + (k >> 4)) * 64 + (size_t)((k & 3) * 16 + rr)) * 4 + ((k & 15) >> 2);
-                        __hip_atomic_store((gu32*)(g.qimg + off), __float_as_uint(accq[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    *reinterpret_cast<f32x4*>(g.dhWa + (size_t)t * g.dhwa_tstride + rowoff) = accq;
+                    *reinterpret_cast<f32x4*>(dcl + 4 * q4) = accq;                 // staged: regrouped into fragment slots below
+                    *reinterpret_cast<f32x4*>(g.dhWa + (size_t)t * g.dhwa_tstride + rowoff) = accq;      // the row-major history
                 }
-                atomicAdd(g.dw + 4 * q4, dwl[0]); atomicAdd(g.dw + 4 * q4 + 1, dwl[1]); atomicAdd(g.dw + 4 * q4 + 2, dwl[2]); atomicAdd(g.dw + 4 * q4 + 3, dwl[3]);
+                dwR[0] += dwl[0]; dwR[1] += dwl[1]; dwR[2] += dwl[2]; dwR[3] += dwl[3];
             }
-            if (t > 0) gs.arrive_one(cntH, tid);
+            if (t > 0) {
+                // dhWa_t -> the fragment-order image as whole 16-byte slots: thread (group j = tid / 4, kq = tid % 4) takes k = 16 j + 4 e + kq
+                __syncthreads();
+                const int j = tid >> 2, kq = tid & 3;
+                if (16 * j < H) {
+                    u32x4v wv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wv[e] = __float_as_uint(16 * j + 4 * e + kq < H ? dcl[16 * j + 4 * e + kq] : 0.0f);
+                    const __amdgpu_buffer_rsrc_t rsQi = __builtin_amdgcn_make_buffer_rsrc(g.qimg, 0, 4 * NG * 1024, 0x00020000);
+                    bstore16_sc1(rsQi, wv, (int)((((size_t)((brow >> 4) * NG + j) * 64 + (size_t)(kq * 16 + (brow & 15))) * 4) * 4), 0);
+                }
+                gh.arrive_as(brow, tid);
+            }
+            AB_STAMP(9);                                       // main loop + dhWa publish
         }
         // ---- (Q) dq_t = dhWa_t @ Wa^T for this workgroup's own tile (row tile `gate`, its 16 units): K cut over the four waves
         if (t > 0) {
-            gs.wait_one(cntH, (unsigned)(M * (int)(it + 1u)), pwave, lane);
+            gh.wait_all(it, pwave, lane);
+            AB_STAMP(10);                                      // dhWa wait
             const float* qt = g.qimg + (size_t)gate * NG * 256 + (size_t)(QG * pwave) * 256;
             const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qt), 0, QG * 1024, 0x00020000);
             const int vq = gate * 16 < M ? lane * 16 : (int)0x80000000u;
             f32x4 aq[QG];
             static_for<0, QG>([&](auto j_) { constexpr int j = decltype(j_)::value; aq[j] = bload16_sc1(rsQ, vq, j * 1024); });
+            // all 16 fragments first: left to its own waits hipcc interleaved them with the MFMAs in a way that cost 2.4 us here (stamps)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            AB_STAMP(12);                                      // query product: fragments landed
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
             static_for<0, QG>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
@@ -333,12 +415,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][2], wa[4 * j + 2], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][3], wa[4 * j + 3], c1, 0, 0, 0);
             });
+#ifdef S2VT_AC_STAMP
+            asm volatile("" : "+v"(c0), "+v"(c1));
+            AB_STAMP(13);                                      // (dev) query product: MFMAs
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) cq[pwave * 256 + (lq * 4 + r) * 16 + l15] = c0[r] + c1[r];
             __syncthreads();
             dq = (cq[tid] + cq[256 + tid]) + (cq[512 + tid] + cq[768 + tid]);
+            AB_STAMP(11);                                      // query product
         }
     }
+    if (roleA && aqok) {
+        atomicAdd(g.dw + 4 * tid, dwR[0]); atomicAdd(g.dw + 4 * tid + 1, dwR[1]); atomicAdd(g.dw + 4 * tid + 2, dwR[2]); atomicAdd(g.dw + 4 * tid + 3, dwR[3]);
+    }
+    if (aregs && aqok) {
+#pragma unroll
+        for (int f = 0; f < TVR; ++f)
+            if (f < Tv) {
+                const size_t o = ((size_t)f * M + brow) * H + 4 * tid;
+                f32x4 a0 = *reinterpret_cast<const f32x4*>(g.dP + o), a1 = *reinterpret_cast<const f32x4*>(g.dVt + o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a0[i] += dPR[f][i]; a1[i] += dVR[f][i]; }
+                *reinterpret_cast<f32x4*>(g.dP + o) = a0;
+                *reinterpret_cast<f32x4*>(g.dVt + o) = a1;
+            }
+    }
+#ifdef S2VT_AC_STAMP
+    {
+        const int nact = 4 * g.ncg;
+        if (tid == 0 && (lin == 0 || lin == nact / 2 || lin == nact - 1)) {
+            const int slot = lin == 0 ? 0 : (lin == nact - 1 ? 2 : 1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) atomicAdd(&ab_stamp_acc[slot * 16 + i], st_acc[i]);
+        }
+    }
+#endif
 }
 
 struct ABCfg { int ng; void (*fn)(const AttnBwdChainKArgs); const char* name; };
@@ -393,7 +505,7 @@ void attn_bwd_chain_scratch(int H, size_t* img_floats, size_t* ex_floats, size_t
     *img_floats = (size_t)(8 + 1) * 4 * ng * 256;               // 2 parities x 4 gate images of dz + the dhWa image
     *ex_floats = (size_t)ncg * 4 * 8 * 256;
     *row_floats = (size_t)64 * H;
-    *sync_bytes = 2 * kChainSyncBytes + 128 + (size_t)ncg * 128;
+    *sync_bytes = 3 * kChainSyncBytes + (size_t)ncg * 128;
 }
 
 hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st)
@@ -448,3 +560,14 @@ hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st)
 }
 
 }  // namespace s2vt
+
+#ifdef S2VT_AC_STAMP
+// dev build only: per-phase clock sums of attn_bwd_chain_kernel (3 workgroups x 16 phases), read and reset (tools/ab_stamp.py)
+extern "C" int s2vt_ab_stamp_read(unsigned long long* out48)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(s2vt::ab_stamp_acc), 48 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    unsigned long long z[48] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(s2vt::ab_stamp_acc), z, sizeof(z)) == hipSuccess ? 0 : -4;
+}
+#endif

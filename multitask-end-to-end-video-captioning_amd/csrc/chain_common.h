@@ -83,6 +83,13 @@ struct GridSync {
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(sync + (blockIdx.x & (kShards - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the same for a hand-off whose arrivers are a SUBSET of the grid numbered 0 .. nwg-1 by `id` (not by blockIdx)
+    __device__ __forceinline__ void arrive_as(int id, int tid)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(sync + (id & (kShards - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __device__ __forceinline__ void wait_all(unsigned arrival, int pwave, int lane)
     {
         if (pwave == 0 && !dead) {

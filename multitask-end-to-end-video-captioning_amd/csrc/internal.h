@@ -220,7 +220,7 @@ struct AttnChainLaunch {
     float* img;                                         // attn_chain_scratch_floats(H) floats, 16-byte aligned
     unsigned* sync;                                     // kAttnChainSyncBytes
 };
-constexpr size_t kAttnChainSyncBytes = kChainSyncBytes + 256;
+constexpr size_t kAttnChainSyncBytes = 3 * kChainSyncBytes;
 bool attn_chain_eligible(int B, int H, int Tv);       // the persistent form serves this shape on this device (S2VT_ACHAIN != 0, no hold / fault)
 size_t attn_chain_scratch_floats(int H);
 hipError_t launch_attn_chain(const AttnChainLaunch& a, hipStream_t st);
