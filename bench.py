@@ -139,12 +139,14 @@ def kernel_signature():
     return h.hexdigest()[:16]
 
 
-def stored_traffic(kernel_class, name):
+def stored_traffic(kernel_class, name, workload="rl"):
     """HBM bytes per launch of (class:tile) from the newest stamped PMC summary under profiles/ (2*FETCH_SIZE +
-    WRITE_SIZE, separate --pmc passes, tools/collect_pmc.sh), or None when there is none for THIS build of the kernels."""
+    WRITE_SIZE, separate --pmc passes, tools/collect_round.sh), or None when there is none for THIS build of the kernels.
+    A workload's own summary (<tag>_pmc_traffic_<workload>.json: the attention workloads) is looked at first."""
     prof = os.path.join(ROOT, "profiles")
     sig = kernel_signature()
-    for f in sorted((x for x in os.listdir(prof) if x.endswith("_pmc_traffic.json")), reverse=True):
+    own = sorted((x for x in os.listdir(prof) if x.endswith(f"_pmc_traffic_{workload[:9]}.json")), reverse=True)
+    for f in own + sorted((x for x in os.listdir(prof) if x.endswith("_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(os.path.join(prof, f)))
         except Exception:
@@ -432,8 +434,9 @@ def main():
             cls = {0: "contraction+store", 1: "fused LSTM cell (4-gate GEMM + pointwise epilogue)", 2: "vocab logits + Gumbel-max pick",
                    3: "weight-gradient TN contraction", 4: "contraction+store, W^T operand (backward data gradients)",
                    5: "persistent LSTM recurrence", 6: "persistent LSTM backward recurrence", 7: "attention score + softmax + context",
-                   8: "attention backward"}.get(dom["kernel_class"], "?")
-            traffic, traffic_src = stored_traffic(dom["kernel_class"], dom["name"])
+                   8: "attention backward", 9: "persistent attention recurrence (query, score/softmax/context, LSTM3)",
+                   10: "persistent attention backward recurrence"}.get(dom["kernel_class"], "?")
+            traffic, traffic_src = stored_traffic(dom["kernel_class"], dom["name"], args.workload)
             # flops the contraction kernels actually executed per step (hoisting, LSTM1 once per video and sampler-state
             # reuse execute fewer than the algorithmic count), from the warm-up table
             executed = sum(r["total_flops"] for r in warm_rows) / max(args.warmup, 1) if warm_rows else None

@@ -301,8 +301,9 @@ hipError_t launch_softmax_nll(float* logits, int ld, int R, int V, const int32_t
 // build_generator's word choice AS THE REFERENCE WRITES IT (tf_s2vt.py:208-209, the quirk switch of SURVEY A9):
 //   p = exp(l) / sum_n exp(l[n])   -- no max shift, fp32 --   then argmax(p), first maximum wins, NaN never wins.
 // A logit >= 88.72 overflows exp to +inf, the sum to +inf, that entry to inf/inf = NaN and every other to 0: the
-// result is index 0 (<eos>), not argmax(l).  Fixed summation order (the oracle restates it): thread t adds elements
-// t, t+256, ... ascending; xor-butterfly 32..1 inside each wave; then ((w0 + w1) + w2) + w3.  One workgroup per row.
+// result is index 0 (<eos>), not argmax(l).  Summation order = the numeric contract's ("reductions that
+// decide a token"): thread t adds elements t, t+256, ... ascending; xor-butterfly 32..1 inside each wave; then
+// ((w0 + w1) + w2) + w3.  One workgroup per row.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_unshifted_argmax_kernel(const float* logits, int ld, int V, int32_t* ids,
                                                                        float* probs)

@@ -364,9 +364,10 @@ ORC_API void orc_row_losses(const float* logits, int64_t ldl, int64_t M, int64_t
 /* ------------------------------------------------------------------------------------
  * build_generator's word choice as written (tf_s2vt.py:208-209): probs = exp(l) / reduce_sum(exp(l)) with NO max shift,
  * then tf.argmax.  fp32; an overflowing logit gives inf / inf = NaN; argmax keeps the FIRST maximum and a NaN never
- * compares greater, so an all-NaN / NaN-and-zeros row yields index 0.  The sum runs in the product kernel's fixed
- * order (256 strided partial sums, xor butterfly inside each group of 64, then ((g0 + g1) + g2) + g3) so that the
- * probabilities are comparable bit for bit.
+ * compares greater, so an all-NaN / NaN-and-zeros row yields index 0.  TF's reduce_sum has no defined order; the
+ * numeric contract ("reductions that decide a token") gives it one -- 256 strided partial sums
+ * (element v into partial v mod 256, ascending), an xor butterfly (32, 16, .. 1) inside each group of 64 partials, then
+ * ((g0 + g1) + g2) + g3 -- and this function and the product kernel both implement that definition.
  * ---------------------------------------------------------------------------------- */
 ORC_API void orc_softmax_unshifted_argmax(const float* logits, int64_t ldl, int64_t M, int64_t V, int32_t* ids, float* probs)
 {

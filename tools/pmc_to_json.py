@@ -45,6 +45,16 @@ def prof_key(kname):
     if m:
         ng, tmw, nc = [int(x) for x in m.groups()]
         return f"6:bchain{2 if nc == 2 else ''}(ng{ng},m{384 if nc == 2 else tmw * 64})"
+    m = re.search(r"attn_chain_kernel<(\d+)>", kname)
+    if m:
+        return f"9:attn_chain(ng{m.group(1)})"
+    m = re.search(r"attn_bwd_chain_kernel<(\d+)>", kname)
+    if m:
+        return f"10:attn_bchain(ng{m.group(1)})"
+    if "attn_fwd_kernel" in kname:
+        return "7:attn_fwd(score+softmax+ctx)"
+    if "attn_bwd_kernel" in kname:
+        return "8:attn_bwd"
     return "x:" + re.sub(r"^void ", "", kname).split("(")[0][-48:]
 
 
