@@ -367,6 +367,11 @@ size_t s2vt_attn_workspace_bytes(const s2vt_dims* d, int32_t B);
 int s2vt_attn_teacher_forced_fwd(const s2vt_dims* d, const s2vt_attn_params* p, const float* video, int32_t B, const int32_t* caption,
                                  int32_t caption_steps, float keep, uint64_t seed, const int32_t* video_id, const int32_t* sample_id,
                                  float* logits, float* alphas_out, void* workspace, size_t workspace_bytes, s2vt_stream stream);
+/* The loss kernels' inputs from what build_model is fed: caption [B, Tc] int32 and caption_mask [B, Tc] (row-major) -> time-major
+ * target_tm[t*B + b], coef_tm[t*B + b] = mask[b, t] (cross_entropy * caption_mask[:, i], :145), reg_tm = beta * mask (NULL: not wanted),
+ * *mask_sum = sum(mask) (:149).  One launch. */
+int s2vt_attn_loss_inputs(const int32_t* caption, const float* mask, int32_t B, int32_t Tc, float beta, int32_t* target_tm, float* coef_tm,
+                          float* reg_tm, float* mask_sum, s2vt_stream stream);
 /* loss = (sum_r coef[r] * nll[r] + sum_r reg_coef[r] * max(0, reg_m - sum(alpha[0:8])[r])) / *mask_sum_local  (:144-149; reg_coef =
  * beta * mask time-major or NULL, reg_m = m; the first-8-frames sums are the ones the forward left in the workspace);
  * *gscale = 1 / *mask_sum_global; *sumsq = 0.  One launch, after s2vt_attn_teacher_forced_fwd on the same workspace. */

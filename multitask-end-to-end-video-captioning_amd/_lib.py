@@ -102,6 +102,7 @@ SIGNATURES = {
     "s2vt_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "s2vt_attn_workspace_bytes": (_sz, [_DP, _i32]),
     "s2vt_attn_teacher_forced_fwd": (C.c_int, [_DP, _AP, _vp, _i32, _vp, _i32, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "s2vt_attn_loss_inputs": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_attn_step_scalars": (C.c_int, [_vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _DP, _i32, _vp, _sz, _vp]),
     "s2vt_attn_bptt_bwd": (C.c_int, [_DP, _AP, _AP, _vp, _i32, _vp, _i32, _vp, _f32, _f32, _u64, _vp, _vp, _vp, _sz, _vp]),
     "s2vt_attn_decode_greedy": (C.c_int, [_DP, _AP, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),

@@ -135,12 +135,13 @@ class Attention_Caption_Generator:
         vid, sid = self._row_ids(B, video_base)
         seed = self.dropout_seed + 104729 * self.global_step
         logits, _, ws = ops.attn_teacher_forced_fwd(self.dims, self.store.params, video, cap, keep, seed, vid, sid, steps=steps)
-        coef = mask.t().contiguous().view(-1)[:R]                      # time-major: cross_entropy * caption_mask[:, i] (:145)
-        target = cap.t().contiguous().view(-1)[:R]
+        # time-major targets / coefficients (cross_entropy * caption_mask[:, i], :145), the regulariser's beta * mask (:123,144: identically
+        # zero while Tv <= 8 -- the softmax sums to 1 > m) and sum(mask): one library launch
+        want_reg = self.n_video_lstm_steps > 8 and self.beta != 0.0
+        target, coef, reg, msum = ops.attn_loss_inputs(cap, mask, self.beta, want_reg)
+        target, coef = target[:R], coef[:R]
+        reg = reg[:R] if reg is not None else None
         nll, _ = ops.softmax_nll_fwd_bwd(logits, target, coef, 0.0)    # logits <- coef * (softmax - onehot)
-        # regularizer = beta * max(0, m - sum(alphas[:, 0:8])) * caption_mask[:, i] (:123,144): zero while Tv <= 8 (the softmax sums to 1 > m)
-        reg = (coef * self.beta) if (self.n_video_lstm_steps > 8 and self.beta != 0.0) else None
-        msum = mask.sum().reshape(1)
         return dict(video=video, B=B, steps=steps, dlogits=logits, ws=ws, coef=coef, nll=nll, reg=reg, msum=msum, keep=keep, seed=seed,
                     vid=vid, sid=sid)
 

@@ -132,6 +132,31 @@ __global__ __launch_bounds__(256) void attn_step_scalars_kernel(const float* coe
     }
 }
 
+// caption [B, Tc] / mask [B, Tc] (row-major, as fed) -> what the loss kernels take, time-major: target_tm[t*B + b], coef_tm[t*B + b] =
+// mask[b, t], reg_tm = beta * mask (optional), *mask_sum = sum(mask): ONE launch of one workgroup (deterministic sum) instead of
+// four tensor-library kernels per step.
+__global__ __launch_bounds__(256) void attn_loss_inputs_kernel(const int32_t* cap, const float* mask, int B, int Tc, float beta, int32_t* target_tm,
+                                                               float* coef_tm, float* reg_tm, float* mask_sum)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B * Tc; i += 256) {
+        const int t = i / B, b = i % B;
+        const float m = mask[b * Tc + t];
+        target_tm[i] = cap[b * Tc + t];
+        coef_tm[i] = m;
+        if (reg_tm) reg_tm[i] = beta * m;
+        s += (double)m;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *mask_sum = (float)sh[0];
+}
+
 // Saved activations + backward scratch, carved from the caller's buffer.  Everything is time-major ([step][row]), so a
 // truncated unroll (caption_steps < Tc) is the leading part of the full one's layout.
 struct AttnWs {
@@ -309,6 +334,15 @@ int s2vt_attn_teacher_forced_fwd(const s2vt_dims* d, const s2vt_attn_params* p, 
         if (cl.add(alphas_out, w.alpha, (size_t)Tc * Tv * B * 4)) HIP_TRY(launch_copy_regions(cl, st));
         else HIP_TRY(hipMemcpyAsync(alphas_out, w.alpha, (size_t)Tc * Tv * B * 4, hipMemcpyDeviceToDevice, st));
     }
+    return S2VT_OK;
+}
+
+int s2vt_attn_loss_inputs(const int32_t* caption, const float* mask, int32_t B, int32_t Tc, float beta, int32_t* target_tm, float* coef_tm,
+                          float* reg_tm, float* mask_sum, s2vt_stream stream)
+{
+    if (!caption || !mask || !target_tm || !coef_tm || !mask_sum || B <= 0 || Tc <= 0) return S2VT_E_BADARG;
+    hipLaunchKernelGGL(attn_loss_inputs_kernel, dim3(1), dim3(256), 0, S(stream), caption, mask, B, Tc, beta, target_tm, coef_tm, reg_tm, mask_sum);
+    HIP_TRY(hipGetLastError());
     return S2VT_OK;
 }
 

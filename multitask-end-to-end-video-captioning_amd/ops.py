@@ -484,6 +484,21 @@ def attn_teacher_forced_fwd(dims: Dims, params: AttnParams, video, caption, keep
     return logits, al, ws
 
 
+def attn_loss_inputs(caption, mask, beta=0.0, want_reg=False):
+    """caption [B,Tc] int32, mask [B,Tc] fp32 (device) -> (target_tm [Tc*B] int32, coef_tm [Tc*B], reg_tm | None, mask_sum [1]): one launch."""
+    _chk_f32(mask)
+    assert caption.is_cuda and caption.dtype == torch.int32 and caption.is_contiguous() and mask.is_contiguous() and mask.shape == caption.shape
+    B, Tc = caption.shape
+    dev = caption.device
+    tgt = torch.empty(B * Tc, dtype=torch.int32, device=dev)
+    coef = torch.empty(B * Tc, dtype=torch.float32, device=dev)
+    reg = torch.empty(B * Tc, dtype=torch.float32, device=dev) if want_reg else None
+    msum = torch.empty(1, dtype=torch.float32, device=dev)
+    check(lib().s2vt_attn_loss_inputs(_ptr(caption), _ptr(mask), B, Tc, float(beta), _ptr(tgt), _ptr(coef), _ptr(reg), _ptr(msum), _stream()),
+          "s2vt_attn_loss_inputs")
+    return tgt, coef, reg, msum
+
+
 def attn_step_scalars(dims: Dims, B: int, ws, coef, nll, reg_coef, reg_m, msum_local, gsum_global, loss, gscale, sumsq):
     _chk_f32(coef, nll, reg_coef, msum_local, gsum_global, loss, gscale, sumsq)
     check(lib().s2vt_attn_step_scalars(_ptr(coef), _ptr(nll), coef.numel(), _ptr(reg_coef), float(reg_m), _ptr(msum_local), _ptr(gsum_global),
