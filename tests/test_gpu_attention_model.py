@@ -199,3 +199,64 @@ def test_attention_replay_train_statements(gpu, oracle):
     # checkpoint names are the reference's TF variable names
     sd = model.state_dict()
     assert "s2vt/LSTM3/basic_lstm_cell/weights" in sd and "embed_att_Wa" in sd and sd["embed_att_w"].shape == (H, 1)
+
+
+@pytest.mark.parametrize("D,V,H,Tv,Tc,B,keep", [
+    (32, 101, 128, 5, 4, 32, 0.9),      # NG = 8 at its largest H; every workgroup of the forward grid is an attention workgroup
+    (32, 101, 144, 3, 3, 20, 1.0),      # NG = 64 at its smallest H (9 k-groups of 64), partial last row tile
+    (24, 67, 256, 6, 3, 64, 0.9),       # B = H / 4: query and attention roles overlap on 16 workgroups; two frame chunks
+    (24, 67, 1024, 2, 2, 33, 0.9),      # every CU, no padded k-group, 3 row tiles (one of them a single row)
+    (16, 53, 64, 1, 5, 1, 1.0),         # one row, one frame
+    (16, 53, 1000, 11, 2, 16, 0.5),     # three frame chunks at the bench's H
+])
+def test_attention_persistent_recurrences_equal_per_step_launches(gpu, oracle, D, V, H, Tv, Tc, B, keep):
+    """attn_chain.hip / attn_chain_bwd.hip against the per-step launches (ops.chain_hold() selects them): logits, alphas and EVERY saved
+    activation the backward reads bit-identical; gradients equal to the noise of the order-free reductions.  Shapes chosen at the edges of
+    the persistent forms (role overlap, k-group padding, partial row tiles, frame chunking)."""
+    import torch
+    from s2vt_amd import attention as A
+    ops = gpu
+    rng = np.random.default_rng(H + Tv)
+    m = A.Attention_Caption_Generator(D, V, H, B, Tv, Tc, keep, seed=5, m=0.5 if Tv <= 8 else 0.9)
+    for k in ("lstm3_b", "embed_att_ba", "embed_nn_bp", "embed_word_b", "encode_image_b"):
+        m.p[k].copy_(torch.as_tensor(rng.uniform(-.1, .1, tuple(m.p[k].shape)).astype(np.float32)))
+    video = torch.as_tensor(np.abs(rng.standard_normal((B, Tv, D)) * 0.5).astype(np.float32)).cuda()
+    cap = rng.integers(0, V, (B, Tc)).astype(np.int32)
+    mask = (rng.random((B, Tc)) < 0.8).astype(np.float32); mask[:, 0] = 1
+    capd = torch.as_tensor(cap).cuda()
+    vid, sid = m._row_ids(B)
+
+    def run(hold):
+        ops.prof_filter(-1, -1); ops.prof_enable(True)
+        ctx = ops.chain_hold() if hold else None
+        if ctx: ctx.__enter__()
+        try:
+            lg, al, ws = ops.attn_teacher_forced_fwd(m.dims, m.store.params, video, capd, keep, 99, vid, sid, want_alphas=True)
+            lg, al, wsc = lg.clone(), al.clone(), ws.clone()
+            m.global_step = 0
+            st = m.xe_update(video, cap, mask, lr=0.0, keep=keep, active_steps=None)
+            grads = {k: m.store.g[k].clone() for k in m.store.names}
+            loss = float(st.loss)
+        finally:
+            if ctx: ctx.__exit__(None, None, None)
+        torch.cuda.synchronize()
+        classes = {r["kernel_class"] for r in ops.prof_collect()}; ops.prof_enable(False)
+        return lg, al, wsc, grads, loss, classes
+    pers = run(False)
+    step = run(True)
+    assert 9 in pers[5] and 10 in pers[5], pers[5]              # the persistent forms really ran ...
+    assert 9 not in step[5] and 10 not in step[5], step[5]      # ... and did not under the hold
+    assert torch.equal(pers[0], step[0]) and torch.equal(pers[1], step[1])
+    # the saved activations: everything up to and including the output layer Y lies at the front of the workspace, in carve order
+    n = lambda *d: (int(np.prod(d)) * 4 + 255) & ~255
+    front = sum([n(Tv * B), n(Tc * B), n(Tc * B), n(B), n(B), n(Tv * B * H), n(Tv * B * H), n(Tc * B * H), n(Tc * Tv * B), n(Tc * B), n(Tc * B * H),
+                 n(Tc * B * 4 * H), n((Tc + 1) * B * H), n((Tc + 1) * B * H), n((Tc + 1) * B * H), n(Tc * B * H)])
+    skip = sum([n(Tv * B), n(Tc * B), n(Tc * B), n(B), n(B), n(Tv * B * H), n(Tv * B * H)]) + n(B * H)    # hWa slot 0 is never written (zero query)
+    a, b = pers[2][:front], step[2][:front]
+    hwa0 = sum([n(Tv * B), n(Tc * B), n(Tc * B), n(B), n(B), n(Tv * B * H), n(Tv * B * H)])
+    assert torch.equal(a[:hwa0], b[:hwa0]) and torch.equal(a[hwa0 + B * H * 4:], b[hwa0 + B * H * 4:])
+    assert abs(pers[4] - step[4]) <= 1e-6 * max(1.0, abs(step[4]))
+    for k in m.store.names:
+        ref = step[3][k]
+        assert float((pers[3][k] - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-10, k
+    assert ops.chain_timeouts() == 0
