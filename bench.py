@@ -60,6 +60,12 @@ WORKLOADS = {
                          "a random-initialised model never emits <eos>), the update teacher-forces synthetic captions of MSVD-like lengths "
                          "(1 + min(Poisson(6), 18) words + <eos>, ~40 % of the positions unmasked) with their mask on the host, as train_rl has it: "
                          "padding steps are not unrolled, the vocabulary-sized and LSTM2-gradient products run on the unmasked positions (exact)"),
+    "rl_msvd_eos": dict(B=64, K=5, seqfwd=lambda B, K: (4 * K + 1) * B, tokens=lambda B, K: K * B * TC,
+                        metric="sampled caption tokens/sec (REINFORCE step, samples of MSVD-like lengths, early-exit sampler)",
+                        desc="rl_msvd with a sampler that behaves like a trained policy's as well: the <eos> logit bias is raised (bias_init_vector's job in the "
+                             "reference) so that samples end after ~7 words, and the opt-in early-exit sampler (s2vt_sample_ex, S2VT_SAMPLE_STOP_AT_EOS) drops a row "
+                             "from the decode loop at its first <eos> (ids up to it bit-identical; the reference samples all T_cap steps and masks afterwards); "
+                             "tokens/s still counts K*B*T_cap nominal positions per step"),
     "xe": dict(B=64, K=0, seqfwd=lambda B, K: 3 * B, tokens=lambda B, K: B * TC,
                metric="caption tokens/sec (XE train step)",
                desc="tf_s2vt XE train step (BASELINE configs[1]): B=64, T_vid=5, T_cap=20, d=1536, E=500, H=1000, |V|=12000; "
@@ -269,7 +275,12 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
             return mdl.reinforce_update(video, s, None, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,      # mask None: PG mask from the ids, in the library
                                         reuse_sampler_state=True)    # LSTM1 trajectory of the sampler pass (same videos, same weights)
         return step
-    if workload == "rl_msvd":
+    if workload in ("rl_msvd", "rl_msvd_eos"):
+        stop = workload == "rl_msvd_eos"
+        if stop:
+            mdl.store.p["embed_word_b"][0] = 7.5          # P(<eos>) per step ~ 1/7: samples of MSVD-like lengths from random weights
+            if info is not None:
+                info["sampler"] = "stop_at_eos, <eos> bias 7.5"
         rng = np.random.default_rng(4321 + rank)
         N = K * B
         ln = 1 + np.minimum(rng.poisson(6, N), TC - 2)
@@ -283,7 +294,7 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
             info["live_fraction"] = round(float(mask.mean()), 3)
 
         def step(i):
-            mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
+            mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B, stop_at_eos=stop)
             return mdl.reinforce_update(video, capd, mask, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,
                                         reuse_sampler_state=True)
         return step
@@ -426,7 +437,7 @@ def main():
         else:
             f_seq = 7.68e6 + 5 * 28e6 + tc_eff * 52e6
         flops_step = f_seq * wl["seqfwd"](B, K)
-        dense_defined = args.workload != "rl_msvd"
+        dense_defined = args.workload not in ("rl_msvd", "rl_msvd_eos")
         dom = max(rows, key=lambda r: r["total_ms"]) if rows else None
         roof = None
         if dom:
@@ -440,6 +451,8 @@ def main():
             # flops the contraction kernels actually executed per step (hoisting, LSTM1 once per video and sampler-state
             # reuse execute fewer than the algorithmic count), from the warm-up table
             executed = sum(r["total_flops"] for r in warm_rows) / max(args.warmup, 1) if warm_rows else None
+            if args.workload == "rl_msvd_eos":
+                executed = None        # (the launch profiler prices a live-row launch at its full row count: only the device knows how many rows ran)
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": f"{cls}, tile {dom['name']}", "launches": dom["launches"],
@@ -486,6 +499,8 @@ def main():
             out["config"]["unrolled_caption_steps"] = info["active_steps"]      # of TC: behind the longest caption all is padding
         if "live_fraction" in info:
             out["config"]["unmasked_positions"] = info["live_fraction"]
+        if "sampler" in info:
+            out["config"]["sampler"] = info["sampler"]
         if world == 1 and not args.no_cpu_baseline and args.workload == "rl":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

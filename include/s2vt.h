@@ -179,6 +179,15 @@ size_t s2vt_sample_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t K, int
 int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t K,
                 int32_t with_greedy, uint64_t seed, int32_t video_base, int32_t* ids_out, void* workspace,
                 size_t workspace_bytes, s2vt_stream stream);
+/* s2vt_sample with flags.  S2VT_SAMPLE_STOP_AT_EOS (opt-in; NOT what the reference does, whose samplers run all Tc steps for every row,
+ * reinforcement_multisampling_tf_s2vt.py:318-337): a row leaves the decode loop once it has picked <eos> = 0 -- every later step's cell
+ * and vocabulary launches cover the rows still sampling only (compact row lists kept on the device, no host round trip) -- and its ids
+ * behind the first <eos> are 0.  Ids up to and including the first <eos> are bit-identical to s2vt_sample's, and those are the only
+ * positions the objective looks at (the mask of cider_evaluation.py:145-172 ends there). */
+#define S2VT_SAMPLE_STOP_AT_EOS 1
+int s2vt_sample_ex(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t K, int32_t with_greedy,
+                   uint64_t seed, int32_t video_base, int32_t flags, int32_t* ids_out, void* workspace, size_t workspace_bytes,
+                   s2vt_stream stream);
 
 /* ---- teacher-forced unroll: build_model (tf_s2vt.py:90-153) / build_loss
  * (reinforcement_multisampling_tf_s2vt.py:227-292) forward --------------------------------------

@@ -78,6 +78,7 @@ SIGNATURES = {
     "s2vt_frame_embed_fwd": (C.c_int, [_DP, _PP, _vp, _i32, _vp, _vp]),
     "s2vt_sample_workspace_bytes": (_sz, [_DP, _i32, _i32, _i32]),
     "s2vt_sample": (C.c_int, [_DP, _PP, _vp, _i32, _i32, _i32, _u64, _i32, _vp, _vp, _sz, _vp]),
+    "s2vt_sample_ex": (C.c_int, [_DP, _PP, _vp, _i32, _i32, _i32, _u64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "s2vt_train_workspace_bytes": (_sz, [_DP, _i32, _i32]),
     "s2vt_teacher_forced_fwd": (C.c_int, [_DP, _PP, _vp, _i32, _i32, _vp, _f32, _u64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "s2vt_teacher_forced_fwd_reuse": (C.c_int, [_DP, _PP, _vp, _i32, _i32, _vp, _f32, _u64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _i32, _vp]),

@@ -3,6 +3,8 @@
 // contraction kernels live in gemm_mfma.h / fwd.hip.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "api_util.h"
 
 namespace s2vt_api {
@@ -42,13 +44,54 @@ __global__ void sampler_rows_kernel(int32_t* vid, int32_t* sid, int B, int K, in
     sid[i] = (i / B) < K ? i / B : -1;
 }
 
-// packed [T][R] (entries `stride` words apart) -> ids [R][T]
+// packed [T][R] (entries `stride` words apart) -> ids [R][T].  A word that was never written (stop-at-<eos> mode: the row had
+// left the loop) reads as <eos> = 0.
 __global__ void unpack_ids_kernel(const unsigned long long* packed, int32_t* ids, int R, int T, int stride)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * T) return;
     const int m = i / T, t = i % T;
-    ids[i] = (int32_t)(~(uint32_t)packed[((size_t)t * R + m) * stride]);
+    const unsigned long long w = packed[((size_t)t * R + m) * stride];
+    ids[i] = w ? (int32_t)(~(uint32_t)w) : 0;
+}
+
+// stop-at-<eos> mode: the rows still sampling at step t from those of step t - 1 and the words they just picked (a row leaves
+// once it has picked <eos> = 0; order preserved).  One workgroup; step 0: every row.
+__global__ __launch_bounds__(256) void live_rows_kernel(const unsigned long long* picked, int stride, const int32_t* prev, const int32_t* nprev,
+                                                        int32_t* next, int32_t* nnext, int R)
+{
+    __shared__ int cnt[256];
+    __shared__ int base;
+    const int tid = threadIdx.x;
+    if (!picked) {                                              // step 0
+        for (int i = tid; i < R; i += 256) next[i] = i;
+        if (tid == 0) *nnext = R;
+        return;
+    }
+    const int n = *nprev;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + tid;
+        int row = -1, alive = 0;
+        if (i < n) {
+            row = prev[i];
+            alive = (uint32_t)(~(uint32_t)picked[(size_t)row * stride]) != 0u;
+        }
+        cnt[tid] = alive;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {                     // inclusive scan
+            const int v = tid >= o ? cnt[tid - o] : 0;
+            __syncthreads();
+            cnt[tid] += v;
+            __syncthreads();
+        }
+        if (alive) next[base + cnt[tid] - 1] = row;
+        __syncthreads();
+        if (tid == 255) base += cnt[255];
+        __syncthreads();
+    }
+    if (tid == 0) *nnext = base;
 }
 
 }  // namespace
@@ -249,6 +292,7 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
         t.w2_p = c.take<float>((size_t)q.ncg * 4 * q.ngt * 256);
         for (int i = 0; i < 2; ++i) t.himg[i] = c.take<float>((size_t)q.img_tiles * q.hgp * 256);
     }
+    t.live[0] = c.take<int32_t>(R); t.live[1] = c.take<int32_t>(R); t.nlive = c.take<int32_t>(Tc + 1);
     if (w) *w = t;
     return c.off;
 }
@@ -328,7 +372,7 @@ int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, 
 // multinomial row blocks then (with_greedy) one argmax block; the R rows of a video share its out1
 // partial (row % B).  Needs sample_encode's results in the same workspace.
 int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int with_greedy, uint64_t seed, int video_base,
-                  int32_t* ids_out, const SampleWs& w, s2vt_stream stream)
+                  int32_t* ids_out, const SampleWs& w, s2vt_stream stream, int stop_at_eos)
 {
     const int H = d->lstm_dim, E = d->word_dim, V = d->n_words, Tv = d->n_video_lstm_step, Tc = d->n_caption_lstm_step;
     const int R = (K + (with_greedy ? 1 : 0)) * B;
@@ -347,8 +391,8 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
     const size_t enc = (size_t)Tv * B * H;   // where sample_encode left the encoder state: slot Tv of the history
     int cur2 = 0;
     // 257-384 rows: the LSTM2 step runs on fragment-order operands packed once per call (decode4.hip); same chain, same bits
-    const bool loop1 = w.wemb_p && (B & 15) == 0 && decode_loop_eligible(R, H, E, V) && chain_operands_ok(p->embed_word_W, V, w.himg[0]);
-    const bool dec4 = loop1 || (w.wemb_p && decode4_eligible(R, H, E));
+    const bool loop1 = !stop_at_eos && w.wemb_p && (B & 15) == 0 && decode_loop_eligible(R, H, E, V) && chain_operands_ok(p->embed_word_W, V, w.himg[0]);
+    const bool dec4 = !stop_at_eos && (loop1 || (w.wemb_p && decode4_eligible(R, H, E)));
     Dec4Geom q4;
     if (dec4) {
         decode4_geometry(R, H, E, &q4);
@@ -395,13 +439,31 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
         const float* h2p = t == 0 ? w.h2e + enc : w.h2[cur2];
         const float* c2p = t == 0 ? w.c2e + enc : w.c2[cur2];
         const int smod = t == 0 ? B : 0;
+        // stop-at-<eos> mode: the launch covers the rows still sampling (compact index -> row through the live list, their number on
+        // the device); a finished row's state stays where it is, nothing reads it again, its later words are never written (= <eos>)
+        const int* omap = nullptr;
+        const int* mdev = nullptr;
+        int lcfg = -1, pcfg = -1;
+        if (stop_at_eos) {
+            // tiles for a launch whose live-row count only the device knows: small row tiles cost a few % while every row is live
+            // and follow the count down afterwards (dev knobs: S2VT_EOS_LSTM_CFG / S2VT_EOS_PICK_CFG)
+            // -- measured at R = 384, mean length 7 (tools/eos_sweep.sh): cell step on 32-row tiles 2.40 ms per sampler call against 2.79
+            // with the tile the full row count would get (96 rows) and 3.32 for the loop that never stops; the pick's 64 x 96 tile stays
+            static const int lk = [] { const char* e = getenv("S2VT_EOS_LSTM_CFG"); return e ? atoi(e) : 4; }();     // kLstm[4] = gw32x16u
+            static const int pk = [] { const char* e = getenv("S2VT_EOS_PICK_CFG"); return e ? atoi(e) : -1; }();
+            lcfg = R > 64 ? lk : -1; pcfg = pk;
+            hipLaunchKernelGGL(live_rows_kernel, dim3(1), dim3(256), 0, st, t == 0 ? nullptr : w.packed + (size_t)(t - 1) * R * kPickStride, kPickStride,
+                               w.live[(t + 1) & 1], w.nlive + (t > 0 ? t - 1 : 0), w.live[t & 1], w.nlive + t, R);
+            HIP_TRY(hipGetLastError());
+            omap = w.live[t & 1]; mdev = w.nlive + t;
+        }
         ASeg s2[2] = {t == 0 ? make_seg(p->Wemb, E, E, H, 0, w.bos)
                              : make_seg(p->Wemb, E, E, H, 0, nullptr, w.packed + (size_t)(t - 1) * R * kPickStride, kPickStride),
                       make_seg(h2p, H, H, H + E, smod)};
         HIP_TRY(lstm_call(s2, 2, p->lstm2_W, p->lstm2_b, c2p, smod, w.c2[nxt2], w.h2[nxt2], nullptr, nullptr, R, H, 1.0f,
-                          none, 0, -1, st, w.P2 + (size_t)(Tv + t) * 4 * BH, 4 * H, B));
+                          none, 0, lcfg, st, w.P2 + (size_t)(Tv + t) * 4 * BH, 4 * H, B, omap, mdev));
         HIP_TRY(pick_call(w.h2[nxt2], H, p->embed_word_W, p->embed_word_b, R, H, V, ids, t, w.packed + (size_t)t * R * kPickStride,
-                          nullptr, -1, st, kPickStride));
+                          nullptr, pcfg, st, kPickStride, omap, mdev));
         cur2 = nxt2;
     }
     hipLaunchKernelGGL(unpack_ids_kernel, dim3((R * Tc + 255) / 256), dim3(256), 0, st, w.packed, ids_out, R, Tc, kPickStride);
@@ -442,6 +504,24 @@ int s2vt_sample(const s2vt_dims* d, const s2vt_params* p, const float* video, in
     int rc = sample_encode(d, p, video, B, w, stream);
     if (rc != S2VT_OK) return rc;
     return sample_decode(d, p, B, K, with_greedy, seed, video_base, ids_out, w, stream);
+}
+
+int s2vt_sample_ex(const s2vt_dims* d, const s2vt_params* p, const float* video, int32_t B, int32_t K, int32_t with_greedy,
+                   uint64_t seed, int32_t video_base, int32_t flags, int32_t* ids_out, void* workspace, size_t workspace_bytes,
+                   s2vt_stream stream)
+{
+    if (!dims_ok(d) || !sampler_params_ok(p) || !video || !ids_out || !workspace || B <= 0 || K < 0 || (K == 0 && !with_greedy) || (flags & ~1))
+        return S2VT_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return S2VT_E_ALIGN;
+    if (chain_fault()) return S2VT_E_CHAIN_TIMEOUT;
+    const int R = (K + (with_greedy ? 1 : 0)) * B;
+    Carver c(workspace, workspace_bytes);
+    SampleWs w;
+    carve_sample(c, d, B, R, &w);
+    if (!c.ok()) return S2VT_E_WORKSPACE;
+    int rc = sample_encode(d, p, video, B, w, stream);
+    if (rc != S2VT_OK) return rc;
+    return sample_decode(d, p, B, K, with_greedy, seed, video_base, ids_out, w, stream, flags & S2VT_SAMPLE_STOP_AT_EOS);
 }
 
 }  // extern "C"

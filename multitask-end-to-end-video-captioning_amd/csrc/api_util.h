@@ -78,7 +78,7 @@ struct NoiseIds {
 inline hipError_t lstm_call(const ASeg* segs, int nseg, const float* W, const float* b, const float* c_prev, int cprev_rowmod,
                      float* c_new, float* h_new, float* out, float* gates, int M, int H, float keep, const NoiseIds& ids,
                      uint32_t drop_code, int cfg, hipStream_t st, const float* cinit = nullptr, int ldcinit = 0,
-                     int cinit_rowmod = 0)
+                     int cinit_rowmod = 0, const int* omap = nullptr, const int* m_dev = nullptr)
 {
     GemmArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -90,11 +90,13 @@ inline hipError_t lstm_call(const ASeg* segs, int nseg, const float* W, const fl
     a.video_id = ids.video_id; a.sample_id = ids.sample_id;
     a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32);
     a.cinit = cinit; a.ldcinit = ldcinit; a.cinit_rowmod = cinit_rowmod;   // a carried partial chain (hoisted input products)
+    a.omap = omap; a.m_dev = m_dev;                                          // live-row launch (gemm_mfma.h)
     return launch_gemm(a, EPI_LSTM, cfg, st);
 }
 
 inline hipError_t pick_call(const float* A, int lda, const float* W, const float* b, int M, int H, int V, const NoiseIds& ids,
-                     int step, unsigned long long* packed, float* logits_out, int cfg, hipStream_t st, int pick_stride = 1)
+                     int step, unsigned long long* packed, float* logits_out, int cfg, hipStream_t st, int pick_stride = 1,
+                     const int* omap = nullptr, const int* m_dev = nullptr)
 {
     GemmArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -104,6 +106,7 @@ inline hipError_t pick_call(const float* A, int lda, const float* W, const float
     a.video_id = ids.video_id; a.sample_id = ids.sample_id;
     a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32);
     a.step = step; a.pick = packed; a.pick_stride = pick_stride; a.logits_out = logits_out; a.ldc = V;
+    a.omap = omap; a.m_dev = m_dev;
     return launch_gemm(a, EPI_PICK, cfg, st);
 }
 
@@ -189,6 +192,8 @@ struct SampleWs {
     float* chain_abuf;       // persistent-recurrence scratch (chain.hip): fragment images of h + arrival counters
     unsigned* chain_sync;
     float *wemb_p, *w2_p, *himg[2];   // fragment-order operands of the decode loop's LSTM2 step (decode4.hip); NULL when R is outside its range
+    int32_t* live[2];        // stop-at-<eos> mode: the rows still sampling at the current / next step (ascending), ...
+    int32_t* nlive;          // ... and their count per step [Tc + 1], device-resident
 };
 
 // One LSTM recurrence of T steps on M rows: ONE persistent launch when the shape fits (chain_eligible), else T
@@ -200,7 +205,7 @@ hipError_t lstm_recurrence(const float* W, int kw0, const float* bias, const flo
 size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w);
 int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, int B, const SampleWs& w, s2vt_stream stream);
 int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int with_greedy, uint64_t seed, int video_base,
-                  int32_t* ids_out, const SampleWs& w, s2vt_stream stream);
+                  int32_t* ids_out, const SampleWs& w, s2vt_stream stream, int stop_at_eos = 0);
 bool sampler_params_ok(const s2vt_params* p);
 
 inline bool dims_ok(const s2vt_dims* d)

@@ -18,14 +18,20 @@ struct CfgEntry {
     const char* name;
     KernelFn vec, scalar;   // 16-byte vector loads / scalar loads (unaligned or odd shapes)
     int BM, CG, NT, lds_bytes;
+    KernelFn vec_om, scalar_om;   // the live-row forms (GemmArgs::omap / m_dev): cell-step and pick tiles only
 };
 
 template <int WM, int WN, int TM, int TN, int NG, int EPI, int BKT = 32, int PW = 0, bool BT = false>
 constexpr CfgEntry make_entry(const char* name)
 {
     using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT>;
+    KernelFn om = nullptr, om_s = nullptr;
+    if constexpr (EPI == EPI_LSTM || EPI == EPI_LSTM_GW || EPI == EPI_PICK) {
+        om = gemm_kernel<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT, true>;
+        om_s = gemm_kernel<WM, WN, TM, TN, NG, EPI, false, BKT, PW, BT, true>;
+    }
     return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT>,
-                    gemm_kernel<WM, WN, TM, TN, NG, EPI, false, BKT, PW, BT>, C::BM, C::CG, C::NT, C::LDS_FLOATS * 4};
+                    gemm_kernel<WM, WN, TM, TN, NG, EPI, false, BKT, PW, BT>, C::BM, C::CG, C::NT, C::LDS_FLOATS * 4, om, om_s};
 }
 
 // name = BMxBN(wavesMxwavesN)
@@ -180,7 +186,8 @@ void set_lds_attrs()
         int n;
         const CfgEntry* t = table(epi, &n);
         for (int i = 0; i < n; ++i) {
-            for (KernelFn fn : {t[i].vec, t[i].scalar}) {
+            for (KernelFn fn : {t[i].vec, t[i].scalar, t[i].vec_om, t[i].scalar_om}) {
+                if (!fn) continue;
                 const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          t[i].lds_bytes);
                 if (e != hipSuccess && g_attr_err == hipSuccess) g_attr_err = e;
@@ -313,6 +320,10 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     const unsigned gx = a2.xcd_map == 1 ? (unsigned)(mt * ceil_div(nt, 8) * 8) : (unsigned)(mt * nt);
     const dim3 grid(gx, (unsigned)(a.splits > 1 ? a.splits : 1), 1);
     KernelFn fn = can_vec(a, epi == EPI_STORE_NT) ? e.vec : e.scalar;
+    if (a.omap || a.m_dev) {                                           // live-row launch: its own instantiations
+        if (!e.vec_om) return hipErrorInvalidValue;
+        fn = fn == e.vec ? e.vec_om : e.scalar_om;
+    }
     const int pcls = epi;                                              // profiler class (0 store, 1 LSTM, 2 pick, 3 = TN kernel, 4 store with W^T)
     if (!prof_wants(pcls, cfg)) {
         hipLaunchKernelGGL(fn, grid, dim3(e.NT), e.lds_bytes, st, a2);

@@ -84,6 +84,11 @@ struct GemmArgs {
                                 // per 128-byte line (kPickStride): every column tile of the launch does an atomicMax per row, and
                                 // 16 rows per line made ~4000 serialized atomics per line at M = 64 (15-18 us of a 48 us launch)
     float* logits_out;          // optional [M, ldc]
+    // live-row launches (the OM instantiations: sampler steps that skip finished samples).  Row m of the launch is a COMPACT index;
+    // every per-row access -- A segments (before their own rowmod / rowidx / rowkey), cinit, c_prev, the state / pick outputs, the
+    // noise ids -- uses row omap[m] of the caller's arrays, and only the first *m_dev rows exist (tiles behind them return at once).
+    const int* omap;
+    const int* m_dev;
 };
 
 // ---- loads the compiler does not schedule (cdna_hip_programming.md §5.7): hipcc sinks ordinary prefetch loads next
@@ -205,7 +210,7 @@ struct GemmCfg {
     static_assert(!GW || (WN == 4 && NG == 4), "gate-per-wave needs four waves along N");
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0, bool BT = false>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0, bool BT = false, bool OM = false>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArgs g)
 {
     using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, BKT, PW, BT>;
@@ -279,6 +284,14 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
     }
     const int m0 = tile_m * BM;
     const int n0 = tile_n * CG;             // within-group column offset
+    // rows of this launch: g.M, or (OM) the device-resident live count -- a tile behind it has nothing to do
+    int MM = g.M;
+    if constexpr (OM) {
+        if (g.m_dev) { const int md = *g.m_dev; MM = md < MM ? md : MM; }
+        if (m0 >= MM) return;
+    }
+    const bool omapped = OM && g.omap != nullptr;
+    auto orow = [&](int m) __attribute__((always_inline)) { if constexpr (OM) return g.omap ? g.omap[m] : m; else return m; };
 
     f32x4 acc[TM][TN];
     // initial accumulator: +0 or a carried partial chain
@@ -294,7 +307,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int m = m0 + (wm * TM + i) * 16 + lq * 4 + r;
-                    if (m < g.M && cok) {
+                    if (m < MM && cok) {
+                        m = orow(m);
                         if (g.cinit_rowmod > 0) m %= g.cinit_rowmod;
                         v[r] = g.cinit[(size_t)m * g.ldcinit + col];
                     }
@@ -322,9 +336,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + (wm * TM + i) * 16 + lq * 4 + r;
-                const bool mok = mma_wave && m < g.M;
-                ep_sid[i][r] = mok ? g.sample_id[m] : -1;
-                ep_vid[i][r] = mok ? g.video_id[m] : 0;
+                const bool mok = mma_wave && m < MM;
+                ep_sid[i][r] = mok ? g.sample_id[orow(m)] : -1;
+                ep_vid[i][r] = mok ? g.video_id[orow(m)] : 0;
             }
     }
     auto pin_epilogue_operands = [&]() __attribute__((always_inline)) {
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
     // vector path then span BM rows, whatever the size of the matrix (a 71680 x 9972 logits gradient is 2.9 GB)
     auto seg_base = [&](int i) __attribute__((always_inline)) -> const float* {
         const ASeg& sg = g.seg[i];
-        const bool plain = sg.ptr && sg.rowmod <= 0 && !sg.rowidx && !sg.rowkey;
+        const bool plain = sg.ptr && sg.rowmod <= 0 && !sg.rowidx && !sg.rowkey && !omapped;
         return uniform(plain ? sg.ptr + (size_t)m0 * sg.ld : sg.ptr);
     };
     const float* const sp0 = seg_base(0);
@@ -390,8 +404,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
             const int idx = ltid + i * NTL;
             int m = m0 + idx / KQ;
             int off = -1;
-            if (sl > 0 && idx >= 0 && idx < BM * KQ && m < g.M) {
-                if (rowmod <= 0 && !rowidx && !rowkey) m -= m0;          // plain segment: relative to the tile's first row (seg_base)
+            if (sl > 0 && idx >= 0 && idx < BM * KQ && m < MM) {
+                if (rowmod <= 0 && !rowidx && !rowkey && !omapped) m -= m0;          // plain segment: relative to the tile's first row (seg_base)
+                if (omapped) m = orow(m);
                 if (rowmod > 0) m %= rowmod;
                 if (rowidx) m = rowidx[m];
                 if (rowkey) m = (int)(~(uint32_t)rowkey[(size_t)m * (rks > 0 ? rks : 1)]);
@@ -839,7 +854,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + (wm * TM + i) * 16 + lq * 4 + r;
-                    if (m < g.M) {
+                    if (m < MM) {
                         float v = acc[i][j][r];
                         if (g.bias) v = v + bj;
                         if (g.act == 1) v = dm_tanhf(v);
@@ -860,7 +875,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + (wm * TM + i) * 16 + lq * 4 + r;
-                    if (m >= g.M) continue;
+                    if (m >= MM) continue;
+                    const int mo = orow(m);
                     const float zi = acc[i][0 * TNG + jj][r] + bi;
                     const float zj = acc[i][1 * TNG + jj][r] + bj;
                     const float zf = acc[i][2 * TNG + jj][r] + bf;
@@ -869,8 +885,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     const float tj = dm_tanhf(zj);
                     const float sf = dm_sigmoidf(zf + 1.0f);
                     const float so = dm_sigmoidf(zo);
-                    const size_t o = (size_t)m * H + u;
-                    const size_t op = (size_t)(g.cprev_rowmod > 0 ? m % g.cprev_rowmod : m) * H + u;
+                    const size_t o = (size_t)mo * H + u;
+                    const size_t op = (size_t)(g.cprev_rowmod > 0 ? mo % g.cprev_rowmod : mo) * H + u;
                     const float t1 = g.c_prev[op] * sf;
                     const float t2 = si * tj;
                     const float c = t1 + t2;
@@ -880,14 +896,14 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     if (g.out) {
                         float ov = h;
                         if (g.keep < 1.0f) {
-                            const float k01 = dropout_keep01(g.seed_lo, g.seed_hi, (uint32_t)g.video_id[m],
-                                                             (uint32_t)g.sample_id[m], g.drop_code, (uint32_t)u, g.keep);
+                            const float k01 = dropout_keep01(g.seed_lo, g.seed_hi, (uint32_t)g.video_id[mo],
+                                                             (uint32_t)g.sample_id[mo], g.drop_code, (uint32_t)u, g.keep);
                             ov = (h / g.keep) * k01;
                         }
                         g.out[o] = ov;
                     }
                     if (g.gates) {
-                        float* gp = g.gates + (size_t)m * 4 * H + u;
+                        float* gp = g.gates + (size_t)mo * 4 * H + u;
                         gp[0] = si; gp[H] = tj; gp[2 * H] = sf; gp[3 * H] = so;
                     }
                 }
@@ -910,7 +926,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
         for (int pidx = tid; pidx < BM * CG; pidx += NT) {
             const int row = pidx / CG, uu = pidx % CG;
             const int m = m0 + row, u = n0 + uu;
-            if (m >= g.M || u >= H) continue;
+            if (m >= MM || u >= H) continue;
+            const int mo = orow(m);
             const float* z = smem + row * ZS + uu;
             const float zi = z[0] + g.bias[u];
             const float zj = z[CG] + g.bias[H + u];
@@ -920,8 +937,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
             const float tj = dm_tanhf(zj);
             const float sf = dm_sigmoidf(zf + 1.0f);
             const float so = dm_sigmoidf(zo);
-            const size_t o = (size_t)m * H + u;
-            const size_t op = (size_t)(g.cprev_rowmod > 0 ? m % g.cprev_rowmod : m) * H + u;
+            const size_t o = (size_t)mo * H + u;
+            const size_t op = (size_t)(g.cprev_rowmod > 0 ? mo % g.cprev_rowmod : mo) * H + u;
             const float t1 = g.c_prev[op] * sf;
             const float t2 = si * tj;
             const float c = t1 + t2;
@@ -931,14 +948,14 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
             if (g.out) {
                 float ov = h;
                 if (g.keep < 1.0f) {
-                    const float k01 = dropout_keep01(g.seed_lo, g.seed_hi, (uint32_t)g.video_id[m], (uint32_t)g.sample_id[m],
+                    const float k01 = dropout_keep01(g.seed_lo, g.seed_hi, (uint32_t)g.video_id[mo], (uint32_t)g.sample_id[mo],
                                                      g.drop_code, (uint32_t)u, g.keep);
                     ov = (h / g.keep) * k01;
                 }
                 g.out[o] = ov;
             }
             if (g.gates) {
-                float* gp = g.gates + (size_t)m * 4 * H + u;
+                float* gp = g.gates + (size_t)mo * 4 * H + u;
                 gp[0] = si; gp[H] = tj; gp[2 * H] = sf; gp[3 * H] = so;
             }
         }
@@ -980,9 +997,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mrow + r;
-                    if (m < g.M && col < g.N) {
+                    if (m < MM && col < g.N) {
                         float v = acc[i][j][r] + ep_bias[j];
-                        if (g.logits_out) g.logits_out[(size_t)m * g.ldc + col] = v;
+                        if (g.logits_out) g.logits_out[(size_t)orow(m) * g.ldc + col] = v;
                         if (sid[r] >= 0) v = v + gumbel_from_word(word[r]);
                         v = v + 0.0f;  // -0 -> +0 so that the integer order equals the float order
                         if (!have[r] || v > best[r]) { best[r] = v; bidx[r] = (uint32_t)col; have[r] = true; }
@@ -1023,10 +1040,10 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mrow + r;
-                    const bool ok = m < g.M && col < g.N;
+                    const bool ok = m < MM && col < g.N;
                     const float v = acc[i][j][r] + ep_bias[j];
                     v0[j][r] = v;
-                    if (ok && g.logits_out) g.logits_out[(size_t)m * g.ldc + col] = v;
+                    if (ok && g.logits_out) g.logits_out[(size_t)orow(m) * g.ldc + col] = v;
                     float k = v;
 #ifndef S2VT_PICK_NONOISE       // (dev ablation)
                     if (sid[r] >= 0) k = v + gumbel_fast_from_word(wd[j][r]);
@@ -1053,7 +1070,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                 for (int j = 1; j < TN; ++j)
                     if (js == j) { vs = v0[j][r]; ws = wd[j][r]; }
                 const int cols = n0 + (wn * TN + js) * 16 + l15;
-                const bool okr = mrow + r < g.M;
+                const bool okr = mrow + r < MM;
                 if (okr && cols < g.N && !(mx < thr)) {
                     float v = vs;
 #ifndef S2VT_PICK_NONOISE
@@ -1090,9 +1107,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
                     key = o > key ? o : key;
                 }
 #ifndef S2VT_PICK_NOATOMIC      // (dev ablation)
-                if (l15 == 0 && m < g.M && key != 0ull) atomicMax(&g.pick[(size_t)m * (g.pick_stride > 0 ? g.pick_stride : 1)], key);
+                if (l15 == 0 && m < MM && key != 0ull) atomicMax(&g.pick[(size_t)orow(m) * (g.pick_stride > 0 ? g.pick_stride : 1)], key);
 #else
-                if (l15 == 0 && m < g.M && key == 1ull) g.pick[(size_t)m * (g.pick_stride > 0 ? g.pick_stride : 1)] = key;
+                if (l15 == 0 && m < MM && key == 1ull) g.pick[(size_t)orow(m) * (g.pick_stride > 0 ? g.pick_stride : 1)] = key;
 #endif
             }
             S2VT_STAMP_AT(11);                     // (dev build) lane reduction + atomics

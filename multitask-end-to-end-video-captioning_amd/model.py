@@ -316,12 +316,14 @@ class Video_Caption_Generator:
         return v.contiguous(), v.shape[0]
 
     # -------------------------------------------------------------------------------- samplers
-    def sample(self, video, K, with_greedy=True, seed=None, video_base=0):
+    def sample(self, video, K, with_greedy=True, seed=None, video_base=0, stop_at_eos=False):
         """K multinomial captions per video (+ the greedy caption): (sampled [K*B,Tc], greedy [B,Tc])
-        int32 device tensors, sample-major rows.  One encode, no host round trip per step."""
+        int32 device tensors, sample-major rows.  One encode, no host round trip per step.
+        stop_at_eos (opt-in): rows that have emitted <eos> leave the decode loop (ids behind it read 0; the reference keeps
+        sampling them, :318-337, and masks them afterwards) -- the same update, a shorter loop on a trained policy."""
         video = self._dev(video, torch.float32)
         out = ops.sample(self.dims, self.store.params, video, K, self.sample_seed if seed is None else seed, video_base,
-                         with_greedy)
+                         with_greedy, stop_at_eos)
         ws, rows, serial = ops.sample.last_state[0], ops.sample.last_state[1], ops.sample.last_state[4]
         self._sampler_state = (ws, rows, video, video._version, video.shape[0], self.global_step, serial)
         return out

@@ -226,8 +226,10 @@ def workspace(nbytes: int, device, tag="default"):
     return t
 
 
-def sample(dims: Dims, params: Params, video, K: int, seed: int, video_base: int = 0, with_greedy: bool = True):
-    """K multinomial captions per video (+ greedy).  Returns (sampled [K*B,Tc], greedy [B,Tc]) int32."""
+def sample(dims: Dims, params: Params, video, K: int, seed: int, video_base: int = 0, with_greedy: bool = True, stop_at_eos: bool = False):
+    """K multinomial captions per video (+ greedy).  Returns (sampled [K*B,Tc], greedy [B,Tc]) int32.
+    stop_at_eos (opt-in, not the reference's behaviour): a row leaves the loop once it has picked <eos>; its later ids are 0.  Ids up to
+    and including the first <eos> -- the positions the objective's mask keeps -- are unchanged."""
     _chk_f32(video)
     assert video.is_contiguous()
     B = video.shape[0]
@@ -236,8 +238,12 @@ def sample(dims: Dims, params: Params, video, K: int, seed: int, video_base: int
     nbytes = L.s2vt_sample_workspace_bytes(C.byref(dims), B, K, g)
     ws = workspace(nbytes, video.device, "sample")
     ids = torch.empty(((K + g) * B, dims.n_caption_lstm_step), dtype=torch.int32, device=video.device)
-    check(L.s2vt_sample(C.byref(dims), C.byref(params), _ptr(video), B, K, g, seed, video_base, _ptr(ids), _ptr(ws),
-                        ws.numel(), _stream()), "s2vt_sample")
+    if stop_at_eos:
+        check(L.s2vt_sample_ex(C.byref(dims), C.byref(params), _ptr(video), B, K, g, seed, video_base, 1, _ptr(ids), _ptr(ws),
+                               ws.numel(), _stream()), "s2vt_sample_ex")
+    else:
+        check(L.s2vt_sample(C.byref(dims), C.byref(params), _ptr(video), B, K, g, seed, video_base, _ptr(ids), _ptr(ws),
+                            ws.numel(), _stream()), "s2vt_sample")
     sample.serial += 1                                                 # the workspace is shared by every caller: a later call overwrites it
     sample.last_state = (ws, (K + g) * B, video.data_ptr(), B, sample.serial)   # for teacher_forced_fwd(sampler_state=...)
     return ids[:K * B], (ids[K * B:] if with_greedy else None)

@@ -35,6 +35,8 @@ class Config:
     max_steps_per_epoch: int = 0       # 0 = the whole epoch (tests bound it)
     checkpoint_format: str = "npz"     # "npz" (name -> array dump) or "tf" (a TensorFlow V2 checkpoint: <name>-<epoch>.index / .data-00000-of-00001)
     step_log: str = ""                 # path of a JSONL step log ("" = none)
+    stop_at_eos: bool = False          # RL: samples leave the decode loop at their first <eos> (opt-in; the reference samples all Tc steps and masks
+                                       # afterwards -- same update, shorter loop: model.sample(stop_at_eos=True))
 
 
 class Corpus:

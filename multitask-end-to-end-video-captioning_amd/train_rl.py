@@ -84,7 +84,7 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
             rb, nxt = {}, {}
 
             def step():
-                samples, greedy_words = model.sample(video, K, True, seed=cfg.seed + 7919 * (model.global_step + 1), video_base=lo)
+                samples, greedy_words = model.sample(video, K, True, seed=cfg.seed + 7919 * (model.global_step + 1), video_base=lo, stop_at_eos=cfg.stop_at_eos)
                 s_host, g_host = samples.cpu().numpy(), greedy_words.cpu().numpy()
                 model.check_health()            # the ids just came to the host: a starved sampler recurrence is caught before it is scored
 
@@ -136,8 +136,9 @@ def main():
     ap.add_argument("--vocab", required=True); ap.add_argument("--restore"); ap.add_argument("--resume")
     ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--samples", type=int, default=8); ap.add_argument("--model-path", default="./new_multisamp_reinforcement_models")
+    ap.add_argument("--stop-at-eos", action="store_true", help="samples leave the decode loop at their first <eos> (same update, shorter sampler loop)")
     a = ap.parse_args()
-    cfg = rl_config(n_epochs=a.epochs, batch_size=a.batch_size, multisample=a.samples, model_path=a.model_path)
+    cfg = rl_config(n_epochs=a.epochs, batch_size=a.batch_size, multisample=a.samples, model_path=a.model_path, stop_at_eos=a.stop_at_eos)
     tr = Corpus(a.train_sents, a.train_feats, vocabulary_file=a.vocab)
     te = Corpus(a.test_sents, a.test_feats, vocabulary=tr.vocabulary) if a.test_sents and a.test_feats else None
     train(cfg, tr, te, restore=a.restore, resume=a.resume)

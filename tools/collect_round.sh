@@ -6,7 +6,7 @@ set -x
 out=${1:-gpurun_out/prof}
 export TMPDIR=/tmp
 mkdir -p $out
-for w in rl xe multitask attention attention32 rl_msvd; do
+for w in rl xe multitask attention attention32 rl_msvd rl_msvd_eos; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$w -o run -- python3 bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $out/stats_$w.log 2>&1
 done
 for w in rl attention; do

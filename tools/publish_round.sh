@@ -4,7 +4,7 @@
 # Run it on the SAME sources the collection ran on: the traffic summaries are stamped with bench.kernel_signature().
 set -e
 src=$1; tag=$2
-for w in rl xe multitask attention attention32 rl_msvd; do
+for w in rl xe multitask attention attention32 rl_msvd rl_msvd_eos; do
   f=$(find $src/stats_$w -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] || continue
   cp $f profiles/${tag}_${w}_kernel_stats.csv
@@ -16,12 +16,12 @@ if [ -d $src/pmc_attention ]; then
   python3 tools/pmc_to_json.py $src/pmc_attention profiles/${tag}_pmc_traffic_attention.json
   python3 tools/sq_summary.py $src/sq_attention > profiles/${tag}_sq_counters_attention.txt
 fi
-for w in rl xe multitask attention attention32 rl_msvd; do
+for w in rl xe multitask attention attention32 rl_msvd rl_msvd_eos; do
   [ -s ${src}_bench_$w.json ] && tail -1 ${src}_bench_$w.json > profiles/${tag}_bench_$w.json
 done
 python3 - <<PY
 import json, os
-for w in ("rl", "xe", "multitask", "attention", "attention32", "rl_msvd"):
+for w in ("rl", "xe", "multitask", "attention", "attention32", "rl_msvd", "rl_msvd_eos"):
     f = "profiles/${tag}_bench_%s.json" % w
     if os.path.exists(f):
         d = json.load(open(f))
