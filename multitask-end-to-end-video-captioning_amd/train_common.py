@@ -220,7 +220,7 @@ def greedy_eval(model, corpus: Corpus, ixtoword, scorer: "reward.CiderD | None",
     return decoded, (total / count if count else None)
 
 
-def save_checkpoint(model, cfg: Config, epoch: int, step_name: str = "g_step"):
+def save_checkpoint(model, cfg: Config, epoch: int, step_name: str = "g_step", tf_version: int = 2):
     """Variables under the reference's TF names plus what its tf.train.Saver keeps beside them when it is created after
     the optimizer (reinforcement_multisampling_tf_s2vt.py:661): Adam slots, beta powers, the step counter -- a resumed
     run continues the moments, the bias correction, the learning-rate staircase and the noise streams."""
@@ -233,7 +233,7 @@ def save_checkpoint(model, cfg: Config, epoch: int, step_name: str = "g_step"):
         path = os.path.join(cfg.model_path, f"{cfg.model_name}-{epoch}")
         sd.pop("global_step", None)                        # (this repository's alias; the graph's counter is `step_name`)
         arrays = {k: np.asarray(v) for k, v in sd.items()}
-        if cfg.checkpoint_format == "tf_v1":               # tf_s2vt.py:440: tf.train.Saver(write_version=1) -- ONE file, the V1 tensor-slice format
+        if cfg.checkpoint_format == "tf_v1" or tf_version == 1:    # tf_s2vt.py:440: tf.train.Saver(write_version=1) -- ONE file, the V1 tensor-slice format
             tfckpt.write_checkpoint_v1(path, arrays)
         else:
             tfckpt.write_checkpoint_v2(path, arrays)
@@ -243,13 +243,13 @@ def save_checkpoint(model, cfg: Config, epoch: int, step_name: str = "g_step"):
     return path
 
 
-def save_checkpoint_checked(model, cfg: Config, epoch: int, step_name: str = "g_step", chief: bool = True):
+def save_checkpoint_checked(model, cfg: Config, epoch: int, step_name: str = "g_step", chief: bool = True, tf_version: int = 2):
     """save_checkpoint behind a COLLECTIVE health check (every rank calls this; the chief writes): a rank whose
     persistent recurrence faulted has fed garbage into an all-reduce, so no replica's variables may be written out."""
     if not all_ranks_healthy(model):
         from ._lib import S2VTChainTimeout
         raise S2VTChainTimeout("a rank of this data-parallel job has a persistent-recurrence fault pending: not writing a checkpoint")
-    return save_checkpoint(model, cfg, epoch, step_name) if chief else None
+    return save_checkpoint(model, cfg, epoch, step_name, tf_version) if chief else None
 
 
 def optimistic_restore(model, path, restore_step: bool = True, step_names=("global_step", "g_step", "Variable"), optimizer_state="auto"):

@@ -81,7 +81,7 @@ def train(cfg: Config, train_corpus: Corpus, test_corpus: Corpus | None = None, 
         entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None}
         if test_corpus is not None:
             _, entry["ciderD"] = greedy_eval(model, test_corpus, ixtoword, scorer, B, par)
-        ck = save_checkpoint_checked(model, cfg, epoch, step_name="Variable", chief=par.chief)      # tf_s2vt.py:441: the unnamed counter
+        ck = save_checkpoint_checked(model, cfg, epoch, step_name="Variable", chief=par.chief, tf_version=1)   # the XE script's saver writes V1 (tf_s2vt.py:440)      # tf_s2vt.py:441: the unnamed counter
         if par.chief:
             entry["checkpoint"] = ck
         history.append(entry)
