@@ -65,6 +65,7 @@ class Attention_Caption_Generator:
         self.world_size, self.rank, self.dp_overlap = 1, 0, False        # data parallel: one all-reduce of the flat bucket (dist.py)
         self.dropout_seed = seed + 1
         self._gscale = torch.ones(1, dtype=torch.float32, device=self.device)
+        self._applied = torch.zeros(1, dtype=torch.int32, device=self.device)   # step number of the last Adam update the device APPLIED
         self._row_ids_cache = {}
 
     # ------------------------------------------------------------------------------------------ utilities
@@ -178,8 +179,43 @@ class Attention_Caption_Generator:
         ops.grad_finalize(st.grad[:st.numel], st.theta, self._gscale, 0.0, sumsq)
         self.global_step += 1
         self.adam_t += 1
-        ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, sumsq, clip_norm, lr, self.adam_t, beta1, beta2, eps)
+        ops.adam_tf(st.theta, st.grad[:st.numel], st.m, st.v, sumsq, clip_norm, lr, self.adam_t, beta1, beta2, eps, applied_step=self._applied)
         return StepStats(loss[0], sumsq, c["msum"][0])
+
+    # ------------------------------------------------------------------------------------------ what the training drivers use
+    def active_steps(self, mask):
+        return self._active_steps(mask, self.n_caption_lstm_steps)
+
+    def sample(self, video, K=0, with_greedy=True, seed=None, video_base=0):
+        """(None, greedy ids [B, Tc]) -- the greedy sampler in the shape train_common.greedy_eval expects (this model has no
+        multinomial sampler: original_attention.py trains with cross entropy only)."""
+        assert K == 0 and with_greedy
+        ids, _ = ops.attn_decode_greedy(self.dims, self.store.params, self._dev(video, torch.float32), video_base)
+        return None, ids
+
+    def set_step(self, global_step, adam_t=None):
+        self.global_step = int(global_step)
+        self.adam_t = int(global_step if adam_t is None else adam_t)
+        self._applied.fill_(self.adam_t)
+
+    def check_health(self):
+        """Raise S2VTChainTimeout if a persistent recurrence (attn_chain.hip / attn_chain_bwd.hip) gave up a grid-wide wait since the
+        last recover() -- a host-memory read, no synchronisation (as Video_Caption_Generator.check_health)."""
+        if ops.chain_fault():
+            from ._lib import S2VTChainTimeout
+            raise S2VTChainTimeout("a persistent attention recurrence timed out (is another process running persistent kernels on this GPU?); "
+                                   "the variables are intact: call recover() and repeat the step")
+
+    def recover(self, disable_persistent=True):
+        """After S2VTChainTimeout: synchronise, rewind the step counters to the last update the device applied, acknowledge the fault and
+        switch to per-step launches (same bits).  Returns (step counter, updates skipped)."""
+        torch.cuda.synchronize(self.device)
+        applied = int(self._applied.item())
+        ops.chain_ack(disable_persistent)
+        lost = max(0, self.adam_t - applied)
+        self.adam_t -= lost
+        self.global_step -= lost
+        return self.global_step, lost
 
     # ------------------------------------------------------------------------------------------ the reference surface
     def build_model(self):

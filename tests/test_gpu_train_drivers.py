@@ -54,6 +54,29 @@ def test_xe_then_rl_drivers(tmp_path):
         assert "s2vt/LSTM1/basic_lstm_cell/weights" in z.files and "Wemb" in z.files
 
 
+def test_attention_driver(tmp_path):
+    """train_attention.train (original_attention.py's train(), :383-520) on the synthetic corpus: the loss falls, greedy evaluation scores,
+    the checkpoint carries the TF variable names and resumes."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import s2vt_amd
+    from s2vt_amd import train_attention, train_common as tc
+    rng = np.random.default_rng(0)
+    sents, feats, vocab = _corpus(tmp_path, "att", rng)
+    corpus = tc.Corpus(sents, feats, vocabulary=vocab)
+    cfg = train_attention.attention_config(dim_image=24, lstm_dim=32, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=6, batch_size=8,
+                                           start_learning_rate=2e-2, model_path=str(tmp_path / "m"), model_name="att", step_log=str(tmp_path / "att.jsonl"))
+    model, hist = train_attention.train(cfg, corpus, corpus, log=lambda *_: None)
+    assert hist[-1]["loss"] < 0.7 * hist[0]["loss"] and hist[-1]["ciderD"] is not None
+    with np.load(hist[-1]["checkpoint"]) as z:
+        assert "s2vt/LSTM3/basic_lstm_cell/weights" in z.files and "embed_att_Wa" in z.files and "embed_att_Wa/Adam" in z.files and "Variable" in z.files
+    cfg1 = train_attention.attention_config(dim_image=24, lstm_dim=32, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=1, batch_size=8,
+                                            start_learning_rate=2e-2, model_path=str(tmp_path / "m2"), model_name="att2")
+    model2, hist2 = train_attention.train(cfg1, corpus, None, log=lambda *_: None, resume=hist[-1]["checkpoint"])
+    assert model2.global_step > model.global_step - 1 and hist2[-1]["loss"] < hist[0]["loss"]
+
+
 def test_e2e_driver_frames_to_checkpoint(tmp_path):
     """train_e2e.train on a synthetic frame corpus (jpg files in the reference's directory layout) with a small
     stand-in CNN: frames -> CNN -> HIP captioner -> joint update; the loss falls, both checkpoints are written."""
