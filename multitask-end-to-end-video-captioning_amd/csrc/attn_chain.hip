@@ -71,12 +71,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int LDT = KP + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                          // [NG][64][4]  B fragments, W3 rows [2H, 3H)
-    float* Wq = smem + NG * 256;                               // [NG][64][4]  B fragments, Wa column tile (query role)
+    float* Wq = smem + NG * 256 + 4 * 16 * ZS;                 // [NG][64][4]  B fragments, Wa column tile (query role)
     const int tid = threadIdx.x, lane = tid & 63;
     const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* zb = smem + 2 * NG * 256 + pwave * (16 * ZS);
-    float* Tt = smem + 2 * NG * 256 + 4 * 16 * ZS;             // [kACRows][LDT] tanh rows (attention role)
-    float* wl = Tt + kACRows * LDT;                            // [KP] the score vector
+    float* zb = smem + NG * 256 + pwave * (16 * ZS);
+    float* Tq = smem + 2 * NG * 256 + 4 * 16 * ZS;             // [kACRows][LDT] tanh rows (attention role) behind the query tile ...
+    float* wl = Tq + kACRows * LDT;                            // [KP] the score vector
     float* ev = wl + KP;                                       // [64] scores, then alphas
     float* xv = ev + kACMaxTv;                                 // [64] exp(e)
     float* sc = xv + kACMaxTv;                                 // [4]
@@ -90,6 +90,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int brow = nwg - 1 - (int)blockIdx.x;                // attention role: batch row
     const bool roleA = brow < M;
     const bool tok = wave * 16 < M;
+    // ... and a workgroup that is NOT a query workgroup has no use for that tile's 64 KB: its tanh rows start there, and a chunk holds
+    // (NG * 256 + kACRows * LDT) / LDT frames instead of kACRows (20 instead of 5 at NG = 64) -- the score chains of a chunk run side by
+    // side on one lane each, so a chunk costs about the same whatever it holds: Tv = 32 in 2 chunks instead of 7
+    float* const Tt = roleQ ? Tq : Wq;
+    const int RCA = roleQ ? kACRows : (NG * 256 + kACRows * LDT) / LDT;
 
     // ---- prologue: weights to their places, once
     for (int idx = tid; idx < NG * 16 * 4; idx += 256) {       // recurrent rows of W3 -> LDS (chain.hip's layout)
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     if (roleA) {
         for (int h = tid; h < KP; h += 256) wl[h] = h < H ? g.w[h] : 0.f;
-        for (int i = tid; i < kACRows * (KP - H); i += 256) Tt[(size_t)(i / (KP - H)) * LDT + H + i % (KP - H)] = 0.f;     // pad columns: zeros for good
+        for (int i = tid; i < RCA * (KP - H); i += 256) Tt[(size_t)(i / (KP - H)) * LDT + H + i % (KP - H)] = 0.f;     // pad columns: zeros for good
     }
     // context rows W3[0:H] of this workgroup's 16 gate columns -> registers: k-step s of group j holds W3[16 j + 4 e + lq][column of l15]
     const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);          // W / cinit column of tile column l15 (gate l15 % 4, unit u0 + l15 / 4)
@@ -265,22 +270,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 AC_STAMP(4);                                   // wait for hWa + its load (and P / V)
             }
-            for (int c0 = 0; c0 < Tv; c0 += kACRows) {
-                const int nr = (Tv - c0) < kACRows ? (Tv - c0) : kACRows;
-                if (c0 > 0) {
+            for (int c0 = 0; c0 < Tv; c0 += RCA) {
+                const int nr = (Tv - c0) < RCA ? (Tv - c0) : RCA;
+                for (int g0 = 0; g0 < nr; g0 += kACRows) {       // tanh rows of the chunk, kACRows frames' loads in flight at a time
+                    if (c0 + g0 > 0) {
 #pragma unroll
-                    for (int j = 0; j < kACRows; ++j)
-                        if (j < nr && qok) pv[j] = *reinterpret_cast<const f32x4*>(g.P + (size_t)(c0 + j) * M * H + rowoff);
-                }
-                if (qok) {
+                        for (int j = 0; j < kACRows; ++j)
+                            if (g0 + j < nr && qok) pv[j] = *reinterpret_cast<const f32x4*>(g.P + (size_t)(c0 + g0 + j) * M * H + rowoff);
+                    }
+                    if (qok) {
 #pragma unroll
-                    for (int j = 0; j < kACRows; ++j)
-                        if (j < nr) {
-                            f32x4 tt;
-                            tt[0] = dm_tanhf(hv[0] + pv[j][0]); tt[1] = dm_tanhf(hv[1] + pv[j][1]);
-                            tt[2] = dm_tanhf(hv[2] + pv[j][2]); tt[3] = dm_tanhf(hv[3] + pv[j][3]);
-                            *reinterpret_cast<f32x4*>(Tt + (size_t)j * LDT + 4 * q) = tt;
-                        }
+                        for (int j = 0; j < kACRows; ++j)
+                            if (g0 + j < nr) {
+                                f32x4 tt;
+                                tt[0] = dm_tanhf(hv[0] + pv[j][0]); tt[1] = dm_tanhf(hv[1] + pv[j][1]);
+                                tt[2] = dm_tanhf(hv[2] + pv[j][2]); tt[3] = dm_tanhf(hv[3] + pv[j][3]);
+                                *reinterpret_cast<f32x4*>(Tt + (size_t)(g0 + j) * LDT + 4 * q) = tt;
+                            }
+                    }
                 }
                 __syncthreads();
                 const int r = (tid & 63) * 4 + (tid >> 6);      // frame r of the chunk -> wave r & 3, lane r >> 2

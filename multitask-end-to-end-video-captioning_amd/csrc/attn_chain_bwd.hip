@@ -301,16 +301,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (qok) *reinterpret_cast<f32x4*>(dcl + 4 * q4) = dense;
                 __syncthreads();
                 AB_STAMP(6);                                   // dctx wait + load
-                for (int f = pwave; f < Tv; f += 4) {           // dalpha[f] = <dctx, V[f, b, :]>: one wave per frame
-                    const float* vp = g.Vt + ((size_t)f * M + brow) * H;
-                    float s = 0.f;
+                for (int f = pwave; f < Tv; f += 16) {          // dalpha[f] = <dctx, V[f, b, :]>: a wave takes frames f, f+4, f+8, f+12 together
+                    float s4[4] = {0.f, 0.f, 0.f, 0.f};          // (16 loads in flight per trip instead of 4: the rows come from L2 / HBM every iteration)
                     for (int q = lane; q < (H >> 2); q += 64) {
-                        const f32x4 x = *reinterpret_cast<const f32x4*>(vp + 4 * q), d = *reinterpret_cast<const f32x4*>(dcl + 4 * q);
-                        s += d[0] * x[0] + d[1] * x[1] + d[2] * x[2] + d[3] * x[3];
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(dcl + 4 * q);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (f + 4 * u < Tv) {
+                                const f32x4 x = *reinterpret_cast<const f32x4*>(g.Vt + ((size_t)(f + 4 * u) * M + brow) * H + 4 * q);
+                                s4[u] += d[0] * x[0] + d[1] * x[1] + d[2] * x[2] + d[3] * x[3];
+                            }
                     }
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-                    if (lane == 0) dal[f] = s;
+                    for (int u = 0; u < 4; ++u) {
+                        float s = s4[u];
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                        if (lane == 0 && f + 4 * u < Tv) dal[f + 4 * u] = s;
+                    }
                 }
             }
             __syncthreads();
@@ -345,10 +353,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             }
                         }
                 } else
-                for (int f0 = 0; f0 < Tv; f0 += 4) {
-                    f32x4 pv[4], op[4], ov[4];
+                for (int f0 = 0; f0 < Tv; f0 += 8) {
+                    f32x4 pv[8], op[8], ov[8];                  // 8 frames' loads in flight at a time
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 8; ++j)
                         if (f0 + j < Tv) {
                             const size_t o = (size_t)(f0 + j) * M * H + rowoff;
                             pv[j] = *reinterpret_cast<const f32x4*>(g.P + o);
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             ov[j] = *reinterpret_cast<const f32x4*>(g.dVt + o);
                         }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 8; ++j)
                         if (f0 + j < Tv) {
                             const size_t o = (size_t)(f0 + j) * M * H + rowoff;
                             const float d = del[f0 + j], alt = all_[f0 + j];
