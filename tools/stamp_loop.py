@@ -65,3 +65,7 @@ for M in (64, 128):
     o2 = torch.randn(M, H, device=dev)
     report(f"PICK M={M}", lambda: ops.vocab_pick(o2, Wout, bout, vid, sid, 0, 1))
     report(f"PICK M={M} greedy rows only", lambda: ops.vocab_pick(o2, Wout, bout, vid, -torch.ones(M, dtype=torch.int32, device=dev), 0, 1))
+for M in [int(x) for x in os.environ.get("PICKM", "64").split(",")]:
+    o2s = torch.randn(M, H, device=dev)
+    for pc in [int(x) for x in os.environ.get("PICKCFG", "0,6").split(",")]:
+        report(f"PICK M={M} cfg {pc}", lambda: ops.vocab_pick(o2s, Wout, bout, vid, sid, 0, 1, tile_cfg=pc))
