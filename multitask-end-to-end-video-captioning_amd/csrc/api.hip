@@ -300,7 +300,7 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
 hipError_t lstm_recurrence(const float* W, int kw0, const float* bias, const float* cinit, size_t cinit_tstride, int ldcinit,
                            int cinit_steps, float* C, float* Hh, size_t state_tstride, float* gates, size_t gates_tstride,
                            float* out, size_t out_tstride, int M, int H, int T, float keep, const NoiseIds& ids,
-                           uint32_t drop_code0, float* chain_abuf, unsigned* chain_sync, hipStream_t st)
+                           uint32_t drop_code0, float* chain_abuf, unsigned* chain_sync, hipStream_t st, const int32_t* perm, const int32_t* nlive)
 {
     if (chain_abuf && chain_sync && chain_eligible(M, H) && chain_operands_ok(W, 4 * H, chain_abuf)) {    // (unaligned W: per-step launches)
         ChainArgs a;
@@ -313,6 +313,7 @@ hipError_t lstm_recurrence(const float* W, int kw0, const float* bias, const flo
         a.seed_lo = (uint32_t)ids.seed; a.seed_hi = (uint32_t)(ids.seed >> 32); a.drop_code0 = drop_code0;
         a.video_id = ids.video_id; a.sample_id = ids.sample_id;
         a.abuf = chain_abuf; a.sync = chain_sync;
+        a.perm = perm; a.nlive = nlive;                        // (forms that cannot skip rows run dense: the same results)
         return launch_lstm_chain(a, st);
     }
     for (int t = 0; t < T; ++t) {

@@ -201,7 +201,8 @@ struct SampleWs {
 hipError_t lstm_recurrence(const float* W, int kw0, const float* bias, const float* cinit, size_t cinit_tstride, int ldcinit,
                            int cinit_steps, float* C, float* Hh, size_t state_tstride, float* gates, size_t gates_tstride,
                            float* out, size_t out_tstride, int M, int H, int T, float keep, const NoiseIds& ids,
-                           uint32_t drop_code0, float* chain_abuf, unsigned* chain_sync, hipStream_t st);
+                           uint32_t drop_code0, float* chain_abuf, unsigned* chain_sync, hipStream_t st, const int32_t* perm = nullptr,
+                           const int32_t* nlive = nullptr);
 size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w);
 int sample_encode(const s2vt_dims* d, const s2vt_params* p, const float* video, int B, const SampleWs& w, s2vt_stream stream);
 int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int with_greedy, uint64_t seed, int video_base,

@@ -554,6 +554,44 @@ hipError_t launch_gather_rows(const float* src, int ld, const int32_t* idx, int 
     hipLaunchKernelGGL(gather_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, st, src, ld, idx, R, C / 4, dst, ldd);
     return hipGetLastError();
 }
+// ---------------------------------------------------------------------------------------------
+// Row order of a live-row unroll for the recurrence kernels (chain.hip, lstm_chain4_kernel<.., true>): from the list of
+// unmasked (step, row) pairs t * N + n -- each row's live steps a PREFIX 0 .. len-1 of the decode steps, the precondition of
+// the *_live entry points -- the rows sorted by length, longest first (stable: equal lengths keep their order), and the number
+// of rows still live at every step of the recurrence (every row during the Tv encode steps).  One workgroup, N <= 1024.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void row_order_kernel(const int32_t* live_rows, int n_live, int N, int Tv, int Tc, int32_t* perm, int32_t* nlive)
+{
+    __shared__ int len[1024];
+    __shared__ int cnt[128];
+    const int tid = threadIdx.x;
+    len[tid] = 0;
+    if (tid < 128) cnt[tid] = 0;
+    __syncthreads();
+    for (int r = tid; r < n_live; r += 1024) {
+        const int idx = live_rows[r];
+        const int t = idx / N, n = idx - t * N;
+        if (t >= 0 && t < Tc && t < 128) { atomicAdd(&len[n], 1); atomicAdd(&cnt[t], 1); }
+    }
+    __syncthreads();
+    if (tid < N) {
+        const int mine = len[tid];
+        int rank = 0;
+        for (int m = 0; m < N; ++m) {
+            const int o = len[m];
+            rank += (o > mine || (o == mine && m < tid)) ? 1 : 0;
+        }
+        perm[rank] = tid;
+    }
+    for (int t = tid; t < Tv + Tc; t += 1024) nlive[t] = t < Tv ? N : cnt[t - Tv];
+}
+hipError_t launch_row_order(const int32_t* live_rows, int n_live, int N, int Tv, int Tc, int32_t* perm, int32_t* nlive, hipStream_t st)
+{
+    if (!live_rows || n_live < 0 || N <= 0 || N > 1024 || Tv < 0 || Tc <= 0 || Tc > 128 || !perm || !nlive) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(row_order_kernel, dim3(1), dim3(1024), 0, st, live_rows, n_live, N, Tv, Tc, perm, nlive);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_i32(const int32_t* src, const int32_t* idx, int R, int32_t* dst, hipStream_t st)
 {
     if (R <= 0) return hipSuccess;

@@ -290,7 +290,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef S2VT_C4_STAMP
 __device__ unsigned long long c4_stamp_acc[12 * 8];
 #endif
-template <int NG, int TPP>
+// LIVE (round 4): the rows are VIRTUAL -- row v of the state image is row g.perm[v] of every per-row array (carried partial,
+// initial state, noise ids, histories), the caller having sorted the rows by caption length, longest first -- and step t
+// computes only the row tiles that hold one of the first g.nlive[t] virtual rows: a row behind its caption's <eos> feeds
+// nothing (cider_evaluation.py:145-172; the callers gather the live (step, row) pairs for every product outside the
+// recurrence), its state simply stops.  The tiles of a part are then INTERLEAVED (tile i of part p is image tile 4 i + p), so
+// the live prefix spreads evenly over the four parts, and the step body is instantiated per count of live tiles.  Live rows
+// are computed exactly as in the dense launch: same chains, same pointwise expressions, bit-identical histories.
+template <int NG, int TPP, bool LIVE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_chain4_kernel(const ChainArgs g)
 {
     constexpr int ZS = 20;
@@ -304,24 +311,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NCH = NG / CG;                               // chunks per step
     constexpr int NBUF = S2VT_C4_NBUF;                         // LDS chunk buffers (NBUF - 1 chunks in flight)
     constexpr int CHF = TPP * CG * 256;                        // floats per chunk buffer
-    constexpr int DPW = (TPP * CG + 3) / 4;                    // DMA instructions per wave per chunk
     static_assert(NG % CG == 0 && NCH >= NBUF, "chunking");
     static_assert((NCH - 1) % NBUF != 0 && CG >= 7, "the epilogue stages 7 x TPP KB in chunk buffer 0 while slow waves may still read the last chunk's buffer");
+    static_assert(CG % 4 == 0, "every wave issues the same number of DMA loads per chunk for any count of live tiles (the vmcnt bookkeeping below)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ab = smem;                                          // [NBUF][CG][TPP][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* zb = smem + NBUF * CHF + wave * (16 * ZS);
+    int* const arow_l = reinterpret_cast<int*>(smem + NBUF * CHF + 4 * 16 * ZS);   // LIVE: [TPP][16] rows of the caller's arrays behind this workgroup's virtual rows
     const int l15 = lane & 15, lq = lane >> 4;
     const int H = g.H, M = g.M, T = g.T;
     const int cg = (int)blockIdx.x % g.ncg, rp = (int)blockIdx.x / g.ncg;     // unit group (16 units), row part
     const int u0 = cg * 16 + wave * 4;                         // this wave's 4 units
     const bool wact = u0 < H;                                  // (the last unit group may be partial: idle waves still move A and keep the barriers)
     const int nwg = gridDim.x;
-    const int tb = rp * TPP;                                   // first row tile of this workgroup
+    constexpr int TS = LIVE ? 4 : 1;                           // image tiles between consecutive row tiles of this workgroup
+    const int tile0 = LIVE ? rp : rp * TPP;                    // image tile of this workgroup's row tile 0
     bool tok[TPP];
 #pragma unroll
-    for (int i = 0; i < TPP; ++i) tok[i] = (tb + i) * 16 < M;
+    for (int i = 0; i < TPP; ++i) tok[i] = (tile0 + i * TS) * 16 < M;
+    auto actual = [&](int v) __attribute__((always_inline)) { if constexpr (LIVE) return v < M ? (int)g.perm[v] : v; else return v; };
+    if constexpr (LIVE) {
+        if (tid < TPP * 16) arow_l[tid] = actual((tile0 + (tid >> 4) * TS) * 16 + (tid & 15));
+        __syncthreads();
+    }
 
     // ---- this wave's column tile of the recurrent rows -> registers, once: k-step s holds W[kw0 + 4s + lq][column of l15]
     const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);          // W / cinit column of tile column l15 (gate l15 % 4, unit u0 + l15 / 4)
@@ -334,44 +348,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- the (row, unit) pairs this lane finishes at every step: one per row tile
     const int rt = lane >> 2, uu = lane & 3;
-    const int row0 = tb * 16 + rt;
     const int u = u0 + uu;
     float bi = 0.f, bj = 0.f, bf = 0.f, bo = 0.f;
     if (wact) { bi = g.bias[u]; bj = g.bias[H + u]; bf = g.bias[2 * H + u]; bo = g.bias[3 * H + u]; }
     float c_reg[TPP];
     uint32_t vid[TPP], sid[TPP];
+    // where this lane's h value of row tile 0 sits in the A-fragment image (tile i: + i * TS * NG * 256 floats)
+    const size_t a_own = ((size_t)(tile0 * NG + (u >> 4)) * 64 + (size_t)((u & 3) * 16 + rt)) * 4 + ((u & 15) >> 2);
+    float* const abuf0 = g.abuf;
+    float* const abuf1 = g.abuf + (size_t)g.img_tiles * NG * 256;
 #pragma unroll
     for (int i = 0; i < TPP; ++i) {
-        const int row = row0 + 16 * i;
-        const bool rok = wact && tok[i] && row < M;
+        const int vrow = (tile0 + i * TS) * 16 + rt;
+        const bool rok = wact && tok[i] && vrow < M;
+        const int row = rok ? actual(vrow) : 0;
         c_reg[i] = (rok && g.c0) ? g.c0[(size_t)row * H + u] : 0.0f;
         vid[i] = (g.keep < 1.0f && rok) ? (uint32_t)g.video_id[row] : 0u;
         sid[i] = (g.keep < 1.0f && rok) ? (uint32_t)g.sample_id[row] : 0u;
+        // ---- arrival 0: h_0 in fragment order
+        if (rok) {
+            const float h0 = g.h0 ? g.h0[(size_t)row * H + u] : 0.0f;
+            __hip_atomic_store((gu32*)(abuf0 + a_own + (size_t)i * TS * NG * 256), __float_as_uint(h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    int hoff[TPP], goff[TPP];                                  // byte offsets of this lane's (row, unit) in a [M, H] / [M, 4H] history slot
-#pragma unroll
-    for (int i = 0; i < TPP; ++i) {
-        const int row = row0 + 16 * i;
-        const bool rok = wact && tok[i] && row < M;
-        hoff[i] = rok ? (row * H + u) * 4 : (int)0x80000000u;
-        goff[i] = rok ? (row * 4 * H + u) * 4 : (int)0x80000000u;
-    }
-    // where this lane's h value of row tile 0 sits in the A-fragment image (tile i: + i * NG * 256 floats)
-    const size_t a_own = ((size_t)(tb * NG + (u >> 4)) * 64 + (size_t)((u & 3) * 16 + rt)) * 4 + ((u & 15) >> 2);
-    float* const abuf0 = g.abuf;
-    float* const abuf1 = g.abuf + (size_t)g.img_tiles * NG * 256;
 
     GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, nwg, false};
 
-    // ---- arrival 0: h_0 in fragment order
-#pragma unroll
-    for (int i = 0; i < TPP; ++i) {
-        const int row = row0 + 16 * i;
-        if (wact && tok[i] && row < M) {
-            const float h0 = g.h0 ? g.h0[(size_t)row * H + u] : 0.0f;
-            __hip_atomic_store((gu32*)(abuf0 + a_own + (size_t)i * NG * 256), __float_as_uint(h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     // the carried partial of a step, branch-free: loop-invariant byte offsets into a per-step buffer resource, an element
     // outside the problem carries an out-of-range offset and reads as zero (20-24 conditional loads per step cost 1.5 us of
     // branches and 64-bit address arithmetic in front of every step)
@@ -381,8 +383,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < TPP; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = (tb + i) * 16 + lq * 4 + r;
-            coff[i][r] = (wact && tok[i] && m < M) ? (m * g.ldcinit + ccol) * 4 : (int)0x80000000u;
+            const int m = (tile0 + i * TS) * 16 + lq * 4 + r;
+            coff[i][r] = (wact && tok[i] && m < M) ? (actual(m) * g.ldcinit + ccol) * 4 : (int)0x80000000u;
         }
     auto load_cinit = [&](int t) __attribute__((always_inline)) {
         if (g.cinit && t < g.cinit_steps) {                       // (uniform)
@@ -409,7 +411,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #else
 #define C4_STAMP(i) do { } while (0)
 #endif
-    for (int t = 0; t < T; ++t) {
+    // One step with NL of this workgroup's TPP row tiles in play (dense: always TPP)
+    auto step = [&](auto nl_, const int t) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_)::value;
+        constexpr int DPW = NL * CG / 4;                          // DMA instructions per wave per chunk
         f32x4 acc[TPP];
 #pragma unroll
         for (int i = 0; i < TPP; ++i) {
@@ -425,24 +430,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         C4_STAMP(0);                                              // acc init (waits for the carried partial)
         gs.wait_all((unsigned)t, wave, lane);
         C4_STAMP(1);                                              // grid-wide wait
-        // ---- the part's slice of h_t: [TPP row tiles][NG groups] KB, global -> LDS in chunks of CG groups.  Piece p of a chunk
-        // = (group p / TPP, row tile p % TPP); wave w issues pieces w, w + 4, ...
+        if constexpr (NL > 0) {
+        // ---- the part's slice of h_t: [NL row tiles][NG groups] KB, global -> LDS in chunks of CG groups.  Piece p of a chunk
+        // = (group p / NL, row tile p % NL); wave w issues pieces w, w + 4, ...
         const float* acur = (t & 1) ? abuf1 : abuf0;
         const __amdgpu_buffer_rsrc_t rsA =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)tb * NG * 256), 0, TPP * NG * 1024, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)tile0 * NG * 256), 0, ((TPP - 1) * TS + 1) * NG * 1024, 0x00020000);
         auto issue_chunk = [&](int c) __attribute__((always_inline)) {
             float* dstb = Ab + (c % NBUF) * CHF;
 #pragma unroll
             for (int q = 0; q < DPW; ++q) {
                 const int p = wave + 4 * q;
-                if (p < TPP * CG) {
-                    const int gq = p / TPP, i = p % TPP;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dstb + (gq * TPP + i) * 256), 16, lane * 16,
-                                                             (i * NG + c * CG + gq) * 1024, 0, 16);                     // aux 16 = sc1
-                }
+                const int gq = p / NL, i = p % NL;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dstb + (gq * TPP + i) * 256), 16, lane * 16,
+                                                         (i * TS * NG + c * CG + gq) * 1024, 0, 16);                     // aux 16 = sc1
             }
         };
-        static_assert((TPP * CG) % 4 == 0, "every wave issues exactly DPW loads per chunk (the vmcnt bookkeeping below)");
         static_for<0, NBUF - 1>([&](auto c_) { issue_chunk(decltype(c_)::value); });
         static_for<0, NCH>([&](auto c_) {
             constexpr int c = decltype(c_)::value;
@@ -456,19 +459,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if constexpr (c == 0) C4_STAMP(2);                    // first chunk in LDS
             if constexpr (c + NBUF - 1 < NCH) issue_chunk(c + NBUF - 1);
             const f32x4* ab = reinterpret_cast<const f32x4*>(Ab + (c % NBUF) * CHF) + lane;
-            f32x4 a[2][TPP];
+            f32x4 a[2][NL];
 #pragma unroll
-            for (int i = 0; i < TPP; ++i) a[0][i] = ab[i * 64];
+            for (int i = 0; i < NL; ++i) a[0][i] = ab[i * 64];
             static_for<0, CG>([&](auto q_) {
                 constexpr int gq = decltype(q_)::value;
                 if constexpr (gq + 1 < CG) {
 #pragma unroll
-                    for (int i = 0; i < TPP; ++i) a[(gq + 1) & 1][i] = ab[((gq + 1) * TPP + i) * 64];
+                    for (int i = 0; i < NL; ++i) a[(gq + 1) & 1][i] = ab[((gq + 1) * TPP + i) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, 4>([&](auto e_) {
                     constexpr int e = decltype(e_)::value;
-                    static_for<0, TPP>([&](auto i_) {
+                    static_for<0, NL>([&](auto i_) {
                         constexpr int i = decltype(i_)::value;
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gq & 1][i][e], breg[(c * CG + gq) * 4 + e], acc[i], 0, 0, 0);
                     });
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+        }
         C4_STAMP(3);                                              // chunk loop (MFMAs)
         // ---- per row tile: the gates of a unit meet through the wave's LDS tile; BasicLSTMCell pointwise (EPI_LSTM expressions).
         // Results are STAGED in LDS (the chunk buffers are idle until the next step's first DMA): a wave's tile is 16 rows x
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         constexpr int ST = TPP * 256;                             // floats per staged array
         float hv[TPP], siv[TPP], tjv[TPP], sfv[TPP], sov[TPP];
 #pragma unroll
-        for (int i = 0; i < TPP; ++i) {
+        for (int i = 0; i < NL; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
             __builtin_amdgcn_wave_barrier();
@@ -513,12 +517,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
         if (t + 1 < T) {
             // h_{t+1} blocks: wave w writes row tiles w, w + 4; lane L = kq * 16 + r takes row r, units kq + 4e
-            const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(((t & 1) ? abuf0 : abuf1) + ((size_t)tb * NG + cg) * 256, 0,
-                                                                                   TPP * NG * 1024, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(((t & 1) ? abuf0 : abuf1) + ((size_t)tile0 * NG + cg) * 256, 0,
+                                                                                   ((TPP - 1) * TS + 1) * NG * 1024, 0x00020000);
 #pragma unroll
-            for (int q = 0; q < (TPP + 3) / 4; ++q) {
+            for (int q = 0; q < (NL + 3) / 4; ++q) {
                 const int i = wave + 4 * q;
-                if (i < TPP) {
+                if (i < NL) {
                     const int r = lane & 15, kq = lane >> 4;
                     u32x4v w4;
 #pragma unroll
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     // (rows >= M of a tile and units >= H of the last group carry garbage-free zeros only if they were computed
                     //  from zeros: rows >= M read zero A fragments and zero partials -> finite values, never read back as
                     //  operands of valid rows; units >= H multiply zero weight rows of every consumer)
-                    bstore16_sc1(rsN, w4, (i * NG * 256 + lane * 4) * 4, 0);
+                    bstore16_sc1(rsN, w4, (i * TS * NG * 256 + lane * 4) * 4, 0);
                 }
             }
             gs.arrive(tid);
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         C4_STAMP(5);                                              // hand-off stores + drain + arrive
         // ---- behind the hand-off: the DropoutWrapper output (one Philox block per element) and the rest of the staging
 #pragma unroll
-        for (int i = 0; i < TPP; ++i) {
+        for (int i = 0; i < NL; ++i) {
             float ov = hv[i];
             if (g.out && g.keep < 1.0f)
                 ov = (hv[i] / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)u, g.keep);
@@ -548,21 +552,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();
         // ---- histories (nobody in this launch reads them): block (array, tile) = [16 rows][16 units]; lane = (row, quarter)
         // writes 16 bytes; an element outside the problem carries an out-of-range offset and its store is dropped
-        {
+        if constexpr (NL > 0) {
             const int srow = lane >> 2, sq = lane & 3;
             const int uq = cg * 16 + sq * 4;
             const __amdgpu_buffer_rsrc_t rsCh = __builtin_amdgcn_make_buffer_rsrc(g.C + (size_t)(t + 1) * g.state_tstride, 0, (int)0x80000000u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsHh = __builtin_amdgcn_make_buffer_rsrc(g.Hh + (size_t)(t + 1) * g.state_tstride, 0, (int)0x80000000u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(g.out ? g.out + (size_t)t * g.out_tstride : g.C, 0, g.out ? (int)0x80000000u : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(g.gates ? g.gates + (size_t)t * g.gates_tstride : g.C, 0, g.gates ? (int)0x80000000u : 0, 0x00020000);
-            // 7 TPP blocks over the 4 waves: block b = array * TPP + tile
+            // 7 NL blocks over the 4 waves: block b = array * NL + tile
 #pragma unroll
-            for (int q = 0; q < (7 * TPP + 3) / 4; ++q) {
+            for (int q = 0; q < (7 * NL + 3) / 4; ++q) {
                 const int bidx = wave + 4 * q;
-                if (bidx < 7 * TPP) {
-                    const int arr = bidx / TPP, i = bidx % TPP;
-                    const int row = (tb + i) * 16 + srow;
-                    const bool ok = row < M && uq < H;
+                if (bidx < 7 * NL) {
+                    const int arr = bidx / NL, i = bidx % NL;
+                    const int vrow = (tile0 + i * TS) * 16 + srow;
+                    const bool ok = vrow < M && uq < H;
+                    int row = vrow;
+                    if constexpr (LIVE) row = arow_l[i * 16 + srow];
                     const u32x4v v = __builtin_bit_cast(u32x4v, *reinterpret_cast<const f32x4*>(stg + arr * ST + (i * 16 + srow) * 16 + sq * 4));
                     const int ho = ok ? (row * H + uq) * 4 : (int)0x80000000u;
                     const int go = ok ? (row * 4 * H + uq) * 4 : (int)0x80000000u;
@@ -577,6 +583,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (t + 1 < T) load_cinit(t + 1);
 #endif
         C4_STAMP(6);                                              // history stores issued
+    };
+    for (int t = 0; t < T; ++t) {
+        if constexpr (!LIVE) {
+            step(std::integral_constant<int, TPP>{}, t);
+        } else {
+            // live tiles of this part: image tiles 0 .. ceil(n / 16) - 1 hold the n live virtual rows; this part owns tiles rp, rp + 4, ..
+            int n = g.nlive ? g.nlive[t] : M;
+            n = n < M ? n : M;
+            int nl = (((n + 15) >> 4) - rp + 3) >> 2;
+            nl = nl < 0 ? 0 : (nl > TPP ? TPP : nl);
+            nl = __builtin_amdgcn_readfirstlane(nl);
+            bool done = false;
+            static_for<0, TPP + 1>([&](auto k_) {
+                if (!done && nl == decltype(k_)::value) { step(k_, t); done = true; }
+            });
+        }
     }
 #ifdef S2VT_C4_STAMP
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 251)) {
@@ -588,7 +610,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 typedef void (*ChainFn)(const ChainArgs);
-struct ChainCfg { int ng, tmw, nc; ChainFn fn; const char* name; };     // nc == 4: the register-weights form (tmw = row tiles per part)
+struct ChainCfg { int ng, tmw, nc; ChainFn fn; const char* name; ChainFn fn_live; const char* name_live; };     // nc == 4: the register-weights form (tmw = row tiles per part); fn_live: its live-row variant
 constexpr int kMaxTmw = 6;                                     // 6 row tiles per wave x 4 waves x 16 rows = 384 rows
 const ChainCfg kChain[] = {
     {8, 1, 1, lstm_chain_kernel<8, 1, 1>, "chain(ng8,m64)"},      {8, 2, 1, lstm_chain_kernel<8, 2, 1>, "chain(ng8,m128)"},
@@ -601,7 +623,8 @@ const ChainCfg kChain[] = {
     {64, 1, 2, lstm_chain_kernel<64, 1, 2>, "chain2(ng64,m128)"}, {64, 2, 2, lstm_chain_kernel<64, 2, 2>, "chain2(ng64,m256)"},
     {64, 3, 2, lstm_chain_kernel<64, 3, 2>, "chain2(ng64,m384)"},
     // weights in registers, 16 units x a quarter of the row tiles per workgroup (M > 256): tmw = row tiles per part
-    {64, 5, 4, lstm_chain4_kernel<64, 5>, "chain4(ng64,m320)"},   {64, 6, 4, lstm_chain4_kernel<64, 6>, "chain4(ng64,m384)"},
+    {64, 5, 4, lstm_chain4_kernel<64, 5, false>, "chain4(ng64,m320)", lstm_chain4_kernel<64, 5, true>, "chain4(ng64,m320)[live]"},
+    {64, 6, 4, lstm_chain4_kernel<64, 6, false>, "chain4(ng64,m384)", lstm_chain4_kernel<64, 6, true>, "chain4(ng64,m384)[live]"},
 };
 constexpr int kNumCfg = (int)(sizeof(kChain) / sizeof(kChain[0]));
 constexpr int kMaxDev = 32;
@@ -624,7 +647,7 @@ std::atomic<int> g_hold{0};                // chain_hold(): per-step launches wh
 
 int chain_lds_bytes(const ChainCfg& c)
 {
-    if (c.nc == 4) return (S2VT_C4_NBUF * c.tmw * S2VT_C4_CG * 256 + 4 * 16 * 20) * 4;     // chunk buffers of tmw x CG KB-pieces + the per-wave z tiles
+    if (c.nc == 4) return (S2VT_C4_NBUF * c.tmw * S2VT_C4_CG * 256 + 4 * 16 * 20 + c.tmw * 16) * 4;     // chunk buffers of tmw x CG KB-pieces + the per-wave z tiles + (live form) the rows behind the virtual rows
     return (c.ng * c.nc * 256 + 4 * 16 * 20) * 4;
 }
 
@@ -686,6 +709,8 @@ DevState* dev_state()
         for (int i = 0; ok && i < kNumCfg; ++i) {
             const ChainCfg& c = kChain[i];
             ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(c)) == hipSuccess;
+            if (ok && c.fn_live)
+                ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn_live), hipFuncAttributeMaxDynamicSharedMemorySize, chain_lds_bytes(c)) == hipSuccess;
             int n = 0;
             // co-residency is CHECKED, not assumed: workgroups of this configuration one CU can hold (registers, LDS, waves)
             if (ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(c.fn), 256, chain_lds_bytes(c)) == hipSuccess)
@@ -726,6 +751,15 @@ bool chain_eligible(int M, int H)
     return (long)d->per_cu[ci] * d->num_cus >= grid;           // every workgroup of the grid fits on the chip at once
 }
 
+bool bwd_chain_live_capable(int M, int H);                     // (chain_bwd.hip)
+bool chain_live_capable(int M, int H)
+{
+    static const bool off = [] { const char* e = getenv("S2VT_CHAIN_LIVE"); return e && e[0] == '0'; }();      // dev knob: dense recurrences under live-row updates
+    if (off || !chain_eligible(M, H)) return false;
+    const int ci = chain_cfg(M, H);
+    return ci >= 0 && kChain[ci].fn_live != nullptr && bwd_chain_live_capable(M, H);
+}
+
 static unsigned spin_limit()
 {
     static const unsigned v = [] { const char* e = getenv("S2VT_CHAIN_SPIN_LIMIT"); return e ? (unsigned)strtoul(e, nullptr, 10) : kSpinLimitDefault; }();   // dev / test knob
@@ -743,6 +777,9 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
     const int ci = chain_cfg(a.M, a.H);
     const ChainCfg& c = kChain[ci];
     ChainArgs a2 = a;
+    const bool live = a.perm && a.nlive && c.fn_live;          // (other forms: a dense launch, the same results)
+    if (!live) { a2.perm = nullptr; a2.nlive = nullptr; }
+    const ChainFn fn = live ? c.fn_live : c.fn;
     a2.status = g_status_dev;
     a2.fault = d->fault;
     a2.spin_limit = spin_limit();
@@ -781,8 +818,9 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
         g_last_device = dev;
         return hipEventRecord(g_last_done, st);
     };
-    if (!prof_wants(5, ci)) {
-        hipLaunchKernelGGL(c.fn, grid, dim3(256), lds, st, a2);
+    const int pci = live ? ci + 100 : ci;                      // (the live-row variant is a profiler row of its own)
+    if (!prof_wants(5, pci)) {
+        hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, a2);
         e = hipGetLastError();
         return e != hipSuccess ? e : mark_done();
     }
@@ -790,9 +828,9 @@ hipError_t launch_lstm_chain(const ChainArgs& a, hipStream_t st)
     hipError_t pe = prof_events(&e0, &e1);
     if (pe != hipSuccess) return pe;
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(c.fn, grid, dim3(256), lds, st, a2);
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, a2);
     (void)hipEventRecord(e1, st);
-    prof_record(5, ci, c.name, flops, e0, e1);
+    prof_record(5, pci, live ? c.name_live : c.name, live ? 0.0 : flops, e0, e1);     // (live rows: the executed count lives on the device -- no rate is claimed)
     e = hipGetLastError();
     return e != hipSuccess ? e : mark_done();
 }

@@ -46,6 +46,7 @@ struct BwdChainArgs {
     unsigned* status; unsigned* fault; unsigned spin_limit;
     int ncg;                                           // unit groups = ceil(H / (16 NC))
     int tpp, img_tiles;                                // row tiles of a row part; row tiles of one image (= parts * tpp)
+    const int32_t* perm; const int32_t* nlive;         // LIVE kernels: virtual row -> row of the arrays; live virtual rows per step
 };
 
 // NC = 16-unit column tiles per workgroup.  NC = 1: workgroup (j, g) takes every row tile (4 TMW of them).  NC = 2 (M > 256
@@ -497,9 +498,265 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// The same with LIVE ROWS (round 4): the rows are VIRTUAL, sorted by caption length (row v of the images is row g.perm[v] of the caller's arrays), the
+// tiles of a part interleaved (tile i of part p = image tile 4 i + p), and step t runs only the row tiles that hold one of the
+// first g.nlive[t] virtual rows -- the form of lstm_chain4_kernel<.., true> (chain.hip).  A tile's steps form a suffix-free prefix
+// 0 .. len-1 of the unroll, so walking backwards a tile JOINS once and then stays: it joins with dc = 0 and a zero dz image (the
+// launcher zeroes the images; a dead tile never writes its slots), exactly what the dense pass computes for it from the zero
+// upstream gradients of the masked positions.  Workgroup (j, gate, part) then finishes column tile `gate` of every live row tile.
+// (A kernel of its own rather than a flag of the one above: at 510 of 512 registers the dense form's allocation does not survive
+// being generated from shared source -- 14 spills and 60 bytes of scratch when it was tried.)
+template <int NG, int TPP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_bwd_chain4_live_kernel(const BwdChainArgs g)
+{
+    constexpr bool LIVE = true;
+    constexpr int NC = 4;                                      // (name of the kernel above: column tiles per workgroup)
+    constexpr int CG = 8, NCH = NG / CG, NBUF = 3;             // k-groups per chunk, chunks per step, LDS chunk buffers
+    constexpr int CHF = TPP * CG * 256;                        // floats per chunk buffer
+    static_assert(NG % CG == 0 && NCH >= NBUF && CG % 4 == 0, "chunking");
+    constexpr int ZS = 20;
+    constexpr int PS = TPP;                                    // (row tile, column tile) slots one workgroup finishes per step: tpp * 4 / 4 gates
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ab = smem;                                          // [NBUF][CG][TPP][64 lanes][4]: the A ring
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* zb = smem + NBUF * CHF + pwave * (16 * ZS);         // per-wave transpose tile
+    float* dzl = smem + NBUF * CHF + 4 * 16 * ZS;              // [4 gates][16 rows][17]: dz of one finished tile, regrouped for the image stores
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int H = g.H, M = g.M, T = g.T;
+    // workgroup id -> (unit group, gate, row part): the four gates of a (unit group, part) share blockIdx % 8
+    const int wg = (int)blockIdx.x;
+    const int gate = (wg >> 3) & 3;
+    const int part = (wg >> 5) & 3;
+    const int jj = (wg >> 7) * 8 + (wg & 7);
+    if (jj >= g.ncg) return;                                   // (grid padded to whole groups of 8: these never take part)
+    const int u0 = jj * 16 * NC;
+    const int tpp = g.tpp;                                     // row tiles of a part
+    const int NT = g.img_tiles;                                // row tiles of an image (= parts * tpp)
+    const size_t img_floats = (size_t)NT * NG * 256;           // one gate image
+    constexpr int TS = LIVE ? 4 : 1;                           // image tiles between consecutive row tiles of this workgroup
+    const int tile0 = LIVE ? part : part * tpp;                // image tile of this workgroup's row tile 0
+
+    // ---- this wave's column tile of the slice -> registers, once: k-step s holds B[k = 4s + lq][n = l15] = Whh[u0 + 16 w + l15][gate H + k]
+    float breg[4 * NG];
+    {
+        const int un = u0 + 16 * pwave + l15;
+#pragma unroll
+        for (int s_ = 0; s_ < 4 * NG; ++s_) {
+            const int kk = 4 * s_ + lq;
+            breg[s_] = (un < H && kk < H) ? g.W[(size_t)(g.kw0 + un) * g.ldw + (size_t)gate * H + kk] : 0.0f;
+        }
+    }
+
+    // ---- the (row, unit) this thread finishes at every step, per slot of the part's tpp * NC (row tile, column tile) pairs.
+    // Dense: slot = gate * PSr + i (PSr = slots per workgroup, the four gate workgroups share them in order); LIVE: row tile i,
+    // column tile `gate` (balanced for any count of live tiles)
+    const int pr = tid >> 4, pn = tid & 15;                    // row within the tile, unit within the column tile
+    const int nslots = tpp * NC, psr = (nslots + 3) >> 2;
+    float dc_reg[PS], cnew[PS];
+    uint32_t vid[PS], sid[PS];
+    bool pok[PS];
+    int pm[PS], pu[PS], ptile[PS], pc[PS];
+    auto slot_of = [&](int i) __attribute__((always_inline)) { return LIVE ? i * NC + gate : gate * psr + i; };
+#pragma unroll
+    for (int i = 0; i < PS; ++i) {
+        const int slot = slot_of(i);
+        ptile[i] = slot / NC; pc[i] = slot % NC;              // row tile within the part, column tile
+        const int vrow = (tile0 + ptile[i] * TS) * 16 + pr;
+        pu[i] = u0 + pc[i] * 16 + pn;
+        pok[i] = i < psr && slot < nslots && vrow < M && pu[i] < H;
+        pm[i] = vrow;
+        if constexpr (LIVE) pm[i] = pok[i] ? (int)g.perm[vrow] : 0;
+        dc_reg[i] = 0.0f;
+        cnew[i] = pok[i] ? g.C[(size_t)T * g.state_tstride + (size_t)pm[i] * H + pu[i]] : 0.0f;      // c_{T-1}
+        vid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.video_id[pm[i]] : 0u;
+        sid[i] = (g.keep < 1.0f && pok[i]) ? (uint32_t)g.sample_id[pm[i]] : 0u;
+    }
+    const int cluster = jj * NC + part;
+    gu32* const ccount = (gu32*)g.sync + (kChainSyncBytes / 4) + cluster * 32;
+    const __amdgpu_buffer_rsrc_t rsEx = __builtin_amdgcn_make_buffer_rsrc(g.ex, 0, g.ncg * NC * 4 * tpp * NC * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsImg = __builtin_amdgcn_make_buffer_rsrc(g.img, 0, (int)(8 * img_floats * 4), 0x00020000);
+    GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, g.ncg, false, 4u * NC};
+    __syncthreads();
+
+    // live row tiles of this part at step t (dense: all)
+    auto live_tiles = [&](int t) __attribute__((always_inline)) {
+        if constexpr (!LIVE) return TPP;
+        else {
+            int n = g.nlive ? g.nlive[t] : M;
+            n = n < M ? n : M;
+            int nl = (((n + 15) >> 4) - part + 3) >> 2;
+            nl = nl < 0 ? 0 : (nl > TPP ? TPP : nl);
+            return __builtin_amdgcn_readfirstlane(nl);
+        }
+    };
+
+    float sg[PS][4], cprev[PS], dx[PS];
+    auto load_step = [&](int t, int nl) __attribute__((always_inline)) {        // operands of step t's pointwise part (independent of the recurrence)
+#pragma unroll
+        for (int i = 0; i < PS; ++i) {
+            const bool ok = pok[i] && i < nl;
+            const float* gp = g.gates + (size_t)t * g.gates_tstride + (size_t)pm[i] * 4 * H + pu[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sg[i][q] = ok ? gp[(size_t)q * H] : 0.0f;
+            cprev[i] = ok ? g.C[(size_t)t * g.state_tstride + (size_t)pm[i] * H + pu[i]] : 0.0f;
+            dx[i] = (ok && g.dext && t >= g.dext_t0) ? g.dext[(size_t)(t - g.dext_t0) * g.dext_tstride + (size_t)pm[i] * g.ld_ext + pu[i]] : 0.0f;
+            cnew[i] = ok ? g.C[(size_t)(t + 1) * g.state_tstride + (size_t)pm[i] * H + pu[i]] : 0.0f;      // (a tile that joins at this step has no c_t from the step before)
+        }
+    };
+    const size_t exc = (size_t)cluster * 4 * nslots;              // tiles of this cluster's exchange before its own
+    // dz_{t+1}[:, gate block] @ slice^T for NL row tiles, the partial tiles handed to the cluster's exchange: the only part of a
+    // step that is instantiated per count of live tiles
+    auto product = [&](auto nl_, const int t) __attribute__((always_inline)) {
+        constexpr int NL = decltype(nl_)::value;
+        constexpr int DPW = NL * CG / 4;                       // DMA instructions per wave per chunk
+        const float* acur = g.img + (size_t)((t + 1) & 1) * 4 * img_floats + (size_t)gate * img_floats;
+        const __amdgpu_buffer_rsrc_t rsA =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)tile0 * NG * 256), 0, ((TPP - 1) * TS + 1) * NG * 1024, 0x00020000);
+        // chunk c = groups c*CG ..; piece p = gq * NL + i; wave w issues pieces w, w + 4, .. (static: CG * NL / 4 each)
+        auto issue_chunk = [&](auto c_) __attribute__((always_inline)) {
+            constexpr int c = decltype(c_)::value;
+            float* dstb = Ab + (c % NBUF) * CHF;
+            static_for<0, DPW>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                const int p = pwave + 4 * q;
+                const int gq = p / NL, i = p % NL;
+                const int vo = (tile0 + i * TS) * 16 < M ? lane * 16 : (int)0x80000000u;          // row tiles beyond the problem: zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr4)(dstb + (gq * TPP + i) * 256), 16, vo, (i * TS * NG + c * CG + gq) * 1024, 0, 16);   // aux 16 = sc1
+            });
+        };
+        f32x4 acc[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        static_for<0, NBUF - 1>([&](auto c_) { issue_chunk(c_); });
+        static_for<0, NCH>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            constexpr int issued = c + NBUF - 1 < NCH ? c + NBUF - 1 : NCH;
+            constexpr int later = issued - (c + 1);
+            static_assert(later * DPW <= 63, "vmcnt range");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(later * DPW) : "memory");
+            __syncthreads();
+            if constexpr (c + NBUF - 1 < NCH) issue_chunk(std::integral_constant<int, c + NBUF - 1>{});
+            const f32x4* ab = reinterpret_cast<const f32x4*>(Ab + (c % NBUF) * CHF) + lane;
+            f32x4 a[2][NL];
+#pragma unroll
+            for (int i = 0; i < NL; ++i) a[0][i] = ab[i * 64];
+            static_for<0, CG>([&](auto q_) {
+                constexpr int gq = decltype(q_)::value;
+                if constexpr (gq + 1 < CG) {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) a[(gq + 1) & 1][i] = ab[((gq + 1) * TPP + i) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    static_for<0, NL>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gq & 1][i][e], breg[(c * CG + gq) * 4 + e], acc[i], 0, 0, 0);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        __syncthreads();                                          // (everybody is done with the ring before the exchange tiles reuse zb / the next step's DMA)
+        // ---- partial tiles -> the cluster's exchange [gate][row tile of the part][column tile] (row-major 16 x 16, one
+        // write-through 16-byte store per lane)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 row = *reinterpret_cast<const f32x4*>(zb + (lane >> 2) * ZS + (lane & 3) * 4);
+            __builtin_amdgcn_wave_barrier();
+            bstore16_sc1(rsEx, __builtin_bit_cast(u32x4v, row), (int)(((exc + (size_t)gate * nslots + (size_t)i * NC + pwave) * 256 + lane * 4) * 4), 0);
+        }
+    };
+
+    int nl = live_tiles(T - 1);
+    load_step(T - 1, nl);
+    unsigned arrival = 0, carrival = 0;                        // grid-wide hand-offs so far; exchanges of this cluster so far
+    for (int t = T - 1; t >= 0; --t) {
+        float dh[PS];
+#pragma unroll
+        for (int i = 0; i < PS; ++i) dh[i] = 0.0f;
+        if (t < T - 1) {
+            gs.wait_all(arrival, pwave, lane);
+            ++arrival;
+            if (nl > 0) {                                         // (uniform over the cluster: the four gate workgroups of a part agree)
+                bool done = false;
+                static_for<1, TPP + 1>([&](auto k_) {
+                    if (!done && nl == decltype(k_)::value) { product(k_, t); done = true; }
+                });
+                gs.arrive_one(ccount, tid);
+                gs.wait_one(ccount, 4u * (carrival + 1u), pwave, lane);
+                ++carrival;
+#pragma unroll
+                for (int i = 0; i < PS; ++i) {
+                    float s_ = 0.0f;
+                    if (i < nl) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            s_ += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * nslots + slot_of(i)) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    }
+                    dh[i] = s_;
+                }
+            }
+        }
+        // ---- BasicLSTMCell backward pointwise (the expressions of lstm_bwd_pointwise_kernel), one (row, unit) per thread and slot
+        float dzv[PS][4];
+#pragma unroll
+        for (int i = 0; i < PS; ++i) {
+            float d = dx[i];
+            if (g.keep < 1.0f && g.dext && t >= g.dext_t0)
+                d = (d / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)pu[i], g.keep);
+            const float dht = dh[i] + d;
+            const float si = sg[i][0], tj = sg[i][1], sf = sg[i][2], so = sg[i][3];
+            const float tc = dm_tanhf(cnew[i]);
+            const float dc = dht * so * (1.f - tc * tc) + dc_reg[i];
+            dzv[i][0] = dc * tj * si * (1.f - si);
+            dzv[i][1] = dc * si * (1.f - tj * tj);
+            dzv[i][2] = dc * cprev[i] * sf * (1.f - sf);
+            dzv[i][3] = dht * tc * so * (1.f - so);
+            if (i < nl) dc_reg[i] = dc * sf;                     // (a tile that has not joined yet keeps dc = 0: its operands above are zeros)
+        }
+        if (t > 0) {
+            // ---- dz_t -> the four gate images of the other parity, regrouped through LDS so that every thread writes ONE
+            // 16-byte fragment slot: thread (gate q = tid / 64, slot L = tid % 64) takes row L % 16, units L / 16 + 4e
+            const size_t inext = (size_t)(t & 1) * 4 * img_floats;
+#pragma unroll
+            for (int i = 0; i < PS; ++i) {
+                if (!(i < nl)) continue;                         // (uniform over the workgroup)
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dzl[(q * 16 + pr) * 17 + pn] = pok[i] ? dzv[i][q] : 0.0f;
+                __syncthreads();
+                const int q = tid >> 6, L = tid & 63, r = L & 15, kq = L >> 4;
+                u32x4v w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(dzl[(q * 16 + r) * 17 + kq + 4 * e]);
+                const size_t dst = inext + (size_t)q * img_floats + ((size_t)((tile0 + ptile[i] * TS) * NG + jj * NC + pc[i]) * 64 + L) * 4;
+                bstore16_sc1(rsImg, w, (int)(dst * 4), 0);
+            }
+            gs.arrive(tid);
+        }
+        // ---- history: dZ[t] (read by the weight-gradient contractions after the launch), then the next step's operands
+#pragma unroll
+        for (int i = 0; i < PS; ++i) {
+            if (!pok[i] || !(i < nl)) continue;
+            float* zp = g.dZ + (size_t)t * g.dz_tstride + (size_t)pm[i] * 4 * H + pu[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zp[(size_t)q * H] = dzv[i][q];
+        }
+        if (t > 0) {
+            nl = live_tiles(t - 1);
+            load_step(t - 1, nl);
+        }
+    }
+}
+
 // ---- backward recurrence: configurations, eligibility, launcher
 typedef void (*BwdFn)(const BwdChainArgs);
-struct BwdCfg { int ng, tmw, nc; BwdFn fn; const char* name; };
+struct BwdCfg { int ng, tmw, nc; BwdFn fn; const char* name; BwdFn fn_live; const char* name_live; };     // fn_live: the live-row variant of the register-weights form
 const BwdCfg kBwd[] = {
     {8, 1, 1, lstm_bwd_chain_kernel<8, 1, 1>, "bchain(ng8,m64)"},     {8, 2, 1, lstm_bwd_chain_kernel<8, 2, 1>, "bchain(ng8,m128)"},
     {8, 4, 1, lstm_bwd_chain_kernel<8, 4, 1>, "bchain(ng8,m256)"},    {64, 1, 1, lstm_bwd_chain_kernel<64, 1, 1>, "bchain(ng64,m64)"},
@@ -507,7 +764,8 @@ const BwdCfg kBwd[] = {
     // 32 units x half the row tiles per workgroup (tmw = row tiles per wave of a part): 257 .. 384 rows
     {64, 3, 2, lstm_bwd_chain_kernel<64, 3, 2>, "bchain2(ng64,m384)"},
     // weights in registers, 64 units x a gate x a quarter of the row tiles per workgroup (tmw = row tiles per part)
-    {64, 5, 4, lstm_bwd_chain4_kernel<64, 5>, "bchain4(ng64,m320)"}, {64, 6, 4, lstm_bwd_chain4_kernel<64, 6>, "bchain4(ng64,m384)"},
+    {64, 5, 4, lstm_bwd_chain4_kernel<64, 5>, "bchain4(ng64,m320)", lstm_bwd_chain4_live_kernel<64, 5>, "bchain4(ng64,m320)[live]"},
+    {64, 6, 4, lstm_bwd_chain4_kernel<64, 6>, "bchain4(ng64,m384)", lstm_bwd_chain4_live_kernel<64, 6>, "bchain4(ng64,m384)[live]"},
 };
 constexpr int kNumBwd = (int)(sizeof(kBwd) / sizeof(kBwd[0]));
 int bwd_lds_bytes(const BwdCfg& c)
@@ -549,6 +807,8 @@ BwdDev* bwd_dev_state()
         for (int i = 0; ok && i < kNumBwd; ++i) {
             const BwdCfg& c = kBwd[i];
             ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(c)) == hipSuccess;
+            if (ok && c.fn_live)
+                ok = hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn_live), hipFuncAttributeMaxDynamicSharedMemorySize, bwd_lds_bytes(c)) == hipSuccess;
             int n = 0;
             if (ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(c.fn), 256, bwd_lds_bytes(c)) == hipSuccess)
                 d.per_cu[i] = n;
@@ -575,6 +835,13 @@ bool bwd_chain_eligible(int M, int H)
     if (ci < 0) return false;
     const int nc = kBwd[ci].nc, ncg = (H + 16 * nc - 1) / (16 * nc);
     return (long)b->per_cu[ci] * d->num_cus >= 4L * nc * ncg;   // every ACTIVE workgroup fits on the chip at once
+}
+
+bool bwd_chain_live_capable(int M, int H)
+{
+    if (!bwd_chain_auto(M, H)) return false;
+    const int ci = bwd_cfg(M, H);
+    return ci >= 0 && kBwd[ci].fn_live != nullptr;
 }
 
 bool bwd_chain_auto(int M, int H)
@@ -632,6 +899,8 @@ hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
     k.keep = a.keep; k.seed_lo = a.seed_lo; k.seed_hi = a.seed_hi; k.drop_code0 = a.drop_code0;
     k.video_id = a.video_id; k.sample_id = a.sample_id;
     k.img = a.img; k.ex = a.ex; k.sync = a.sync;
+    const bool live = a.perm && a.nlive && c.fn_live;
+    if (live) { k.perm = a.perm; k.nlive = a.nlive; }
     k.status = hst.status_dev; k.fault = hst.fault; k.spin_limit = hst.spin_limit;
     int nc_, tmw_, tpp_, ncg_;
     bwd_geometry(a.M, a.H, &nc_, &tmw_, &tpp_, &ncg_);
@@ -650,16 +919,17 @@ hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
     const dim3 grid((unsigned)((k.ncg + 7) / 8 * 32 * nc_));
     const double flops = 2.0 * a.M * (double)a.H * 4.0 * a.H * (a.T - 1);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool prof = prof_wants(6, ci);
+    const int pci = live ? ci + 100 : ci;                      // (the live-row variant is a profiler row of its own)
+    const bool prof = prof_wants(6, pci);
     if (prof) {
         hipError_t pe = prof_events(&e0, &e1);
         if (pe != hipSuccess) return pe;
         (void)hipEventRecord(e0, st);
     }
-    hipLaunchKernelGGL(c.fn, grid, dim3(256), bwd_lds_bytes(c), st, k);
+    hipLaunchKernelGGL(live ? c.fn_live : c.fn, grid, dim3(256), bwd_lds_bytes(c), st, k);
     if (prof) {
         (void)hipEventRecord(e1, st);
-        prof_record(6, ci, c.name, flops, e0, e1);
+        prof_record(6, pci, live ? c.name_live : c.name, live ? 0.0 : flops, e0, e1);     // (live rows: the executed count lives on the device -- no rate is claimed)
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -115,7 +115,13 @@ struct ChainArgs {
     unsigned* fault;                                   // (set by the launcher) device-resident fault word: 1 after a timeout until chain_ack()
     unsigned spin_limit;                               // (set by the launcher) polls before a grid-wide wait gives up
     int ncg, tpp, img_tiles;                           // (set by the launcher) column groups, row tiles per row part, row tiles of one state image
+    // optional (the register-weights form, 257-384 rows; ignored -- a dense launch, same results -- elsewhere): rows sorted by length.
+    // perm[v] = row of every per-row array that virtual row v stands for (a permutation of 0 .. M-1), nlive[t] = virtual rows
+    // 0 .. nlive[t]-1 are computed at step t (non-increasing in t); the other rows' histories are NOT written at that step
+    const int32_t* perm; const int32_t* nlive;
 };
+bool chain_live_capable(int M, int H);                 // the forward AND backward recurrences of this shape take perm / nlive
+hipError_t launch_row_order(const int32_t* live_rows, int n_live, int N, int Tv, int Tc, int32_t* perm, int32_t* nlive, hipStream_t st);
 constexpr size_t kChainSyncBytes = 9 * 128;            // 8 counter shards + the status line, a block of its own (multiple of 16)
 bool chain_eligible(int M, int H);                     // shape fits the persistent form on this device (and S2VT_CHAIN != 0)
 size_t chain_scratch_floats(int H);
@@ -137,6 +143,7 @@ struct BwdChainLaunch {
     float keep; uint32_t seed_lo, seed_hi, drop_code0;
     const int32_t* video_id; const int32_t* sample_id;
     float* img; float* ex; unsigned* sync;             // scratch, sizes from bwd_chain_scratch (16-byte aligned)
+    const int32_t* perm; const int32_t* nlive;         // optional, as ChainArgs: step t runs virtual rows 0 .. nlive[t]-1 only (their dZ rows are the only ones written)
 };
 bool bwd_chain_eligible(int M, int H);               // the shape fits the persistent form on this device
 bool bwd_chain_auto(int M, int H);                   // ... and it is the faster form there (chosen when the caller does not say)

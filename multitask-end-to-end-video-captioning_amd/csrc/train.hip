@@ -39,6 +39,7 @@ struct TrainWs {
     float* dO2p;         // dO2 of the LIVE rows only (the *_live entry points), scattered into dO2
     float *dZ2p, *dX2p;  // the live decode rows of dZ2 (packed copy) and of dX2 (computed packed, scattered into dX2)
     int32_t* prevp;      // previous word of the live decode rows
+    int32_t *perm, *nlive;   // live rows in the recurrences (chain_live_capable shapes): LSTM2's rows by length, live rows per step
     size_t dXs_floats;   // capacity of dXs
     float* dXs;          // split-K slabs of dX2 / dX1 when they are short of tiles (NULL otherwise)
 };
@@ -106,6 +107,7 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     w.dX2 = c.take<float>(T * n * (H + E)); w.dX1 = c.take<float>(Tv * b * E); w.dH1 = c.take<float>(T * b * H);
     w.slab = c.take<float>((size_t)kMaxSlabs * n * H); w.dc = c.take<float>(n * H);
     w.decidx = c.take<int32_t>(Tv * b);
+    w.perm = c.take<int32_t>(n); w.nlive = c.take<int32_t>(T);
     w.chain_sync = c.take<unsigned>(kChainSyncBytes / 4);
     w.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
     {
@@ -185,7 +187,8 @@ bool params_ok(const s2vt_params* p)
 struct BwdScratch { float* slab; float* dc; float* bimg; float* bex; unsigned* bsync; };
 hipError_t lstm_recurrence_bwd(const float* W, int kw0, const float* gates, const float* C, const float* dext, size_t dext_tstride,
                                int ld_ext, int dext_t0, float* dZ, int M, int H, int T, float keep, uint64_t seed, uint32_t drop_code0,
-                               const int32_t* video_id, const int32_t* sample_id, const BwdScratch& sc, int persistent, hipStream_t st)
+                               const int32_t* video_id, const int32_t* sample_id, const BwdScratch& sc, int persistent, hipStream_t st,
+                               const int32_t* perm = nullptr, const int32_t* nlive = nullptr)
 {
     const size_t MH = (size_t)M * H;
     const bool can = sc.bimg && sc.bex && sc.bsync && bwd_chain_eligible(M, H) && !(reinterpret_cast<uintptr_t>(W) & 15);
@@ -199,6 +202,7 @@ hipError_t lstm_recurrence_bwd(const float* W, int kw0, const float* gates, cons
         a.keep = keep; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code0 = drop_code0;
         a.video_id = video_id; a.sample_id = sample_id;
         a.img = sc.bimg; a.ex = sc.bex; a.sync = sc.bsync;
+        a.perm = perm; a.nlive = nlive;
         return launch_lstm_bwd_chain(a, st);
     }
     const SlabPlan sp = slab_plan(M, H);
@@ -380,13 +384,22 @@ int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const
             float* const dec = w.G2 + (size_t)Tv * 4 * NH;
             ZeroList z;
             z.add(dec, (size_t)Tc * N * 4 * H * 4);
+            // (recurrences that stop the rows behind their <eos> leave those rows' histories unwritten: G2 keeps the zeros of this
+            //  fill there, and the cell states get zeros too, so that a DENSE backward recurrence over this workspace -- the per-step
+            //  form under s2vt_chain_hold -- multiplies its zero gradients with finite values)
+            if (live_rows && Tc <= 128 && chain_live_capable(N, H)) z.add(w.C2 + (size_t)(Tv + 1) * NH, (size_t)Tc * NH * 4);
             HIP_TRY(launch_zero_regions(z, st));
             HIP_TRY(launch_scatter_rows(w.dZ2p, 4 * H, live_rows, n_live, 4 * H, dec, 4 * H, st));
         }
     }
-    // the recurrence continues each chain from its partial in G2[t] and overwrites it with the activated gates
+    // the recurrence continues each chain from its partial in G2[t] and overwrites it with the activated gates.  Live rows at
+    // 257-384 rows: a row behind its <eos> stops stepping (rows by length, live rows per step -- its histories there are not
+    // written and not read: every consumer below and in the backward pass gathers the live pairs)
+    const bool rec_live = live_rows && Tc <= 128 && chain_live_capable(N, H);
+    if (rec_live) HIP_TRY(launch_row_order(live_rows, n_live, N, Tv, Tc, w.perm, w.nlive, st));
     HIP_TRY(lstm_recurrence(p->lstm2_W, H + E, p->lstm2_b, w.G2, (size_t)4 * NH, 4 * H, T, w.C2, w.H2, NH, w.G2, (size_t)4 * NH,
-                            w.O2, NH, N, H, T, keep, ids, 512u, w.chain_abuf, w.chain_sync, st));
+                            w.O2, NH, N, H, T, keep, ids, 512u, w.chain_abuf, w.chain_sync, st, rec_live ? w.perm : nullptr,
+                            rec_live ? w.nlive : nullptr));
     // vocab logits for all Tc steps at once (tf_s2vt.py:153): rows t*N + n -- or only the LIVE ones (row r of the output is
     // row live_rows[r] of the unroll: a masked position's logits feed nothing, its loss term and gradient are exact zeros)
     ASeg so = make_seg(w.O2 + (size_t)Tv * NH, H, H, 0, 0, live_rows);
@@ -549,7 +562,11 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
     // ---- LSTM2 back through time (one persistent launch up to 128 rows: chain.hip)
     {
         BwdScratch sc{w.slab, w.dc, w.bimg, w.bex, w.bsync};
-        HIP_TRY(lstm_recurrence_bwd(p->lstm2_W, H + E, w.G2, w.C2, w.dO2, NH, H, Tv, w.dZ2, N, H, T, keep, seed, 512u, video_id, sample_id, sc, -1, st));
+        // (live rows: the forward pass of this workspace stopped the rows behind their <eos>, see there -- the same order here)
+        const bool rec_live = live_rows && Tc <= 128 && chain_live_capable(N, H);
+        if (rec_live) HIP_TRY(launch_row_order(live_rows, n_live, N, Tv, Tc, w.perm, w.nlive, st));
+        HIP_TRY(lstm_recurrence_bwd(p->lstm2_W, H + E, w.G2, w.C2, w.dO2, NH, H, Tv, w.dZ2, N, H, T, keep, seed, 512u, video_id, sample_id, sc, -1, st,
+                                    rec_live ? w.perm : nullptr, rec_live ? w.nlive : nullptr));
     }
     // Live rows: the packed copies of the live dZ2 rows / previous words are read on BOTH streams (weight gradients on the side
     // stream, dX2 and the embedding scatter on the caller's), so they are made on the caller's stream, ahead of the fork

@@ -111,3 +111,73 @@ def test_live_rows_helper_thresholds():
     assert mdl.live_rows(torch.as_tensor(m).cuda(), 3) is None and mdl.live_rows(None, 3) is None
     m[1, 2] = 1                                                       # a hole: row 1 is masked at step 1 and live again at step 2
     assert mdl.live_rows(m, 3) is None                               # not a prefix per row: the dense pass
+
+
+BIG = dict(dim_image=64, n_words=300, word_dim=32, lstm_dim=256, n_video_lstm_step=3, n_caption_lstm_step=9)
+
+
+@pytest.mark.parametrize("B,rep,keep", [(64, 5, 0.9), (64, 6, 1.0), (66, 5, 1.0)])
+def test_live_rows_stop_inside_the_recurrences(gpu, oracle, B, rep, keep):
+    """257-384 rows (the register-weights recurrences, chain.hip / chain_bwd.hip): with a live list the rows are sorted by length
+    on the device and a row tile behind every <eos> of its rows stops stepping, forward and backward.  Logits and loss terms of the
+    live rows stay bit-identical to the dense pass (same chains), gradients equal to the noise of the order-free reductions -- and
+    the launches that ran are the [live] variants."""
+    import torch
+    from s2vt_amd import hostglue, ops
+    d = oracle.Dims(label_dim=0, **BIG)
+    p = oracle.init_params(d, seed=11)
+    rng = np.random.default_rng(12)
+    for k in ("lstm1_b", "lstm2_b", "encode_image_b", "embed_word_b"):
+        p[k] = rng.uniform(-.1, .1, p[k].shape).astype(np.float32)
+    N, Tc = B * rep, d.n_caption_lstm_step
+    video = np.abs(rng.standard_normal((B, d.n_video_lstm_step, d.dim_image)) * 0.5).astype(np.float32)
+    cap = rng.integers(2, d.n_words, (N, Tc)).astype(np.int32)
+    ln = np.minimum(rng.poisson(2.5, N), Tc - 2)                 # mask length = ln + 1: short rows, a few long ones
+    ln[7] = Tc - 2
+    for n in range(N):
+        cap[n, ln[n]:] = 0
+    vid = np.tile(np.arange(B, dtype=np.int32) + 5, rep); sid = np.repeat(np.arange(rep, dtype=np.int32), B)
+    mask = hostglue.masks_from_ids(cap)
+    steps = int(np.flatnonzero(mask.any(0))[-1]) + 1
+    tm = mask[:, :steps].T.reshape(-1)
+    live = np.flatnonzero(tm != 0).astype(np.int32)
+    assert live.size < 0.6 * tm.size
+    gd = gpu.make_dims(d.dim_image, d.n_words, d.word_dim, d.lstm_dim, d.n_video_lstm_step, Tc)
+    dp_ = {k: _dev(v) for k, v in p.items()}
+    params = gpu.make_params(dp_)
+    coef = (mask * rng.standard_normal(N)[:, None]).T.astype(np.float32).reshape(-1)[:steps * N]
+    tgt = _dev(cap).t().contiguous().view(-1)[:steps * N]
+    dl = _dev(live)
+
+    import contextlib
+
+    def run(lv, hold_bwd=False):
+        ops.prof_filter(-1, -1); ops.prof_enable(True)
+        # every byte of the workspace starts as 0xFF (NaN as a float): a history slot of a stopped row that anything consumed shows
+        ws = torch.full_like(ops.train_workspace(gd, B, N, torch.device("cuda")), 255)
+        logits, ws = gpu.teacher_forced_fwd(gd, params, _dev(video), _dev(cap), N, keep, 99, _dev(vid), _dev(sid), steps=steps, live=lv, ws=ws)
+        raw = logits.clone()
+        ix = slice(None) if lv is None else lv.long()
+        nll, _ = gpu.softmax_nll_fwd_bwd(logits, tgt[ix].contiguous(), _dev(coef)[ix].contiguous(), 0.0)
+        g = {k: torch.zeros_like(v) for k, v in dp_.items()}
+        with (ops.chain_hold() if hold_bwd else contextlib.nullcontext()):
+            gpu.bptt_bwd(gd, params, gpu.make_params(g), _dev(video), N, logits, ws, keep, 99, _dev(vid), _dev(sid), steps=steps, live=lv)
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        names = sorted(r["name"] for r in ops.prof_collect() if r["kernel_class"] in (5, 6))
+        return raw, nll, g, names
+    full, nll_f, g_f, names_f = run(None)
+    part, nll_p, g_p, names_p = run(dl)
+    # a collective in flight (s2vt_chain_hold) sends the backward recurrence to its per-step DENSE form over the workspace of a
+    # forward pass that stopped rows: the unwritten slots hold the zeros the forward pass put there, the gradients are the same
+    _, _, g_h, names_h = run(dl, hold_bwd=True)
+    assert not any("[live]" in n for n in names_f)
+    assert sum("chain4" in n and "[live]" in n for n in names_p) == 2, names_p        # forward and backward recurrence of LSTM2
+    assert sum("[live]" in n for n in names_h) == 1 and not any(n.startswith("bchain") for n in names_h), names_h
+    assert torch.equal(part, full[dl.long()])
+    assert torch.equal(nll_p, nll_f[dl.long()])
+    for k in g_f:
+        ref = g_f[k].cpu().numpy()
+        for got in (g_p[k].cpu().numpy(), g_h[k].cpu().numpy()):
+            assert np.isfinite(got).all(), k
+            assert np.abs(got - ref).max() <= 1e-5 * (np.abs(ref).max() + 1e-12) + 1e-9, k
