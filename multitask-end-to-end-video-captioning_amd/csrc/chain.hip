@@ -290,14 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef S2VT_C4_STAMP
 __device__ unsigned long long c4_stamp_acc[12 * 8];
 #endif
-// LIVE (round 4): the rows are VIRTUAL -- row v of the state image is row g.perm[v] of every per-row array (carried partial,
-// initial state, noise ids, histories), the caller having sorted the rows by caption length, longest first -- and step t
-// computes only the row tiles that hold one of the first g.nlive[t] virtual rows: a row behind its caption's <eos> feeds
-// nothing (cider_evaluation.py:145-172; the callers gather the live (step, row) pairs for every product outside the
-// recurrence), its state simply stops.  The tiles of a part are then INTERLEAVED (tile i of part p is image tile 4 i + p), so
-// the live prefix spreads evenly over the four parts, and the step body is instantiated per count of live tiles.  Live rows
-// are computed exactly as in the dense launch: same chains, same pointwise expressions, bit-identical histories.
-template <int NG, int TPP, bool LIVE>
+template <int NG, int TPP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_chain4_kernel(const ChainArgs g)
 {
     constexpr int ZS = 20;
@@ -311,6 +304,306 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NCH = NG / CG;                               // chunks per step
     constexpr int NBUF = S2VT_C4_NBUF;                         // LDS chunk buffers (NBUF - 1 chunks in flight)
     constexpr int CHF = TPP * CG * 256;                        // floats per chunk buffer
+    constexpr int DPW = (TPP * CG + 3) / 4;                    // DMA instructions per wave per chunk
+    static_assert(NG % CG == 0 && NCH >= NBUF, "chunking");
+    static_assert((NCH - 1) % NBUF != 0 && CG >= 7, "the epilogue stages 7 x TPP KB in chunk buffer 0 while slow waves may still read the last chunk's buffer");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ab = smem;                                          // [NBUF][CG][TPP][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* zb = smem + NBUF * CHF + wave * (16 * ZS);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int H = g.H, M = g.M, T = g.T;
+    const int cg = (int)blockIdx.x % g.ncg, rp = (int)blockIdx.x / g.ncg;     // unit group (16 units), row part
+    const int u0 = cg * 16 + wave * 4;                         // this wave's 4 units
+    const bool wact = u0 < H;                                  // (the last unit group may be partial: idle waves still move A and keep the barriers)
+    const int nwg = gridDim.x;
+    const int tb = rp * TPP;                                   // first row tile of this workgroup
+    bool tok[TPP];
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) tok[i] = (tb + i) * 16 < M;
+
+    // ---- this wave's column tile of the recurrent rows -> registers, once: k-step s holds W[kw0 + 4s + lq][column of l15]
+    const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);          // W / cinit column of tile column l15 (gate l15 % 4, unit u0 + l15 / 4)
+    float breg[4 * NG];
+#pragma unroll
+    for (int s = 0; s < 4 * NG; ++s) {
+        const int k = 4 * s + lq;
+        breg[s] = (wact && k < H) ? g.W[(size_t)(g.kw0 + k) * g.ldw + ccol] : 0.0f;
+    }
+
+    // ---- the (row, unit) pairs this lane finishes at every step: one per row tile
+    const int rt = lane >> 2, uu = lane & 3;
+    const int row0 = tb * 16 + rt;
+    const int u = u0 + uu;
+    float bi = 0.f, bj = 0.f, bf = 0.f, bo = 0.f;
+    if (wact) { bi = g.bias[u]; bj = g.bias[H + u]; bf = g.bias[2 * H + u]; bo = g.bias[3 * H + u]; }
+    float c_reg[TPP];
+    uint32_t vid[TPP], sid[TPP];
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) {
+        const int row = row0 + 16 * i;
+        const bool rok = wact && tok[i] && row < M;
+        c_reg[i] = (rok && g.c0) ? g.c0[(size_t)row * H + u] : 0.0f;
+        vid[i] = (g.keep < 1.0f && rok) ? (uint32_t)g.video_id[row] : 0u;
+        sid[i] = (g.keep < 1.0f && rok) ? (uint32_t)g.sample_id[row] : 0u;
+    }
+    int hoff[TPP], goff[TPP];                                  // byte offsets of this lane's (row, unit) in a [M, H] / [M, 4H] history slot
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) {
+        const int row = row0 + 16 * i;
+        const bool rok = wact && tok[i] && row < M;
+        hoff[i] = rok ? (row * H + u) * 4 : (int)0x80000000u;
+        goff[i] = rok ? (row * 4 * H + u) * 4 : (int)0x80000000u;
+    }
+    // where this lane's h value of row tile 0 sits in the A-fragment image (tile i: + i * NG * 256 floats)
+    const size_t a_own = ((size_t)(tb * NG + (u >> 4)) * 64 + (size_t)((u & 3) * 16 + rt)) * 4 + ((u & 15) >> 2);
+    float* const abuf0 = g.abuf;
+    float* const abuf1 = g.abuf + (size_t)g.img_tiles * NG * 256;
+
+    GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, nwg, false};
+
+    // ---- arrival 0: h_0 in fragment order
+#pragma unroll
+    for (int i = 0; i < TPP; ++i) {
+        const int row = row0 + 16 * i;
+        if (wact && tok[i] && row < M) {
+            const float h0 = g.h0 ? g.h0[(size_t)row * H + u] : 0.0f;
+            __hip_atomic_store((gu32*)(abuf0 + a_own + (size_t)i * NG * 256), __float_as_uint(h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the carried partial of a step, branch-free: loop-invariant byte offsets into a per-step buffer resource, an element
+    // outside the problem carries an out-of-range offset and reads as zero (20-24 conditional loads per step cost 1.5 us of
+    // branches and 64-bit address arithmetic in front of every step)
+    float ci[TPP][4];
+    int coff[TPP][4];
+#pragma unroll
+    for (int i = 0; i < TPP; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = (tb + i) * 16 + lq * 4 + r;
+            coff[i][r] = (wact && tok[i] && m < M) ? (m * g.ldcinit + ccol) * 4 : (int)0x80000000u;
+        }
+    auto load_cinit = [&](int t) __attribute__((always_inline)) {
+        if (g.cinit && t < g.cinit_steps) {                       // (uniform)
+            const __amdgpu_buffer_rsrc_t rsC =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.cinit + (size_t)t * g.cinit_tstride), 0, (int)0x80000000u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TPP; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ci[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, coff[i][r], 0, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < TPP; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ci[i][r] = 0.0f;
+        }
+    };
+    load_cinit(0);
+    gs.arrive(tid);
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#ifdef S2VT_C4_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#define C4_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[i] += n_ - st_prev; st_prev = n_; } while (0)
+#else
+#define C4_STAMP(i) do { } while (0)
+#endif
+    for (int t = 0; t < T; ++t) {
+        f32x4 acc[TPP];
+#pragma unroll
+        for (int i = 0; i < TPP; ++i) {
+            acc[i] = f32x4{ci[i][0], ci[i][1], ci[i][2], ci[i][3]};
+            asm volatile("" : "+v"(acc[i]));
+        }
+#ifndef S2VT_C4_LATE_CINIT
+        // the NEXT step's carried partial is requested now: its latency (HBM / Infinity Cache, ~2 us) passes under this step's
+        // hand-off wait and MFMAs instead of in front of the next step's (older than every DMA load below: the counted vmcnt
+        // waits of the chunk loop still mean what they say)
+        if (t + 1 < T) load_cinit(t + 1);
+#endif
+        C4_STAMP(0);                                              // acc init (waits for the carried partial)
+        gs.wait_all((unsigned)t, wave, lane);
+        C4_STAMP(1);                                              // grid-wide wait
+        // ---- the part's slice of h_t: [TPP row tiles][NG groups] KB, global -> LDS in chunks of CG groups.  Piece p of a chunk
+        // = (group p / TPP, row tile p % TPP); wave w issues pieces w, w + 4, ...
+        const float* acur = (t & 1) ? abuf1 : abuf0;
+        const __amdgpu_buffer_rsrc_t rsA =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)tb * NG * 256), 0, TPP * NG * 1024, 0x00020000);
+        auto issue_chunk = [&](int c) __attribute__((always_inline)) {
+            float* dstb = Ab + (c % NBUF) * CHF;
+#pragma unroll
+            for (int q = 0; q < DPW; ++q) {
+                const int p = wave + 4 * q;
+                if (p < TPP * CG) {
+                    const int gq = p / TPP, i = p % TPP;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dstb + (gq * TPP + i) * 256), 16, lane * 16,
+                                                             (i * NG + c * CG + gq) * 1024, 0, 16);                     // aux 16 = sc1
+                }
+            }
+        };
+        static_assert((TPP * CG) % 4 == 0, "every wave issues exactly DPW loads per chunk (the vmcnt bookkeeping below)");
+        static_for<0, NBUF - 1>([&](auto c_) { issue_chunk(decltype(c_)::value); });
+        static_for<0, NCH>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            // my loads of chunk c have landed (those of the later chunks already issued may be in flight); then everybody's
+            // have, and everybody is done reading chunk c - 1, whose buffer chunk c + NBUF - 1 now takes
+            constexpr int issued = c + NBUF - 1 < NCH ? c + NBUF - 1 : NCH;
+            constexpr int later = issued - (c + 1);
+            static_assert(later * DPW <= 63, "vmcnt range");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(later * DPW) : "memory");
+            __syncthreads();
+            if constexpr (c == 0) C4_STAMP(2);                    // first chunk in LDS
+            if constexpr (c + NBUF - 1 < NCH) issue_chunk(c + NBUF - 1);
+            const f32x4* ab = reinterpret_cast<const f32x4*>(Ab + (c % NBUF) * CHF) + lane;
+            f32x4 a[2][TPP];
+#pragma unroll
+            for (int i = 0; i < TPP; ++i) a[0][i] = ab[i * 64];
+            static_for<0, CG>([&](auto q_) {
+                constexpr int gq = decltype(q_)::value;
+                if constexpr (gq + 1 < CG) {
+#pragma unroll
+                    for (int i = 0; i < TPP; ++i) a[(gq + 1) & 1][i] = ab[((gq + 1) * TPP + i) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 4>([&](auto e_) {
+                    constexpr int e = decltype(e_)::value;
+                    static_for<0, TPP>([&](auto i_) {
+                        constexpr int i = decltype(i_)::value;
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gq & 1][i][e], breg[(c * CG + gq) * 4 + e], acc[i], 0, 0, 0);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        C4_STAMP(3);                                              // chunk loop (MFMAs)
+        // ---- per row tile: the gates of a unit meet through the wave's LDS tile; BasicLSTMCell pointwise (EPI_LSTM expressions).
+        // Results are STAGED in LDS (the chunk buffers are idle until the next step's first DMA): a wave's tile is 16 rows x
+        // 4 units = 16 bytes per row, stored directly that is 140 scattered 4-byte store instructions per workgroup and
+        // step (7 history arrays x 5 tiles x 4 waves) whose issue alone cost ~4 us per step; the four waves' units are
+        // adjacent, so from LDS one 16-byte store per lane writes 64 contiguous bytes per row (35 instructions), and the
+        // hand-off block of a row tile -- exactly ONE 1-KB fragment block, this workgroup's 16 units being one k-group --
+        // goes out as one write-through 16-byte store per lane.
+        float* const stg = Ab;                                    // [7 arrays][TPP tiles][16 rows][16 units] floats (35-42 KB of the 120)
+        constexpr int ST = TPP * 256;                             // floats per staged array
+        float hv[TPP], siv[TPP], tjv[TPP], sfv[TPP], sov[TPP];
+#pragma unroll
+        for (int i = 0; i < TPP; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
+            __builtin_amdgcn_wave_barrier();
+            const f32x4 z = *reinterpret_cast<const f32x4*>(zb + rt * ZS + uu * 4);
+            __builtin_amdgcn_wave_barrier();
+            const float zi = z[0] + bi, zj = z[1] + bj, zf = z[2] + bf, zo = z[3] + bo;
+            const float si = dm_sigmoidf(zi);
+            const float tj = dm_tanhf(zj);
+            const float sf = dm_sigmoidf(zf + 1.0f);
+            const float so = dm_sigmoidf(zo);
+            const float t1 = c_reg[i] * sf;
+            const float t2 = si * tj;
+            const float cc = t1 + t2;
+            const float hvv = dm_tanhf(cc) * so;
+            c_reg[i] = cc;
+            hv[i] = hvv; siv[i] = si; tjv[i] = tj; sfv[i] = sf; sov[i] = so;
+#ifndef S2VT_C4_NOEPI
+            stg[1 * ST + (i * 16 + rt) * 16 + wave * 4 + uu] = hvv;       // only what the hand-off needs is staged before it
+#endif
+        }
+        C4_STAMP(4);                                              // pointwise
+        __syncthreads();
+        if (t + 1 < T) {
+            // h_{t+1} blocks: wave w writes row tiles w, w + 4; lane L = kq * 16 + r takes row r, units kq + 4e
+            const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(((t & 1) ? abuf0 : abuf1) + ((size_t)tb * NG + cg) * 256, 0,
+                                                                                   TPP * NG * 1024, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < (TPP + 3) / 4; ++q) {
+                const int i = wave + 4 * q;
+                if (i < TPP) {
+                    const int r = lane & 15, kq = lane >> 4;
+                    u32x4v w4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w4[e] = __float_as_uint(stg[1 * ST + (i * 16 + r) * 16 + kq + 4 * e]);
+                    // (rows >= M of a tile and units >= H of the last group carry garbage-free zeros only if they were computed
+                    //  from zeros: rows >= M read zero A fragments and zero partials -> finite values, never read back as
+                    //  operands of valid rows; units >= H multiply zero weight rows of every consumer)
+                    bstore16_sc1(rsN, w4, (i * NG * 256 + lane * 4) * 4, 0);
+                }
+            }
+            gs.arrive(tid);
+        }
+        C4_STAMP(5);                                              // hand-off stores + drain + arrive
+        // ---- behind the hand-off: the DropoutWrapper output (one Philox block per element) and the rest of the staging
+#pragma unroll
+        for (int i = 0; i < TPP; ++i) {
+            float ov = hv[i];
+            if (g.out && g.keep < 1.0f)
+                ov = (hv[i] / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)u, g.keep);
+#ifndef S2VT_C4_NOEPI
+            float* sp = stg + (i * 16 + rt) * 16 + wave * 4 + uu;
+            sp[0 * ST] = c_reg[i]; sp[2 * ST] = ov; sp[3 * ST] = siv[i]; sp[4 * ST] = tjv[i]; sp[5 * ST] = sfv[i]; sp[6 * ST] = sov[i];
+#else
+            asm volatile("" ::"v"(ov));
+#endif
+        }
+        __syncthreads();
+        // ---- histories (nobody in this launch reads them): block (array, tile) = [16 rows][16 units]; lane = (row, quarter)
+        // writes 16 bytes; an element outside the problem carries an out-of-range offset and its store is dropped
+        {
+            const int srow = lane >> 2, sq = lane & 3;
+            const int uq = cg * 16 + sq * 4;
+            const __amdgpu_buffer_rsrc_t rsCh = __builtin_amdgcn_make_buffer_rsrc(g.C + (size_t)(t + 1) * g.state_tstride, 0, (int)0x80000000u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsHh = __builtin_amdgcn_make_buffer_rsrc(g.Hh + (size_t)(t + 1) * g.state_tstride, 0, (int)0x80000000u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(g.out ? g.out + (size_t)t * g.out_tstride : g.C, 0, g.out ? (int)0x80000000u : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(g.gates ? g.gates + (size_t)t * g.gates_tstride : g.C, 0, g.gates ? (int)0x80000000u : 0, 0x00020000);
+            // 7 TPP blocks over the 4 waves: block b = array * TPP + tile
+#pragma unroll
+            for (int q = 0; q < (7 * TPP + 3) / 4; ++q) {
+                const int bidx = wave + 4 * q;
+                if (bidx < 7 * TPP) {
+                    const int arr = bidx / TPP, i = bidx % TPP;
+                    const int row = (tb + i) * 16 + srow;
+                    const bool ok = row < M && uq < H;
+                    const u32x4v v = __builtin_bit_cast(u32x4v, *reinterpret_cast<const f32x4*>(stg + arr * ST + (i * 16 + srow) * 16 + sq * 4));
+                    const int ho = ok ? (row * H + uq) * 4 : (int)0x80000000u;
+                    const int go = ok ? (row * 4 * H + uq) * 4 : (int)0x80000000u;
+                    if (arr == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rsCh, ho, 0, 0);
+                    else if (arr == 1) __builtin_amdgcn_raw_buffer_store_b128(v, rsHh, ho, 0, 0);
+                    else if (arr == 2) __builtin_amdgcn_raw_buffer_store_b128(v, rsO, ho, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(v, rsG, go, (arr - 3) * H * 4, 0);
+                }
+            }
+        }
+#ifdef S2VT_C4_LATE_CINIT
+        if (t + 1 < T) load_cinit(t + 1);
+#endif
+        C4_STAMP(6);                                              // history stores issued
+    }
+#ifdef S2VT_C4_STAMP
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 251)) {
+        const int slot = (blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : 2) * 4 + wave;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&c4_stamp_acc[slot * 8 + i], st_acc[i]);
+    }
+#endif
+}
+
+// The same with LIVE ROWS (round 4): the rows are VIRTUAL -- row v of the state image is row g.perm[v] of every per-row array
+// (carried partial, initial state, noise ids, histories), the caller having sorted the rows by caption length, longest first --
+// and step t computes only the row tiles that hold one of the first g.nlive[t] virtual rows: a row behind its caption's <eos>
+// feeds nothing (cider_evaluation.py:145-172; the callers gather the live (step, row) pairs for every product outside the
+// recurrence), its state simply stops.  The tiles of a part are INTERLEAVED (tile i of part p is image tile 4 i + p), so the live
+// prefix spreads evenly over the four parts; the product phase is instantiated per count of live tiles, everything else loops
+// over the tiles behind a uniform `i < nl`.  Live rows are computed exactly as in the dense launch: same chains, same pointwise
+// expressions, bit-identical histories (tests/test_gpu_live_rows.py).  (A kernel of its own rather than a flag of the one above:
+// the dense form's register allocation sits at the limit and does not survive being generated from shared source.)
+template <int NG, int TPP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lstm_chain4_live_kernel(const ChainArgs g)
+{
+    constexpr int ZS = 20;
+    constexpr int CG = S2VT_C4_CG;                             // k-groups per chunk
+    constexpr int NCH = NG / CG;                               // chunks per step
+    constexpr int NBUF = S2VT_C4_NBUF;                         // LDS chunk buffers (NBUF - 1 chunks in flight)
+    constexpr int CHF = TPP * CG * 256;                        // floats per chunk buffer
     static_assert(NG % CG == 0 && NCH >= NBUF, "chunking");
     static_assert((NCH - 1) % NBUF != 0 && CG >= 7, "the epilogue stages 7 x TPP KB in chunk buffer 0 while slow waves may still read the last chunk's buffer");
     static_assert(CG % 4 == 0, "every wave issues the same number of DMA loads per chunk for any count of live tiles (the vmcnt bookkeeping below)");
@@ -319,23 +612,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* zb = smem + NBUF * CHF + wave * (16 * ZS);
-    int* const arow_l = reinterpret_cast<int*>(smem + NBUF * CHF + 4 * 16 * ZS);   // LIVE: [TPP][16] rows of the caller's arrays behind this workgroup's virtual rows
+    int* const arow_l = reinterpret_cast<int*>(smem + NBUF * CHF + 4 * 16 * ZS);   // [TPP][16] rows of the caller's arrays behind this workgroup's virtual rows
     const int l15 = lane & 15, lq = lane >> 4;
     const int H = g.H, M = g.M, T = g.T;
     const int cg = (int)blockIdx.x % g.ncg, rp = (int)blockIdx.x / g.ncg;     // unit group (16 units), row part
     const int u0 = cg * 16 + wave * 4;                         // this wave's 4 units
     const bool wact = u0 < H;                                  // (the last unit group may be partial: idle waves still move A and keep the barriers)
     const int nwg = gridDim.x;
-    constexpr int TS = LIVE ? 4 : 1;                           // image tiles between consecutive row tiles of this workgroup
-    const int tile0 = LIVE ? rp : rp * TPP;                    // image tile of this workgroup's row tile 0
+    constexpr int TS = 4;                                      // image tiles between consecutive row tiles of this workgroup
+    const int tile0 = rp;                                      // image tile of this workgroup's row tile 0
     bool tok[TPP];
 #pragma unroll
     for (int i = 0; i < TPP; ++i) tok[i] = (tile0 + i * TS) * 16 < M;
-    auto actual = [&](int v) __attribute__((always_inline)) { if constexpr (LIVE) return v < M ? (int)g.perm[v] : v; else return v; };
-    if constexpr (LIVE) {
-        if (tid < TPP * 16) arow_l[tid] = actual((tile0 + (tid >> 4) * TS) * 16 + (tid & 15));
-        __syncthreads();
-    }
+    auto actual = [&](int v) __attribute__((always_inline)) { return v < M ? (int)g.perm[v] : v; };
+    if (tid < TPP * 16) arow_l[tid] = actual((tile0 + (tid >> 4) * TS) * 16 + (tid & 15));
+    __syncthreads();
 
     // ---- this wave's column tile of the recurrent rows -> registers, once: k-step s holds W[kw0 + 4s + lq][column of l15]
     const int ccol = (l15 & 3) * H + u0 + (l15 >> 2);          // W / cinit column of tile column l15 (gate l15 % 4, unit u0 + l15 / 4)
@@ -374,9 +665,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     GridSync gs{(gu32*)g.sync, g.status, g.fault, g.spin_limit, nwg, false};
 
-    // the carried partial of a step, branch-free: loop-invariant byte offsets into a per-step buffer resource, an element
-    // outside the problem carries an out-of-range offset and reads as zero (20-24 conditional loads per step cost 1.5 us of
-    // branches and 64-bit address arithmetic in front of every step)
+    // the carried partial of a step, branch-free (as above); the offsets go through the row order
     float ci[TPP][4];
     int coff[TPP][4];
 #pragma unroll
@@ -386,14 +675,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int m = (tile0 + i * TS) * 16 + lq * 4 + r;
             coff[i][r] = (wact && tok[i] && m < M) ? (actual(m) * g.ldcinit + ccol) * 4 : (int)0x80000000u;
         }
-    auto load_cinit = [&](int t) __attribute__((always_inline)) {
+    auto load_cinit = [&](int t, int nl) __attribute__((always_inline)) {
         if (g.cinit && t < g.cinit_steps) {                       // (uniform)
             const __amdgpu_buffer_rsrc_t rsC =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.cinit + (size_t)t * g.cinit_tstride), 0, (int)0x80000000u, 0x00020000);
 #pragma unroll
             for (int i = 0; i < TPP; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ci[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, coff[i][r], 0, 0));
+                for (int r = 0; r < 4; ++r) ci[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, i < nl ? coff[i][r] : (int)0x80000000u, 0, 0));
         } else {
 #pragma unroll
             for (int i = 0; i < TPP; ++i)
@@ -401,38 +690,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int r = 0; r < 4; ++r) ci[i][r] = 0.0f;
         }
     };
-    load_cinit(0);
+    // live tiles of this part at step t: image tiles 0 .. ceil(n / 16) - 1 hold the n live virtual rows; this part owns tiles rp, rp + 4, ..
+    auto live_tiles = [&](int t) __attribute__((always_inline)) {
+        int n = g.nlive[t];
+        n = n < M ? n : M;
+        int nl = (((n + 15) >> 4) - rp + 3) >> 2;
+        nl = nl < 0 ? 0 : (nl > TPP ? TPP : nl);
+        return __builtin_amdgcn_readfirstlane(nl);
+    };
+    int nl = live_tiles(0);
+    load_cinit(0, nl);
     gs.arrive(tid);
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
-#ifdef S2VT_C4_STAMP
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
-#define C4_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[i] += n_ - st_prev; st_prev = n_; } while (0)
-#else
-#define C4_STAMP(i) do { } while (0)
-#endif
-    // One step with NL of this workgroup's TPP row tiles in play (dense: always TPP)
-    auto step = [&](auto nl_, const int t) __attribute__((always_inline)) {
+    f32x4 acc[TPP];
+    // the product phase of a step for NL live row tiles: the part's slice of h_t global -> LDS in chunks, MFMAs (as above)
+    auto product = [&](auto nl_, const int t) __attribute__((always_inline)) {
         constexpr int NL = decltype(nl_)::value;
         constexpr int DPW = NL * CG / 4;                          // DMA instructions per wave per chunk
-        f32x4 acc[TPP];
-#pragma unroll
-        for (int i = 0; i < TPP; ++i) {
-            acc[i] = f32x4{ci[i][0], ci[i][1], ci[i][2], ci[i][3]};
-            asm volatile("" : "+v"(acc[i]));
-        }
-#ifndef S2VT_C4_LATE_CINIT
-        // the NEXT step's carried partial is requested now: its latency (HBM / Infinity Cache, ~2 us) passes under this step's
-        // hand-off wait and MFMAs instead of in front of the next step's (older than every DMA load below: the counted vmcnt
-        // waits of the chunk loop still mean what they say)
-        if (t + 1 < T) load_cinit(t + 1);
-#endif
-        C4_STAMP(0);                                              // acc init (waits for the carried partial)
-        gs.wait_all((unsigned)t, wave, lane);
-        C4_STAMP(1);                                              // grid-wide wait
-        if constexpr (NL > 0) {
-        // ---- the part's slice of h_t: [NL row tiles][NG groups] KB, global -> LDS in chunks of CG groups.  Piece p of a chunk
-        // = (group p / NL, row tile p % NL); wave w issues pieces w, w + 4, ...
         const float* acur = (t & 1) ? abuf1 : abuf0;
         const __amdgpu_buffer_rsrc_t rsA =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(acur + (size_t)tile0 * NG * 256), 0, ((TPP - 1) * TS + 1) * NG * 1024, 0x00020000);
@@ -449,14 +724,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         static_for<0, NBUF - 1>([&](auto c_) { issue_chunk(decltype(c_)::value); });
         static_for<0, NCH>([&](auto c_) {
             constexpr int c = decltype(c_)::value;
-            // my loads of chunk c have landed (those of the later chunks already issued may be in flight); then everybody's
-            // have, and everybody is done reading chunk c - 1, whose buffer chunk c + NBUF - 1 now takes
             constexpr int issued = c + NBUF - 1 < NCH ? c + NBUF - 1 : NCH;
             constexpr int later = issued - (c + 1);
             static_assert(later * DPW <= 63, "vmcnt range");
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(later * DPW) : "memory");
             __syncthreads();
-            if constexpr (c == 0) C4_STAMP(2);                    // first chunk in LDS
             if constexpr (c + NBUF - 1 < NCH) issue_chunk(c + NBUF - 1);
             const f32x4* ab = reinterpret_cast<const f32x4*>(Ab + (c % NBUF) * CHF) + lane;
             f32x4 a[2][NL];
@@ -479,20 +751,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+    };
+
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int i = 0; i < TPP; ++i) {
+            acc[i] = f32x4{ci[i][0], ci[i][1], ci[i][2], ci[i][3]};
+            asm volatile("" : "+v"(acc[i]));
         }
-        C4_STAMP(3);                                              // chunk loop (MFMAs)
-        // ---- per row tile: the gates of a unit meet through the wave's LDS tile; BasicLSTMCell pointwise (EPI_LSTM expressions).
-        // Results are STAGED in LDS (the chunk buffers are idle until the next step's first DMA): a wave's tile is 16 rows x
-        // 4 units = 16 bytes per row, stored directly that is 140 scattered 4-byte store instructions per workgroup and
-        // step (7 history arrays x 5 tiles x 4 waves) whose issue alone cost ~4 us per step; the four waves' units are
-        // adjacent, so from LDS one 16-byte store per lane writes 64 contiguous bytes per row (35 instructions), and the
-        // hand-off block of a row tile -- exactly ONE 1-KB fragment block, this workgroup's 16 units being one k-group --
-        // goes out as one write-through 16-byte store per lane.
-        float* const stg = Ab;                                    // [7 arrays][TPP tiles][16 rows][16 units] floats (35-42 KB of the 120)
+        // the NEXT step's carried partial is requested now (older than every DMA load below: the counted vmcnt waits of the chunk
+        // loop still mean what they say), for the tiles that will still be live
+        const int nl_next = t + 1 < T ? live_tiles(t + 1) : 0;
+        if (t + 1 < T) load_cinit(t + 1, nl_next);
+        gs.wait_all((unsigned)t, wave, lane);
+        if (nl > 0) {
+            bool done = false;
+            static_for<1, TPP + 1>([&](auto k_) {
+                if (!done && nl == decltype(k_)::value) { product(k_, t); done = true; }
+            });
+        }
+        // ---- per row tile: the gates of a unit meet through the wave's LDS tile; BasicLSTMCell pointwise (EPI_LSTM expressions);
+        // results staged in LDS (the chunk buffers are idle until the next step's first DMA), as above
+        float* const stg = Ab;                                    // [7 arrays][TPP tiles][16 rows][16 units] floats
         constexpr int ST = TPP * 256;                             // floats per staged array
         float hv[TPP], siv[TPP], tjv[TPP], sfv[TPP], sov[TPP];
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
+        for (int i = 0; i < TPP; ++i) {
+            if (!(i < nl)) continue;                              // (uniform)
 #pragma unroll
             for (int r = 0; r < 4; ++r) zb[(lq * 4 + r) * ZS + l15] = acc[i][r];
             __builtin_amdgcn_wave_barrier();
@@ -509,66 +794,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float hvv = dm_tanhf(cc) * so;
             c_reg[i] = cc;
             hv[i] = hvv; siv[i] = si; tjv[i] = tj; sfv[i] = sf; sov[i] = so;
-#ifndef S2VT_C4_NOEPI
             stg[1 * ST + (i * 16 + rt) * 16 + wave * 4 + uu] = hvv;       // only what the hand-off needs is staged before it
-#endif
         }
-        C4_STAMP(4);                                              // pointwise
         __syncthreads();
         if (t + 1 < T) {
             // h_{t+1} blocks: wave w writes row tiles w, w + 4; lane L = kq * 16 + r takes row r, units kq + 4e
             const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(((t & 1) ? abuf0 : abuf1) + ((size_t)tile0 * NG + cg) * 256, 0,
                                                                                    ((TPP - 1) * TS + 1) * NG * 1024, 0x00020000);
 #pragma unroll
-            for (int q = 0; q < (NL + 3) / 4; ++q) {
+            for (int q = 0; q < (TPP + 3) / 4; ++q) {
                 const int i = wave + 4 * q;
-                if (i < NL) {
+                if (i < nl) {
                     const int r = lane & 15, kq = lane >> 4;
                     u32x4v w4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) w4[e] = __float_as_uint(stg[1 * ST + (i * 16 + r) * 16 + kq + 4 * e]);
-                    // (rows >= M of a tile and units >= H of the last group carry garbage-free zeros only if they were computed
-                    //  from zeros: rows >= M read zero A fragments and zero partials -> finite values, never read back as
-                    //  operands of valid rows; units >= H multiply zero weight rows of every consumer)
                     bstore16_sc1(rsN, w4, (i * TS * NG * 256 + lane * 4) * 4, 0);
                 }
             }
             gs.arrive(tid);
         }
-        C4_STAMP(5);                                              // hand-off stores + drain + arrive
         // ---- behind the hand-off: the DropoutWrapper output (one Philox block per element) and the rest of the staging
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
+        for (int i = 0; i < TPP; ++i) {
+            if (!(i < nl)) continue;
             float ov = hv[i];
             if (g.out && g.keep < 1.0f)
                 ov = (hv[i] / g.keep) * dropout_keep01(g.seed_lo, g.seed_hi, vid[i], sid[i], g.drop_code0 + (uint32_t)t, (uint32_t)u, g.keep);
-#ifndef S2VT_C4_NOEPI
             float* sp = stg + (i * 16 + rt) * 16 + wave * 4 + uu;
             sp[0 * ST] = c_reg[i]; sp[2 * ST] = ov; sp[3 * ST] = siv[i]; sp[4 * ST] = tjv[i]; sp[5 * ST] = sfv[i]; sp[6 * ST] = sov[i];
-#else
-            asm volatile("" ::"v"(ov));
-#endif
         }
         __syncthreads();
-        // ---- histories (nobody in this launch reads them): block (array, tile) = [16 rows][16 units]; lane = (row, quarter)
-        // writes 16 bytes; an element outside the problem carries an out-of-range offset and its store is dropped
-        if constexpr (NL > 0) {
+        // ---- histories (nobody in this launch reads them): block b = tile * 7 + array = [16 rows][16 units]; lane = (row, quarter)
+        // writes 16 bytes to the row the virtual row stands for; an element outside the problem carries an out-of-range offset
+        if (nl > 0) {
             const int srow = lane >> 2, sq = lane & 3;
             const int uq = cg * 16 + sq * 4;
             const __amdgpu_buffer_rsrc_t rsCh = __builtin_amdgcn_make_buffer_rsrc(g.C + (size_t)(t + 1) * g.state_tstride, 0, (int)0x80000000u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsHh = __builtin_amdgcn_make_buffer_rsrc(g.Hh + (size_t)(t + 1) * g.state_tstride, 0, (int)0x80000000u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(g.out ? g.out + (size_t)t * g.out_tstride : g.C, 0, g.out ? (int)0x80000000u : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(g.gates ? g.gates + (size_t)t * g.gates_tstride : g.C, 0, g.gates ? (int)0x80000000u : 0, 0x00020000);
-            // 7 NL blocks over the 4 waves: block b = array * NL + tile
 #pragma unroll
-            for (int q = 0; q < (7 * NL + 3) / 4; ++q) {
+            for (int q = 0; q < (7 * TPP + 3) / 4; ++q) {
                 const int bidx = wave + 4 * q;
-                if (bidx < 7 * NL) {
-                    const int arr = bidx / NL, i = bidx % NL;
+                const int i = bidx / 7, arr = bidx - 7 * i;
+                if (i < nl) {
                     const int vrow = (tile0 + i * TS) * 16 + srow;
                     const bool ok = vrow < M && uq < H;
-                    int row = vrow;
-                    if constexpr (LIVE) row = arow_l[i * 16 + srow];
+                    const int row = arow_l[i * 16 + srow];
                     const u32x4v v = __builtin_bit_cast(u32x4v, *reinterpret_cast<const f32x4*>(stg + arr * ST + (i * 16 + srow) * 16 + sq * 4));
                     const int ho = ok ? (row * H + uq) * 4 : (int)0x80000000u;
                     const int go = ok ? (row * 4 * H + uq) * 4 : (int)0x80000000u;
@@ -579,34 +852,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         }
-#ifdef S2VT_C4_LATE_CINIT
-        if (t + 1 < T) load_cinit(t + 1);
-#endif
-        C4_STAMP(6);                                              // history stores issued
-    };
-    for (int t = 0; t < T; ++t) {
-        if constexpr (!LIVE) {
-            step(std::integral_constant<int, TPP>{}, t);
-        } else {
-            // live tiles of this part: image tiles 0 .. ceil(n / 16) - 1 hold the n live virtual rows; this part owns tiles rp, rp + 4, ..
-            int n = g.nlive ? g.nlive[t] : M;
-            n = n < M ? n : M;
-            int nl = (((n + 15) >> 4) - rp + 3) >> 2;
-            nl = nl < 0 ? 0 : (nl > TPP ? TPP : nl);
-            nl = __builtin_amdgcn_readfirstlane(nl);
-            bool done = false;
-            static_for<0, TPP + 1>([&](auto k_) {
-                if (!done && nl == decltype(k_)::value) { step(k_, t); done = true; }
-            });
-        }
+        nl = nl_next;
     }
-#ifdef S2VT_C4_STAMP
-    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 251)) {
-        const int slot = (blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : 2) * 4 + wave;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&c4_stamp_acc[slot * 8 + i], st_acc[i]);
-    }
-#endif
 }
 
 typedef void (*ChainFn)(const ChainArgs);
@@ -623,8 +870,8 @@ const ChainCfg kChain[] = {
     {64, 1, 2, lstm_chain_kernel<64, 1, 2>, "chain2(ng64,m128)"}, {64, 2, 2, lstm_chain_kernel<64, 2, 2>, "chain2(ng64,m256)"},
     {64, 3, 2, lstm_chain_kernel<64, 3, 2>, "chain2(ng64,m384)"},
     // weights in registers, 16 units x a quarter of the row tiles per workgroup (M > 256): tmw = row tiles per part
-    {64, 5, 4, lstm_chain4_kernel<64, 5, false>, "chain4(ng64,m320)", lstm_chain4_kernel<64, 5, true>, "chain4(ng64,m320)[live]"},
-    {64, 6, 4, lstm_chain4_kernel<64, 6, false>, "chain4(ng64,m384)", lstm_chain4_kernel<64, 6, true>, "chain4(ng64,m384)[live]"},
+    {64, 5, 4, lstm_chain4_kernel<64, 5>, "chain4(ng64,m320)", lstm_chain4_live_kernel<64, 5>, "chain4(ng64,m320)[live]"},
+    {64, 6, 4, lstm_chain4_kernel<64, 6>, "chain4(ng64,m384)", lstm_chain4_live_kernel<64, 6>, "chain4(ng64,m384)[live]"},
 };
 constexpr int kNumCfg = (int)(sizeof(kChain) / sizeof(kChain[0]));
 constexpr int kMaxDev = 32;
