@@ -229,7 +229,9 @@ int s2vt_teacher_forced_fwd_steps(const s2vt_dims* d, const s2vt_params* p, cons
  * time-major index t * N + n) names the unrolled row whose logits land in row r of logits_out [n_live, V].  A position behind a
  * sample's first <eos> is masked (cider_evaluation.py:145-172): its logits feed nothing, its loss term and every gradient
  * contribution are exact zeros -- on a trained model's samples (8 of 20 positions live) the four vocabulary-sized kernels of a
- * step (logits, softmax, dWout, dO2: a third of it) shrink with the live fraction.  The recurrences are unchanged.
+ * step (logits, softmax, dWout, dO2: a third of it) shrink with the live fraction.  At 257-384 rows LSTM2's recurrence also stops
+ * a row behind its last live step (rows sorted by length on the device; the history slots of a stopped row are not written and
+ * nothing reads them); the other recurrence forms step every row.
  * live_rows == NULL (n_live == 0): every row, as s2vt_teacher_forced_fwd_steps.  Pair it with s2vt_bptt_bwd_live on the same list.
  * The list must be closed towards earlier steps (t * N + n live => (t - 1) * N + n live), as masks up to a first <eos> are: the
  * backward also leaves the dead rows out of LSTM2's weight- and input-gradient products, whose dZ2 rows are zeros only BEHIND
