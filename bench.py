@@ -148,11 +148,12 @@ def kernel_signature():
 def stored_traffic(kernel_class, name, workload="rl"):
     """HBM bytes per launch of (class:tile) from the newest stamped PMC summary under profiles/ (2*FETCH_SIZE +
     WRITE_SIZE, separate --pmc passes, tools/collect_round.sh), or None when there is none for THIS build of the kernels.
-    A workload's own summary (<tag>_pmc_traffic_<workload>.json: the attention workloads) is looked at first."""
+    Every workload has its own summary (<tag>_pmc_traffic_<workload>.json; the default workload's is <tag>_pmc_traffic.json): the
+    same tile moves different bytes per launch on another workload's shapes, so a figure is never borrowed across workloads."""
     prof = os.path.join(ROOT, "profiles")
     sig = kernel_signature()
-    own = sorted((x for x in os.listdir(prof) if x.endswith(f"_pmc_traffic_{workload[:9]}.json")), reverse=True)
-    for f in own + sorted((x for x in os.listdir(prof) if x.endswith("_pmc_traffic.json")), reverse=True):
+    sfx = "_pmc_traffic.json" if workload == "rl" else f"_pmc_traffic_{workload}.json"
+    for f in sorted((x for x in os.listdir(prof) if x.endswith(sfx)), reverse=True):
         try:
             d = json.load(open(os.path.join(prof, f)))
         except Exception:

@@ -33,6 +33,14 @@ def prof_key(kname):
     if m:
         ng, tmw, nc = [int(x) for x in m.groups()]
         return f"5:chain{2 if nc == 2 else ''}(ng{ng},m{tmw * 64 * nc})"
+    m = re.search(r"lstm_chain4_live_kernel<(\d+), (\d+)>", kname)
+    if m:
+        ng, tpp = [int(x) for x in m.groups()]
+        return f"5:chain4(ng{ng},m{tpp * 64})[live]"
+    m = re.search(r"lstm_bwd_chain4_live_kernel<(\d+), (\d+)>", kname)
+    if m:
+        ng, tpp = [int(x) for x in m.groups()]
+        return f"6:bchain4(ng{ng},m{tpp * 64})[live]"
     m = re.search(r"lstm_chain4_kernel<(\d+), (\d+)>", kname)
     if m:
         ng, tpp = [int(x) for x in m.groups()]

@@ -12,10 +12,10 @@ for w in rl xe multitask attention attention32 rl_msvd rl_msvd_eos; do
 done
 python3 tools/pmc_to_json.py $src/pmc profiles/${tag}_pmc_traffic.json
 python3 tools/sq_summary.py $src/sq > profiles/${tag}_sq_counters.txt
-if [ -d $src/pmc_attention ]; then
-  python3 tools/pmc_to_json.py $src/pmc_attention profiles/${tag}_pmc_traffic_attention.json
-  python3 tools/sq_summary.py $src/sq_attention > profiles/${tag}_sq_counters_attention.txt
-fi
+for w in xe multitask attention attention32 rl_msvd rl_msvd_eos; do
+  [ -d $src/pmc_$w ] && python3 tools/pmc_to_json.py $src/pmc_$w profiles/${tag}_pmc_traffic_$w.json
+  [ -d $src/sq_$w ] && python3 tools/sq_summary.py $src/sq_$w > profiles/${tag}_sq_counters_$w.txt
+done
 for w in rl xe multitask attention attention32 rl_msvd rl_msvd_eos; do
   [ -s ${src}_bench_$w.json ] && tail -1 ${src}_bench_$w.json > profiles/${tag}_bench_$w.json
 done

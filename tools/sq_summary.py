@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{src}/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        m = re.search(r"(gemm_kernel|gemm_tn_kernel|gemm_tn_dma_kernel|lstm_chain_kernel|lstm_chain4_kernel|lstm_bwd_chain_kernel|lstm_bwd_chain4_kernel|decode_lstm4_kernel|attn_chain_kernel|attn_bwd_chain_kernel)<([^>]*)>", k)
+        m = re.search(r"(gemm_kernel|gemm_tn_kernel|gemm_tn_dma_kernel|lstm_chain_kernel|lstm_chain4_kernel|lstm_chain4_live_kernel|lstm_bwd_chain_kernel|lstm_bwd_chain4_kernel|lstm_bwd_chain4_live_kernel|decode_lstm4_kernel|attn_chain_kernel|attn_bwd_chain_kernel)<([^>]*)>", k)
         name = (m.group(1).replace("gemm_", "") + "<" + m.group(2).replace(" ", "") + ">") if m else k.split("(")[0][-40:]
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []
