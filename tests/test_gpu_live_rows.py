@@ -181,3 +181,36 @@ def test_live_rows_stop_inside_the_recurrences(gpu, oracle, B, rep, keep):
         for got in (g_p[k].cpu().numpy(), g_h[k].cpu().numpy()):
             assert np.isfinite(got).all(), k
             assert np.abs(got - ref).max() <= 1e-5 * (np.abs(ref).max() + 1e-12) + 1e-9, k
+
+
+def test_reinforce_update_at_320_rows_live_against_dense(gpu, oracle):
+    """model.reinforce_update at K B = 320 rows (the shape whose recurrences stop rows, above) with the host mask ("auto" live rows,
+    truncated unroll) against the dense full unroll: same loss, same finalised gradients, and the live variants of both
+    register-weights recurrences ran."""
+    import torch
+    from s2vt_amd import hostglue, ops, model as M
+    B, rep, Tc, Tv, H, E, V, D = 64, 5, 9, 3, 256, 32, 300, 64
+    rng = np.random.default_rng(21)
+    N = B * rep
+    cap = rng.integers(1, V, (N, Tc)).astype(np.int32)
+    ln = np.minimum(rng.poisson(2.5, N), Tc - 1)
+    for n in range(N):
+        cap[n, ln[n]:] = 0
+    mask = hostglue.masks_from_ids(cap)
+    video = np.abs(rng.standard_normal((B, Tv, D))).astype(np.float32)
+    r = rng.random(N).astype(np.float32) * 2; b = np.tile(rng.random(B).astype(np.float32), rep)
+    outs = []
+    for live in (None, "auto"):
+        mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, Tv, Tc, dropout_rate=0.9, seed=3)
+        ops.prof_filter(-1, -1); ops.prof_enable(True)
+        st = mdl.reinforce_update(video, cap, mask, r, b, lr=0.0, active_steps=None if live is None else "auto", live_mask=live)
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        names = [x["name"] for x in ops.prof_collect() if x["kernel_class"] in (5, 6)]
+        outs.append((float(st.loss), mdl.store.grad[:mdl.store.numel].clone(), names))
+    assert not any("[live]" in n for n in outs[0][2])
+    assert sorted(n for n in outs[1][2] if "[live]" in n) == ["bchain4(ng64,m320)[live]", "chain4(ng64,m320)[live]"], outs[1][2]
+    g0, g1 = outs[0][1], outs[1][1]
+    assert torch.isfinite(g1).all()
+    assert float((g0 - g1).abs().max()) <= 5e-5 * float(g0.abs().max())
+    assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * max(1.0, abs(outs[0][0]))
