@@ -314,6 +314,25 @@ int s2vt_pg_coef(const float* mask, const float* rewards, const float* baseline,
 int s2vt_step_scalars(const float* coef, const float* nll, int64_t R, const float* mask_sum_local, const float* mask_sum_global, float* loss,
                       float* gscale, float* sumsq, s2vt_stream stream);
 
+/* ---- the same for the XE update (tf_s2vt.py:150-166) and the mixed multitask objective (reinforce_multitask_e2e_attribute_s2vt.py:850):
+ * one launch each instead of the tensor-library expressions (single process; a data-parallel caller needs the GLOBAL column
+ * sums and keeps its own expressions).  Tc <= 128.
+ * s2vt_xe_prep: coef_tm[t*N + n] = q1 ? (sum_n' mask[n'][t] / n_global) * loss_weight : mask[n][t] * loss_weight;
+ *   target_tm[t*N + n] = caption[n][t] (may be NULL); *mask_sum = sum(mask) (may be NULL).
+ * s2vt_mixed_prep: rows 0..Ns-1 = the sampled captions, Ns..Ns+B-1 = the ground truth (N = Ns + B):
+ *   coef_tm[t*N + n] = n < Ns ? mask[n][t] * ((rewards[n] - baseline[n]) * (1 - lambda)) / sum(mask)
+ *                             : (q1 ? (sum_b gt_mask[b][t] / n_global_b) * loss_weight : gt_mask[n-Ns][t] * loss_weight) * (lambda / sum(gt_mask));
+ *   smooth_tm[t*N + n] = n < Ns ? 0 : smoothing;  caption_all [N, Tc] = [sampled ; gt_caption], target_tm [Tc*N] the same ids time-major;
+ *   sums = {sum(mask), sum(gt_mask)}.
+ * s2vt_mixed_loss: out3 = {sum over sampled rows, sum over ground-truth rows, both} of coef[r] * nll[r], r < R; the row of entry r is
+ *   (live_rows ? live_rows[r] : r) % N. */
+int s2vt_xe_prep(const float* mask, const int32_t* caption, int32_t N, int32_t Tc, float loss_weight, float n_global, int32_t q1, float* coef_tm,
+                 int32_t* target_tm, float* mask_sum, s2vt_stream stream);
+int s2vt_mixed_prep(const float* mask, const float* gt_mask, const float* rewards, const float* baseline, const int32_t* sampled,
+                    const int32_t* gt_caption, int32_t Ns, int32_t B, int32_t Tc, float lambda_loss, float loss_weight, int32_t q1,
+                    float smoothing, float n_global_b, float* coef_tm, float* smooth_tm, int32_t* caption_all, int32_t* target_tm, float* sums, s2vt_stream stream);
+int s2vt_mixed_loss(const float* coef, const float* nll, const int32_t* live_rows, int64_t R, int32_t N, int32_t Ns, float* out3, s2vt_stream stream);
+
 /* ---- gradient finalisation + tf.clip_by_global_norm + tf.train.AdamOptimizer ------------------
  * (reinforcement_multisampling_tf_s2vt.py:638-652; tf_s2vt.py:163-166,445-448).
  * s2vt_grad_finalize: g <- g * (*gscale) + weight_decay * theta over one flat range, and

@@ -96,6 +96,9 @@ SIGNATURES = {
     "s2vt_embed_scatter_add": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "s2vt_caption_mask": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_pg_coef": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp]),
+    "s2vt_xe_prep": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "s2vt_mixed_prep": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "s2vt_mixed_loss": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "s2vt_step_scalars": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_grad_finalize": (C.c_int, [_vp, _vp, _i64, _vp, _f32, _vp, _vp]),
     "s2vt_adam_tf": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _i64, _f32, _f32, _f32, _vp]),

@@ -100,6 +100,129 @@ hipError_t launch_caption_mask(const int32_t* ids, int N, int Tc, float* mask, i
     return hipGetLastError();
 }
 
+// ---- the coefficient / target preparation of the XE and the mixed (multitask) update as ONE launch each (round 4: the tensor
+// library spent 8 and ~25 launches per step on them, 55 and 145 us of a 2.5 / 4.5 ms step).  One workgroup; the sums are over
+// 0/1 masks (exact in any order), every other expression is written in the order the tensor-library code had it.
+//   xe_prep (tf_s2vt.py:150-166): colsum[t] = sum_n mask[n][t];  coef_tm[t N + n] = q1 ? (colsum[t] * (1 / n_glob)) * loss_weight
+//   : mask[n][t] * loss_weight;  target_tm[t N + n] = caption[n][t];  *msum = sum(mask)
+__global__ __launch_bounds__(1024) void xe_prep_kernel(const float* mask, const int32_t* cap, int N, int Tc, float loss_weight, float n_glob,
+                                                       int q1, float* coef_tm, int32_t* target_tm, float* msum)
+{
+    __shared__ float col[128];
+    const int tid = threadIdx.x;
+    if (tid < Tc) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += mask[(size_t)n * Tc + tid];
+        col[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0 && msum) {
+        float s = 0.f;
+        for (int t = 0; t < Tc; ++t) s += col[t];
+        *msum = s;
+    }
+    const float inv_n = 1.0f / n_glob;           // (a tensor divided by a host scalar is a multiplication by its reciprocal in the tensor library: the same here)
+    for (int i = tid; i < N * Tc; i += 1024) {
+        const int t = i / N, n = i - t * N;
+        coef_tm[i] = q1 ? (col[t] * inv_n) * loss_weight : mask[(size_t)n * Tc + t] * loss_weight;
+        if (target_tm) target_tm[i] = cap[(size_t)n * Tc + t];
+    }
+}
+hipError_t launch_xe_prep(const float* mask, const int32_t* cap, int N, int Tc, float loss_weight, float n_glob, int q1, float* coef_tm,
+                          int32_t* target_tm, float* msum, hipStream_t st)
+{
+    if (N <= 0 || Tc <= 0 || Tc > 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(xe_prep_kernel, dim3(1), dim3(1024), 0, st, mask, cap, N, Tc, loss_weight, n_glob, q1, coef_tm, target_tm, msum);
+    return hipGetLastError();
+}
+
+//   mixed_prep (reinforce_multitask_e2e_attribute_s2vt.py:850): rows 0 .. Ns-1 are the sampled captions, rows Ns .. Ns+B-1 the
+//   ground truth.  coef_tm[t N + n] = n < Ns ? mask[n][t] * ((r[n] - b[n]) * one_minus_lam) / sum(mask)
+//                                           : (q1 ? (colsum_gt[t] / n_glob_b) * loss_weight : gmask[.][t] * loss_weight) * (lam / sum(gmask));
+//   smooth_tm = 0 | smoothing;  cap_all = [cap ; gcap], target_tm the same ids time-major;  sums = {sum(mask), sum(gmask)}
+__global__ __launch_bounds__(1024) void mixed_prep_kernel(const float* mask, const float* gmask, const float* rewards, const float* baseline,
+                                                          const int32_t* cap, const int32_t* gcap, int Ns, int B, int Tc, float one_minus_lam,
+                                                          float lam, float loss_weight, int q1, float smoothing, float n_glob_b, float* coef_tm,
+                                                          float* smooth_tm, int32_t* cap_all, int32_t* target_tm, float* sums)
+{
+    __shared__ float col[128], colp[128];
+    __shared__ float s01[2];
+    const int tid = threadIdx.x;
+    if (tid < Tc) {
+        float s = 0.f;
+        for (int n = 0; n < B; ++n) s += gmask[(size_t)n * Tc + tid];
+        col[tid] = s;
+    } else if (tid >= 512 && tid - 512 < Tc) {
+        const int t = tid - 512;
+        float s = 0.f;
+        for (int n = 0; n < Ns; ++n) s += mask[(size_t)n * Tc + t];
+        colp[t] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.f, b = 0.f;
+        for (int t = 0; t < Tc; ++t) { a += colp[t]; b += col[t]; }
+        s01[0] = a; s01[1] = b;
+        sums[0] = a; sums[1] = b;
+    }
+    __syncthreads();
+    const float s0 = s01[0], xs = lam / s01[1], inv_nb = 1.0f / n_glob_b;
+    const int N = Ns + B;
+    for (int i = tid; i < N * Tc; i += 1024) {
+        const int t = i / N, n = i - t * N;
+        float c;
+        if (n < Ns) {
+            const float a = (rewards[n] - baseline[n]) * one_minus_lam;
+            c = mask[(size_t)n * Tc + t] * a / s0;
+        } else {
+            const float x = q1 ? (col[t] * inv_nb) * loss_weight : gmask[(size_t)(n - Ns) * Tc + t] * loss_weight;
+            c = x * xs;
+        }
+        coef_tm[i] = c;
+        smooth_tm[i] = n < Ns ? 0.0f : smoothing;
+        cap_all[i] = i < Ns * Tc ? cap[i] : gcap[i - Ns * Tc];
+        target_tm[i] = n < Ns ? cap[(size_t)n * Tc + t] : gcap[(size_t)(n - Ns) * Tc + t];
+    }
+}
+hipError_t launch_mixed_prep(const float* mask, const float* gmask, const float* rewards, const float* baseline, const int32_t* cap,
+                             const int32_t* gcap, int Ns, int B, int Tc, float one_minus_lam, float lam, float loss_weight, int q1,
+                             float smoothing, float n_glob_b, float* coef_tm, float* smooth_tm, int32_t* cap_all, int32_t* target_tm, float* sums, hipStream_t st)
+{
+    if (Ns <= 0 || B <= 0 || Tc <= 0 || Tc > 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mixed_prep_kernel, dim3(1), dim3(1024), 0, st, mask, gmask, rewards, baseline, cap, gcap, Ns, B, Tc, one_minus_lam, lam,
+                       loss_weight, q1, smoothing, n_glob_b, coef_tm, smooth_tm, cap_all, target_tm, sums);
+    return hipGetLastError();
+}
+
+//   mixed_loss: out = {sum over the sampled rows, sum over the ground-truth rows, their sum} of coef * nll; row of entry r =
+//   (live_rows ? live_rows[r] : r) % N, sampled when < Ns
+__global__ __launch_bounds__(1024) void mixed_loss_kernel(const float* coef, const float* nll, const int32_t* live_rows, int R, int N, int Ns,
+                                                          float* out3)
+{
+    __shared__ float sh[2][32];
+    float a = 0.f, b = 0.f;
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        const int n = (live_rows ? live_rows[r] : r) % N;
+        const float v = coef[r] * nll[r];
+        if (n < Ns) a += v; else b += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float x = 0.f, y = 0.f;
+        for (int w = 0; w < 16; ++w) { x += sh[0][w]; y += sh[1][w]; }
+        out3[0] = x; out3[1] = y; out3[2] = x + y;
+    }
+}
+hipError_t launch_mixed_loss(const float* coef, const float* nll, const int32_t* live_rows, int R, int N, int Ns, float* out3, hipStream_t st)
+{
+    if (R < 0 || N <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mixed_loss_kernel, dim3(1), dim3(1024), 0, st, coef, nll, live_rows, R, N, Ns, out3);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void pg_coef_kernel(const float* mask, const float* rewards, const float* baseline, float scale, int N,
                                                       int Tc, float* coef_tm)
 {

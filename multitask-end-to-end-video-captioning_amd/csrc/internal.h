@@ -42,6 +42,12 @@ hipError_t launch_gemm_tn(const TnArgs& a, hipStream_t st);
 
 hipError_t launch_prep_caption(const int32_t* cap, int32_t* prev, int32_t* tgt, int N, int Tc, hipStream_t st);
 hipError_t launch_caption_mask(const int32_t* ids, int N, int Tc, float* mask, int32_t* target_tm, float* mask_sum, float* mask_sum_copy, hipStream_t st);
+hipError_t launch_xe_prep(const float* mask, const int32_t* cap, int N, int Tc, float loss_weight, float n_glob, int q1, float* coef_tm,
+                          int32_t* target_tm, float* msum, hipStream_t st);
+hipError_t launch_mixed_prep(const float* mask, const float* gmask, const float* rewards, const float* baseline, const int32_t* cap,
+                             const int32_t* gcap, int Ns, int B, int Tc, float one_minus_lam, float lam, float loss_weight, int q1,
+                             float smoothing, float n_glob_b, float* coef_tm, float* smooth_tm, int32_t* cap_all, int32_t* target_tm, float* sums, hipStream_t st);
+hipError_t launch_mixed_loss(const float* coef, const float* nll, const int32_t* live_rows, int R, int N, int Ns, float* out3, hipStream_t st);
 hipError_t launch_pg_coef(const float* mask, const float* rewards, const float* baseline, float scale, int N, int Tc, float* coef_tm,
                           hipStream_t st);
 hipError_t launch_step_scalars(const float* coef, const float* nll, int64_t R, const float* msum_local, const float* gsum_global, float* loss,

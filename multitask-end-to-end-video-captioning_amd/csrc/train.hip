@@ -422,6 +422,32 @@ int s2vt_pg_coef(const float* mask, const float* rewards, const float* baseline,
     return S2VT_OK;
 }
 
+int s2vt_xe_prep(const float* mask, const int32_t* caption, int32_t N, int32_t Tc, float loss_weight, float n_global, int32_t q1, float* coef_tm,
+                 int32_t* target_tm, float* mask_sum, s2vt_stream stream)
+{
+    if (!mask || !coef_tm || (target_tm && !caption) || N <= 0 || Tc <= 0 || Tc > 128 || !(n_global > 0.0f)) return S2VT_E_BADARG;
+    HIP_TRY(launch_xe_prep(mask, caption, N, Tc, loss_weight, n_global, q1, coef_tm, target_tm, mask_sum, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_mixed_prep(const float* mask, const float* gt_mask, const float* rewards, const float* baseline, const int32_t* sampled,
+                    const int32_t* gt_caption, int32_t Ns, int32_t B, int32_t Tc, float lambda_loss, float loss_weight, int32_t q1,
+                    float smoothing, float n_global_b, float* coef_tm, float* smooth_tm, int32_t* caption_all, int32_t* target_tm, float* sums, s2vt_stream stream)
+{
+    if (!mask || !gt_mask || !rewards || !baseline || !sampled || !gt_caption || !coef_tm || !smooth_tm || !caption_all || !target_tm || !sums) return S2VT_E_BADARG;
+    if (Ns <= 0 || B <= 0 || Tc <= 0 || Tc > 128 || !(n_global_b > 0.0f)) return S2VT_E_BADARG;
+    HIP_TRY(launch_mixed_prep(mask, gt_mask, rewards, baseline, sampled, gt_caption, Ns, B, Tc, (float)(1.0 - (double)lambda_loss), lambda_loss,
+                              loss_weight, q1, smoothing, n_global_b, coef_tm, smooth_tm, caption_all, target_tm, sums, S(stream)));
+    return S2VT_OK;
+}
+
+int s2vt_mixed_loss(const float* coef, const float* nll, const int32_t* live_rows, int64_t R, int32_t N, int32_t Ns, float* out3, s2vt_stream stream)
+{
+    if (!coef || !nll || !out3 || R < 0 || R > 0x7fffffff || N <= 0 || Ns < 0 || Ns > N) return S2VT_E_BADARG;
+    HIP_TRY(launch_mixed_loss(coef, nll, live_rows, (int)R, N, Ns, out3, S(stream)));
+    return S2VT_OK;
+}
+
 int s2vt_gemm_nt_splitk(const float* A, int32_t lda, const float* Wt, int32_t ldw, float* C, int32_t ldc, int32_t M, int32_t N,
                         int32_t K, int32_t splits, int32_t tile_cfg, float* slabs, size_t slab_floats, s2vt_stream stream)
 {

@@ -678,18 +678,23 @@ class Video_Caption_Generator:
         cap = self._dev(caption, torch.int32)
         mask = self._dev(caption_mask, torch.float32)
         N = cap.shape[0]
-        colsum = mask.sum(0)
         n_glob = float(N * self.world_size)
-        if q1:
-            dp.allreduce_small(colsum)
-            coef = (colsum[:, None] / n_glob).expand(-1, N) * self.loss_weight
-        else:
-            coef = mask.t() * self.loss_weight
-        coef = coef.contiguous().view(-1)
         keep = self.dropout_rate if keep is None else keep
-        nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep, steps=steps, live=live)
+        if not dp.active() and cap.shape[1] <= 128:
+            # one process: coefficients, time-major targets and sum(mask) in ONE library launch (the expressions below, same order)
+            coef, target_tm, msum = ops.xe_prep(mask.contiguous(), cap.contiguous(), self.loss_weight, n_glob, q1)
+            nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep, steps=steps, live=live, target_tm=target_tm)
+        else:
+            colsum = mask.sum(0)
+            if q1:
+                dp.allreduce_small(colsum)
+                coef = (colsum[:, None] / n_glob).expand(-1, N) * self.loss_weight
+            else:
+                coef = mask.t() * self.loss_weight
+            coef = coef.contiguous().view(-1)
+            nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep, steps=steps, live=live)
+            msum = mask.sum().reshape(1)
         coef = self._coef_used
-        msum = mask.sum().reshape(1)
         self.backward()
         self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value, extra_sumsq=extra_sumsq, decay_all=decay_all,
                              loss_terms=(coef, nll, msum))
@@ -726,36 +731,47 @@ class Video_Caption_Generator:
         mask = self._dev(mask, torch.float32)
         gcap = self._dev(gt_caption, torch.int32)
         gmask = self._dev(gt_mask, torch.float32)
-        adv = self._dev(rewards, torch.float32) - self._dev(baseline, torch.float32)
         B = video.shape[0]
         rep = cap.shape[0] // B
         assert gcap.shape[0] == B, "one ground-truth caption per video of the batch (reinforce_multitask_e2e_attribute_s2vt.py:977)"
         keep = self.dropout_rate if keep is None else keep
         lam = float(lambda_loss)
-        sums = torch.stack([mask.sum(), gmask.sum()])
-        dp.allreduce_small(sums)                                           # global sum(mask) of both objectives
-        coef_pg = mask * (adv * (1.0 - lam))[:, None] / sums[0]            # [rep*B, Tc] policy gradient on the sampled captions
-        if q1:                                                             # cross entropy on the ground truth (tf_s2vt.py:150-166, as xe_update)
-            colsum = gmask.sum(0)
-            dp.allreduce_small(colsum)
-            coef_xe = (colsum[None, :] / float(B * self.world_size)).expand(B, -1) * self.loss_weight
-        else:
-            coef_xe = gmask * self.loss_weight
-        coef_xe = coef_xe * (lam / sums[1])                                # [B, Tc]
-        coef = torch.cat([coef_pg, coef_xe], 0).t().contiguous().view(-1)  # time-major over the (rep+1)*B rows
-        smooth = torch.zeros((rep + 1) * B, dtype=torch.float32, device=self.device)
-        smooth[rep * B:] = float(smoothing)
-        smooth_tm = smooth.repeat(self.n_caption_lstm_step).contiguous()
-        nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, rep + 1, video_base, keep,
-                                    steps=steps, live=live)
         N = (rep + 1) * B
-        terms = self._coef_used * nll
-        if live is None:
-            per_row = terms.view(-1, N)
-            loss_pg, loss_xe = per_row[:, :rep * B].sum(), per_row[:, rep * B:].sum()
-        else:                                                    # (row of the unroll = live index % N: sampled rows first)
-            is_pg = (live.long() % N) < rep * B
-            loss_pg, loss_xe = terms[is_pg].sum(), terms[~is_pg].sum()
+        fused = not dp.active() and self.n_caption_lstm_step <= 128
+        if fused:
+            # one process: both blocks' coefficients, the smoothing vector, the joined caption block and the two mask sums in ONE
+            # library launch (the expressions of the branch below, in their order); the loss terms in one more
+            coef, smooth_tm, cap_all, target_tm, sums = ops.mixed_prep(mask.contiguous(), gmask.contiguous(), self._dev(rewards, torch.float32), self._dev(baseline, torch.float32),
+                                                            cap.contiguous(), gcap.contiguous(), lam, self.loss_weight, q1, smoothing, float(B * self.world_size))
+            nll, _ = self._forward_loss(video, cap_all, coef, smooth_tm, rep + 1, video_base, keep, steps=steps, live=live, target_tm=target_tm)
+            losses = ops.mixed_loss(self._coef_used, nll, live, N, rep * B)
+            loss_total = losses[2]
+        else:
+            adv = self._dev(rewards, torch.float32) - self._dev(baseline, torch.float32)
+            sums = torch.stack([mask.sum(), gmask.sum()])
+            dp.allreduce_small(sums)                                           # global sum(mask) of both objectives
+            coef_pg = mask * (adv * (1.0 - lam))[:, None] / sums[0]            # [rep*B, Tc] policy gradient on the sampled captions
+            if q1:                                                             # cross entropy on the ground truth (tf_s2vt.py:150-166, as xe_update)
+                colsum = gmask.sum(0)
+                dp.allreduce_small(colsum)
+                coef_xe = (colsum[None, :] / float(B * self.world_size)).expand(B, -1) * self.loss_weight
+            else:
+                coef_xe = gmask * self.loss_weight
+            coef_xe = coef_xe * (lam / sums[1])                                # [B, Tc]
+            coef = torch.cat([coef_pg, coef_xe], 0).t().contiguous().view(-1)  # time-major over the (rep+1)*B rows
+            smooth = torch.zeros((rep + 1) * B, dtype=torch.float32, device=self.device)
+            smooth[rep * B:] = float(smoothing)
+            smooth_tm = smooth.repeat(self.n_caption_lstm_step).contiguous()
+            nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, rep + 1, video_base, keep,
+                                        steps=steps, live=live)
+            terms = self._coef_used * nll
+            if live is None:
+                per_row = terms.view(-1, N)
+                loss_pg, loss_xe = per_row[:, :rep * B].sum(), per_row[:, rep * B:].sum()
+            else:                                                    # (row of the unroll = live index % N: sampled rows first)
+                is_pg = (live.long() % N) < rep * B
+                loss_pg, loss_xe = terms[is_pg].sum(), terms[~is_pg].sum()
+            loss_total = loss_pg + loss_xe
         self.backward(accumulate=False, overlap=False)
         attr_scale = attr_loss = None
         if true_labels is not None and self.label_dim > 0:
@@ -765,9 +781,11 @@ class Video_Caption_Generator:
             attr_scale = self.alpha / float(self.label_dim * B * self.world_size)
             self._attr_ctx = (dz, attr_scale)
             attr_loss = bce.sum() * attr_scale
-        one = torch.full((), 1.0 / self.world_size, device=self.device)   # the bucket is already normalised: global "sum(mask)" = 1
-        self.apply_gradients(one, lr, clip_norm, weight_decay=lam * self.decay_value, attr_scale=attr_scale)
-        st = StepStats(loss_pg + loss_xe, self._sumsq, sums[0])
+        one = getattr(self, "_one_over_world", None)                      # the bucket is already normalised: global "sum(mask)" = 1
+        if one is None or one[1] != self.world_size:
+            one = self._one_over_world = (torch.full((), 1.0 / self.world_size, device=self.device), self.world_size)
+        self.apply_gradients(one[0], lr, clip_norm, weight_decay=lam * self.decay_value, attr_scale=attr_scale)
+        st = StepStats(loss_total, self._sumsq, sums[0])
         st.attr_loss = attr_loss
         return st
 

@@ -363,6 +363,47 @@ def pg_coef(mask, rewards, baseline, scale=1.0):
     return coef
 
 
+def xe_prep(mask, caption, loss_weight, n_global, q1):
+    """(coef_tm [Tc*N], target_tm [Tc*N] int32, sum(mask) [1]) of the XE update in one launch (s2vt_xe_prep)."""
+    _chk_f32(mask)
+    N, Tc = mask.shape
+    assert caption.is_cuda and caption.dtype == torch.int32 and caption.is_contiguous() and tuple(caption.shape) == (N, Tc)
+    coef = torch.empty(N * Tc, dtype=torch.float32, device=mask.device)
+    target = torch.empty(N * Tc, dtype=torch.int32, device=mask.device)
+    msum = torch.empty(1, dtype=torch.float32, device=mask.device)
+    check(lib().s2vt_xe_prep(_ptr(mask), _ptr(caption), N, Tc, float(loss_weight), float(n_global), int(bool(q1)), _ptr(coef), _ptr(target),
+                             _ptr(msum), _stream()), "s2vt_xe_prep")
+    return coef, target, msum
+
+
+def mixed_prep(mask, gt_mask, rewards, baseline, sampled, gt_caption, lambda_loss, loss_weight, q1, smoothing, n_global_b):
+    """The mixed objective's coefficients (s2vt_mixed_prep): (coef_tm [Tc*N], smooth_tm [Tc*N], caption_all [N, Tc] int32, target_tm [Tc*N] int32, sums [2])."""
+    _chk_f32(mask, gt_mask, rewards, baseline)
+    Ns, Tc = mask.shape
+    B = gt_mask.shape[0]
+    N = Ns + B
+    for c_, n_ in ((sampled, Ns), (gt_caption, B)):
+        assert c_.is_cuda and c_.dtype == torch.int32 and c_.is_contiguous() and tuple(c_.shape) == (n_, Tc)
+    dev = mask.device
+    coef = torch.empty(N * Tc, dtype=torch.float32, device=dev)
+    smooth = torch.empty(N * Tc, dtype=torch.float32, device=dev)
+    cap_all = torch.empty((N, Tc), dtype=torch.int32, device=dev)
+    target = torch.empty(N * Tc, dtype=torch.int32, device=dev)
+    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    check(lib().s2vt_mixed_prep(_ptr(mask), _ptr(gt_mask), _ptr(rewards), _ptr(baseline), _ptr(sampled), _ptr(gt_caption), Ns, B, Tc,
+                                float(lambda_loss), float(loss_weight), int(bool(q1)), float(smoothing), float(n_global_b), _ptr(coef),
+                                _ptr(smooth), _ptr(cap_all), _ptr(target), _ptr(sums), _stream()), "s2vt_mixed_prep")
+    return coef, smooth, cap_all, target, sums
+
+
+def mixed_loss(coef, nll, live, N, Ns):
+    """[sum over the sampled rows, sum over the ground-truth rows, both] of coef * nll (s2vt_mixed_loss)."""
+    _chk_f32(coef, nll)
+    out = torch.empty(3, dtype=torch.float32, device=coef.device)
+    check(lib().s2vt_mixed_loss(_ptr(coef), _ptr(nll), _ptr(live), coef.numel(), N, Ns, _ptr(out), _stream()), "s2vt_mixed_loss")
+    return out
+
+
 def step_scalars(coef, nll, msum_local, gsum_global, loss=None, gscale=None, sumsq=None):
     _chk_f32(coef, nll, msum_local, gsum_global, loss, gscale, sumsq)
     R = 0 if coef is None else coef.numel()
