@@ -33,6 +33,7 @@ namespace s2vt {
 namespace {
 
 constexpr int kABMaxTv = 64;
+constexpr int kABRegFrames = 5;                            // up to this many frames a row's P, V, dP, dV live in registers (the script's default Tv)
 
 struct AttnBwdChainKArgs {
     const float* W3; int ldw;                          // [3H, 4H]
@@ -40,6 +41,8 @@ struct AttnBwdChainKArgs {
     const float* gates; size_t gates_tstride;          // activated gates [T][B][4H]
     const float* C; size_t state_tstride;              // cell states [T+1][B][H]
     const float* dcat; size_t dcat_tstride; int ld_cat;   // d[out | ctx | emb] of the output layer [T][B][3H]
+    float* dctx_hist;                                  // Tv > 5: == dcat, whose ctx block of step t is OVERWRITTEN with the total d(ctx_t) (attn_dpdv_kernel reads it)
+    float* deh;                                        // Tv > 5: [T][Tv][B] d(score) of every step (the same)
     float* dZ; size_t dz_tstride;                      // [T][B][4H]
     const float* hWa; size_t hwa_tstride;              // forward history [T][B][H] (slot 0 unused: zero query)
     const float* P; const float* Vt; const float* w; const float* alpha;   // [Tv,B,H] x2, [H], [T][Tv][B]
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // attention role with few frames (the script's default 5): the row's P and V, and the accumulators of dP and dV, live in REGISTERS
     // for the whole launch (4 columns x Tv frames each per thread) -- as global read-modify-writes per iteration they were 7 us of it
-    constexpr int TVR = 5;
+    constexpr int TVR = kABRegFrames;
     const bool aregs = roleA && Tv <= TVR;
     const bool aqok = 4 * tid < H;
     f32x4 pR[TVR], vR[TVR], dPR[TVR], dVR[TVR];
@@ -298,19 +301,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 AB_STAMP(6);                                   // dctx wait + load
                 if (tid < Tv) dal[tid] = (cq[tid] + cq[8 + tid]) + (cq[16 + tid] + cq[24 + tid]);
             } else {
-                if (qok) *reinterpret_cast<f32x4*>(dcl + 4 * q4) = dense;
+                if (qok) {
+                    *reinterpret_cast<f32x4*>(dcl + 4 * q4) = dense;
+                    // the total d(ctx_t) of this row: what the accumulation of dV needs, done for all steps at once behind the launch
+                    *reinterpret_cast<f32x4*>(g.dctx_hist + (size_t)t * g.dcat_tstride + (size_t)brow * g.ld_cat + H + 4 * q4) = dense;
+                }
                 __syncthreads();
                 AB_STAMP(6);                                   // dctx wait + load
-                for (int f = pwave; f < Tv; f += 16) {          // dalpha[f] = <dctx, V[f, b, :]>: a wave takes frames f, f+4, f+8, f+12 together
-                    float s4[4] = {0.f, 0.f, 0.f, 0.f};          // (16 loads in flight per trip instead of 4: the rows come from L2 / HBM every iteration)
-                    for (int q = lane; q < (H >> 2); q += 64) {
-                        const f32x4 d = *reinterpret_cast<const f32x4*>(dcl + 4 * q);
+                for (int f = pwave; f < Tv; f += 16) {          // dalpha[f] = <dctx, V[f, b, :]>: a wave takes frames f, f+4, f+8, f+12 together,
+                    f32x4 xv[4][4];                             // and ALL their loads go out before the first dot (16 in flight per lane: as
+                                                                // 4 x 4 dependent batches the rows' L2 latency was 12 us of a 52 us iteration at 32 frames)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (f + 4 * u < Tv) {
-                                const f32x4 x = *reinterpret_cast<const f32x4*>(g.Vt + ((size_t)(f + 4 * u) * M + brow) * H + 4 * q);
-                                s4[u] += d[0] * x[0] + d[1] * x[1] + d[2] * x[2] + d[3] * x[3];
-                            }
+                    for (int k = 0; k < 4; ++k) {
+                        const int q = lane + 64 * k;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            xv[k][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (q < (H >> 2) && f + 4 * u < Tv)
+                                xv[k][u] = *reinterpret_cast<const f32x4*>(g.Vt + ((size_t)(f + 4 * u) * M + brow) * H + 4 * q);
+                        }
+                    }
+                    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int q = lane + 64 * k;
+                        if (q < (H >> 2)) {
+                            const f32x4 d = *reinterpret_cast<const f32x4*>(dcl + 4 * q);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) s4[u] += d[0] * xv[k][u][0] + d[1] * xv[k][u][1] + d[2] * xv[k][u][2] + d[3] * xv[k][u][3];
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -323,17 +342,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             __syncthreads();
             AB_STAMP(7);                                       // dalpha dots
-            if (tid == 0) {
-                if (g.reg_coef && (g.reg_m - g.asum[(size_t)t * M + brow]) > 0.f) {
-                    const int n8 = Tv < 8 ? Tv : 8;
-                    const float rc = g.reg_coef[(size_t)t * M + brow];
-                    for (int f = 0; f < n8; ++f) dal[f] -= rc;
+            if (tid < 64) {                                      // softmax backward over the Tv <= 64 frames: one lane per frame (a serial loop
+                float al = 0.f, dl = 0.f;                      // of one thread was 2.3 us of the iteration at 32 frames)
+                if (tid < Tv) {
+                    al = all_[tid]; dl = dal[tid];
+                    if (g.reg_coef && tid < 8 && (g.reg_m - g.asum[(size_t)t * M + brow]) > 0.f) dl -= g.reg_coef[(size_t)t * M + brow];
                 }
-                float dot = 0.f;
-                for (int f = 0; f < Tv; ++f) dot += all_[f] * dal[f];
-                for (int f = 0; f < Tv; ++f) del[f] = all_[f] * (dal[f] - dot);
+                float dot = al * dl;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+                if (tid < Tv) del[tid] = al * (dl - dot);
             }
             __syncthreads();
+            if (!aregs && tid < Tv) g.deh[((size_t)t * Tv + tid) * M + brow] = del[tid];
             AB_STAMP(8);                                       // de
             if (qok) {
                 f32x4 accq = {0.f, 0.f, 0.f, 0.f}, dwl = {0.f, 0.f, 0.f, 0.f};
@@ -353,33 +374,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             }
                         }
                 } else
-                for (int f0 = 0; f0 < Tv; f0 += 8) {
-                    f32x4 pv[8], op[8], ov[8];                  // 8 frames' loads in flight at a time
+                // more frames than registers hold: P is streamed (16 frames' loads in flight), and the accumulation of dP and dV -- as
+                // global read-modify-writes here they were two thirds of this phase's 0.77 MB per iteration through one CU's L2 port
+                // at 32 frames -- is left to attn_dpdv_kernel, which redoes the tanh for all steps at once on the whole chip
+                for (int f0 = 0; f0 < Tv; f0 += 16) {
+                    f32x4 pv[16];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (f0 + j < Tv) {
-                            const size_t o = (size_t)(f0 + j) * M * H + rowoff;
-                            pv[j] = *reinterpret_cast<const f32x4*>(g.P + o);
-                            op[j] = *reinterpret_cast<const f32x4*>(g.dP + o);
-                            ov[j] = *reinterpret_cast<const f32x4*>(g.dVt + o);
-                        }
+                    for (int j = 0; j < 16; ++j)
+                        if (f0 + j < Tv) pv[j] = *reinterpret_cast<const f32x4*>(g.P + (size_t)(f0 + j) * M * H + rowoff);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < 16; ++j)
                         if (f0 + j < Tv) {
-                            const size_t o = (size_t)(f0 + j) * M * H + rowoff;
-                            const float d = del[f0 + j], alt = all_[f0 + j];
-                            f32x4 ds, dv;
+                            const float d = del[f0 + j];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const float Tn = dm_tanhf(hv[i] + pv[j][i]);
                                 const float s_ = d * wh[i] * (1.f - Tn * Tn);
                                 accq[i] += s_;
                                 dwl[i] += d * Tn;
-                                ds[i] = s_ + op[j][i];
-                                dv[i] = alt * dense[i] + ov[j][i];
                             }
-                            *reinterpret_cast<f32x4*>(g.dP + o) = ds;
-                            *reinterpret_cast<f32x4*>(g.dVt + o) = dv;
                         }
                 }
                 if (t > 0) {
@@ -461,6 +474,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
+// Behind the persistent launch, Tv > 5: dP[f][b][:] += sum_t de_t[f][b] w[:] (1 - tanh^2(hWa_t[b][:] + P[f][b][:])) and
+// dV[f][b][:] += sum_t alpha_t[f][b] dctx_t[b][:], t descending -- the expressions and the order of the in-loop accumulation (and of
+// attn.hip::attn_bwd_kernel), one workgroup per (row, frame) instead of one CU per row.
+__global__ __launch_bounds__(256) void attn_dpdv_kernel(const float* P, const float* hWa, size_t hwa_tstride, const float* dcat, size_t dcat_tstride,
+                                                        int ld_cat, const float* alpha, const float* deh, const float* w, int B, int H, int T, int Tv,
+                                                        float* dP, float* dVt)
+{
+    const int b = blockIdx.x, f = blockIdx.y, q4 = threadIdx.x;
+    if (4 * q4 >= H) return;
+    const size_t o = ((size_t)f * B + b) * H + 4 * q4;
+    const f32x4 pv = *reinterpret_cast<const f32x4*>(P + o), wh = *reinterpret_cast<const f32x4*>(w + 4 * q4);
+    f32x4 ap = *reinterpret_cast<const f32x4*>(dP + o), av = *reinterpret_cast<const f32x4*>(dVt + o);
+    for (int t0 = T - 1; t0 >= 0; t0 -= 4) {
+        f32x4 hv[4], dn[4];
+        float d[4], al[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 - u;
+            hv[u] = dn[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            d[u] = al[u] = 0.f;
+            if (t >= 0) {
+                d[u] = deh[((size_t)t * Tv + f) * B + b];
+                al[u] = alpha[((size_t)t * Tv + f) * B + b];
+                if (t > 0) hv[u] = *reinterpret_cast<const f32x4*>(hWa + (size_t)t * hwa_tstride + (size_t)b * H + 4 * q4);
+                dn[u] = *reinterpret_cast<const f32x4*>(dcat + (size_t)t * dcat_tstride + (size_t)b * ld_cat + H + 4 * q4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (t0 - u >= 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float Tn = dm_tanhf(hv[u][i] + pv[i]);
+                    const float s_ = d[u] * wh[i] * (1.f - Tn * Tn);
+                    ap[i] = s_ + ap[i];
+                    av[i] = al[u] * dn[u][i] + av[i];
+                }
+            }
+    }
+    *reinterpret_cast<f32x4*>(dP + o) = ap;
+    *reinterpret_cast<f32x4*>(dVt + o) = av;
+}
+
 struct ABCfg { int ng; void (*fn)(const AttnBwdChainKArgs); const char* name; };
 const ABCfg kABCfg[] = {{8, attn_bwd_chain_kernel<8>, "attn_bchain(ng8)"}, {64, attn_bwd_chain_kernel<64>, "attn_bchain(ng64)"}};
 constexpr int kNumABCfg = 2;
@@ -520,6 +576,7 @@ hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st)
 {
     if (!attn_bwd_chain_eligible(a.B, a.H, a.Tv)) return hipErrorInvalidValue;
     if (a.T <= 0) return hipSuccess;
+    if (a.Tv > kABRegFrames && !a.deh) return hipErrorInvalidValue;
     const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     if (!al16(a.W3) || (a.ldw & 3) || !al16(a.Wa) || !al16(a.P) || !al16(a.Vt) || !al16(a.w) || !al16(a.hWa) || !al16(a.dhWa) || !al16(a.dP) || !al16(a.dVt) ||
         !al16(a.dcat) || (a.ld_cat & 3) || (a.dcat_tstride & 3) || !al16(a.img) || !al16(a.ex) || !al16(a.dctxs) || (a.hwa_tstride & 3) || (a.dhwa_tstride & 3))
@@ -531,6 +588,7 @@ hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st)
     std::memset(&k, 0, sizeof(k));
     k.W3 = a.W3; k.ldw = a.ldw; k.Wa = a.Wa; k.ldwa = a.ldwa; k.gates = a.gates; k.gates_tstride = a.gates_tstride; k.C = a.C; k.state_tstride = a.state_tstride;
     k.dcat = a.dcat; k.dcat_tstride = a.dcat_tstride; k.ld_cat = a.ld_cat; k.dZ = a.dZ; k.dz_tstride = a.dz_tstride;
+    k.dctx_hist = a.dcat; k.deh = a.deh;
     k.hWa = a.hWa; k.hwa_tstride = a.hwa_tstride; k.P = a.P; k.Vt = a.Vt; k.w = a.w; k.alpha = a.alpha;
     k.reg_coef = a.reg_coef; k.asum = a.asum; k.reg_m = a.reg_m; k.dhWa = a.dhWa; k.dhwa_tstride = a.dhwa_tstride; k.dP = a.dP; k.dVt = a.dVt; k.dw = a.dw;
     k.B = a.B; k.H = a.H; k.T = a.T; k.Tv = a.Tv;
@@ -564,7 +622,14 @@ hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st)
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return order.after(st, hst.device);
+    e = order.after(st, hst.device);
+    if (e != hipSuccess) return e;
+    if (a.Tv > kABRegFrames) {                                 // the accumulation of dP / dV the kernel left out (see there)
+        hipLaunchKernelGGL(attn_dpdv_kernel, dim3((unsigned)a.B, (unsigned)a.Tv), dim3(256), 0, st, a.P, a.hWa, a.hwa_tstride, a.dcat, a.dcat_tstride,
+                           a.ld_cat, a.alpha, a.deh, a.w, a.B, a.H, a.T, a.Tv, a.dP, a.dVt);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 }  // namespace s2vt

@@ -170,6 +170,7 @@ struct AttnWs {
     unsigned long long* packed;    // greedy picks [Tc][B][kPickStride]
     float* aimg; unsigned* async_; // persistent forward recurrence (attn_chain.hip): fragment images, hand-off counters
     float *bimg, *bex, *brow_; unsigned* bsync;   // persistent backward recurrence (attn_chain_bwd.hip)
+    float* deh;                                   // ... its d(score) history [Tc][Tv][B] (more than 5 frames: dP / dV are accumulated behind the launch)
 };
 
 size_t carve_attn(Carver& c, const s2vt_dims* d, int B, AttnWs* out)
@@ -187,6 +188,7 @@ size_t carve_attn(Carver& c, const s2vt_dims* d, int B, AttnWs* out)
     w.dxs = c.take<float>((size_t)kXSlabs * b * 3 * H); w.dqs = c.take<float>((size_t)kQSlabs * b * H); w.dc = c.take<float>(b * H);
     w.dhWa = c.take<float>(Tc * b * H); w.dEmb = c.take<float>(Tc * b * H);
     w.dPt = c.take<float>(Tv * b * H); w.dVtt = c.take<float>(Tv * b * H); w.dEv = c.take<float>(Tv * b * H);
+    w.deh = c.take<float>(Tc * Tv * b);
     {
         // dY = dlogits @ Wout^T ([Tc B, H], K = |V|) and dcat = dpre @ Wp^T ([Tc B, 3H], K = H) when they are short of tiles
         size_t need = 0;
@@ -419,6 +421,7 @@ int s2vt_attn_bptt_bwd(const s2vt_dims* d, const s2vt_attn_params* p, const s2vt
         a.hWa = w.hWa; a.hwa_tstride = BH; a.P = w.P; a.Vt = w.Vt; a.w = p->embed_att_w; a.alpha = w.alpha;
         a.reg_coef = reg_coef; a.asum = w.asum; a.reg_m = reg_m;
         a.dhWa = w.dhWa; a.dhwa_tstride = BH; a.dP = w.dPt; a.dVt = w.dVtt; a.dw = grads->embed_att_w;
+        a.deh = w.deh;
         a.B = B; a.H = H; a.T = Tc; a.Tv = Tv;
         a.keep = keep; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code0 = kDropCode3;
         a.video_id = video_id; a.sample_id = sample_id;

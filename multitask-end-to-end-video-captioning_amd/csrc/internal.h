@@ -242,7 +242,8 @@ hipError_t launch_attn_chain(const AttnChainLaunch& a, hipStream_t st);
 struct AttnBwdChainLaunch {
     const float* W3; int ldw; const float* Wa; int ldwa;
     const float* gates; size_t gates_tstride; const float* C; size_t state_tstride;      // forward histories
-    const float* dcat; size_t dcat_tstride; int ld_cat;     // d[out | ctx | emb] of the output layer, [T][B][3H]
+    float* dcat; size_t dcat_tstride; int ld_cat;           // d[out | ctx | emb] of the output layer, [T][B][3H]; Tv > 5: the ctx block comes back as the TOTAL d(ctx_t)
+    float* deh;                                             // Tv > 5: [T][Tv][B] floats of scratch (d(score) per step, for the dP / dV accumulation behind the launch)
     float* dZ; size_t dz_tstride;                           // [T][B][4H]
     const float* hWa; size_t hwa_tstride; const float* P; const float* Vt; const float* w; const float* alpha;
     const float* reg_coef; const float* asum; float reg_m;  // alpha regulariser (reg_coef NULL = none)
