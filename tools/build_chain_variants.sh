@@ -12,6 +12,6 @@ done
 wait
 for spec in "$@"; do
   name=${spec%%:*}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api.o train.o attn.o session.o chain_bwd.o decode4.o /tmp/cvar_$name/chain.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so $(ls *.o | grep -v '^chain.o$') /tmp/cvar_$name/chain.o
 done
 ls -la ../../variants
