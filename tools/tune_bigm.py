@@ -30,7 +30,7 @@ for M in (int(x) for x in os.environ.get("MS", "2304,2048,256").split(",")):
     for name, x0, x1 in (("K=1500", ops.operand(None, k=H), ops.operand(Wemb, rowidx=idx)), ("K=1000", ops.operand(None, k=H + E), None)):
         flops = 2 * M * (1500 if x1 is not None else 1000) * 4 * H
         res = []
-        for cfg in range(-1, 12):
+        for cfg in range(-1, int(os.environ.get('NCFG', '12'))):
             t = timeit(lambda: ops.lstm_cell_fwd(x0, x1, h, c, W2, b2, M, tile_cfg=cfg))
             res.append(f"cfg{cfg}:{t:.0f}us/{flops / t / 1e6:.0f}TF")
         print(f"LSTM2 M={M} {name}: " + "  ".join(res), flush=True)
