@@ -100,9 +100,14 @@ class EndToEnd:
         ops.adam_tf(self.theta, self.grad, self.m, self.v, m._sumsq, clip_norm, lr, m.adam_t)
 
     # ---------------------------------------------------------------- training steps
-    def xe_step(self, frames, caption, caption_mask, lr, clip_norm=10.0, video_base=0):
+    def xe_step(self, frames, caption, caption_mask, lr, clip_norm=10.0, video_base=0, freeze_cnn=False):
         """One step of train() in e2e_tf_s2vt.py:482-700: label-smoothed XE through the CNN; weight decay on EVERY
-        trainable variable (the always-true predicate at :199)."""
+        trainable variable (the always-true predicate at :199).
+        freeze_cnn: the variant of fix_e2e_tf_s2vt.py (:120, :284: `net = tf.stop_gradient(net)`) -- the CNN runs in the loop,
+        feature dropout and all, but no gradient reaches it and its variables stay: only the captioner is clipped and updated."""
+        if freeze_cnn:
+            video, _ = self.extract(frames, dropout=True, track=False, video_base=video_base)
+            return self.model.xe_update(video, caption, caption_mask, lr, clip_norm=clip_norm, video_base=video_base, decay_all=True)
         video, h = self.extract(frames, dropout=True, track=True, video_base=video_base)
         st = self.model.xe_update(video, caption, caption_mask, lr, clip_norm=clip_norm, video_base=video_base,
                                   extra_sumsq=self._cnn_grads(h, self.model.decay_value, False), decay_all=True)

@@ -35,7 +35,9 @@ def save_cnn(trainer, cfg: Config, epoch: int):
 
 
 def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, width=299, height=299, restore=None,
-          cnn_variables=None, log=print):
+          cnn_variables=None, log=print, freeze_cnn=False):
+    """freeze_cnn: fix_e2e_tf_s2vt.py's variant (:120, :284 -- the CNN in the loop behind tf.stop_gradient; that script also runs
+    batch 64 at lr 1e-3: the caller's cfg)."""
     import torch
     from . import e2e, irv2, model as M
     par = DataParallel(model.device if model is not None else None)      # cfg.batch_size is the GLOBAL batch (16 in the reference)
@@ -68,7 +70,7 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
             captions_ind, captions_mask = hostglue.sentence_padding_toix(sentence, wordtoix, cfg.n_caption_lstm_step)
             st, loss = run_step(model, lambda: trainer.xe_step(frames, np.asarray(captions_ind, np.int32), captions_mask,
                                                                lr=learning_rate(cfg, model.global_step), clip_norm=cfg.clip_norm,
-                                                               video_base=lo), log)
+                                                               video_base=lo, freeze_cnn=freeze_cnn), log)
             losses.append(loss)
             log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} "
                 f"loss: {losses[-1]:.5f} Elapsed time: {time.time() - t0:.3f}")
@@ -88,6 +90,7 @@ def main():
     ap.add_argument("--vocab", required=True); ap.add_argument("--cnn-npz"); ap.add_argument("--restore")
     ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=16)
     ap.add_argument("--model-path", default="./new_e2e_models")
+    ap.add_argument("--freeze-cnn", action="store_true", help="fix_e2e_tf_s2vt.py: no gradient into the CNN")
     a = ap.parse_args()
     cfg = e2e_config(n_epochs=a.epochs, batch_size=a.batch_size, model_path=a.model_path)
     sents, frames = data.get_video_frame_caption_pair(a.train_sents, a.frames, cfg.n_video_lstm_step)
@@ -95,7 +98,7 @@ def main():
     if a.cnn_npz:
         with np.load(a.cnn_npz) as z:
             variables = {k: z[k] for k in z.files}
-    train(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, cnn_variables=variables)
+    train(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, cnn_variables=variables, freeze_cnn=a.freeze_cnn)
 
 
 if __name__ == "__main__":
