@@ -323,13 +323,15 @@ int s2vt_step_scalars(const float* coef, const float* nll, int64_t R, const floa
  *   coef_tm[t*N + n] = n < Ns ? mask[n][t] * ((rewards[n] - baseline[n]) * (1 - lambda)) / sum(mask)
  *                             : (q1 ? (sum_b gt_mask[b][t] / n_global_b) * loss_weight : gt_mask[n-Ns][t] * loss_weight) * (lambda / sum(gt_mask));
  *   smooth_tm[t*N + n] = n < Ns ? 0 : smoothing;  caption_all [N, Tc] = [sampled ; gt_caption], target_tm [Tc*N] the same ids time-major;
- *   sums = {sum(mask), sum(gt_mask)}.
+ *   sums = {sum(mask), sum(gt_mask)}.  lambda_loss is a DOUBLE: (1 - lambda) is formed in double and rounded to fp32 once, lambda itself
+ *   rounded to fp32 -- what the tensor expressions of a data-parallel caller (model.mixed_update) do with a Python float, so the two
+ *   paths give the same bits for a non-dyadic lambda (0.9: 0.1 -> 0x3dcccccd, not the 0x3dccccd0 of 1 - fl32(0.9)).
  * s2vt_mixed_loss: out3 = {sum over sampled rows, sum over ground-truth rows, both} of coef[r] * nll[r], r < R; the row of entry r is
  *   (live_rows ? live_rows[r] : r) % N. */
 int s2vt_xe_prep(const float* mask, const int32_t* caption, int32_t N, int32_t Tc, float loss_weight, float n_global, int32_t q1, float* coef_tm,
                  int32_t* target_tm, float* mask_sum, s2vt_stream stream);
 int s2vt_mixed_prep(const float* mask, const float* gt_mask, const float* rewards, const float* baseline, const int32_t* sampled,
-                    const int32_t* gt_caption, int32_t Ns, int32_t B, int32_t Tc, float lambda_loss, float loss_weight, int32_t q1,
+                    const int32_t* gt_caption, int32_t Ns, int32_t B, int32_t Tc, double lambda_loss, float loss_weight, int32_t q1,
                     float smoothing, float n_global_b, float* coef_tm, float* smooth_tm, int32_t* caption_all, int32_t* target_tm, float* sums, s2vt_stream stream);
 int s2vt_mixed_loss(const float* coef, const float* nll, const int32_t* live_rows, int64_t R, int32_t N, int32_t Ns, float* out3, s2vt_stream stream);
 
@@ -428,6 +430,10 @@ int s2vt_attr_head_fwd(const float* video, int32_t B, int32_t Tv, int32_t D, con
                        int32_t A, const float* labels, float* mean_feat, float* z, float* bce, s2vt_stream stream);
 int s2vt_attr_head_bwd(const float* mean_feat, const float* z, const float* labels, int32_t B, int32_t D, int32_t A,
                        float scale, float* dz_scratch, float* d_attr_W, float* d_attr_b, s2vt_stream stream);
+/* evaluate_multilabel (reinforce_multitask_e2e_attribute_loss.py:606-626): the head's forward followed by
+ * scores[B, A] = sigmoid(z) (:624).  mean_feat [B, D] and z [B, A] are written as by s2vt_attr_head_fwd. */
+int s2vt_attr_head_scores(const float* video, int32_t B, int32_t Tv, int32_t D, const float* attr_W, const float* attr_b,
+                          int32_t A, float* mean_feat, float* z, float* scores, s2vt_stream stream);
 
 /* ==== session API + the single-op entry points of the boundary ============= */
 

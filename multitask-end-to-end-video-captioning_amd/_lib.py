@@ -97,7 +97,7 @@ SIGNATURES = {
     "s2vt_caption_mask": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_pg_coef": (C.c_int, [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp]),
     "s2vt_xe_prep": (C.c_int, [_vp, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
-    "s2vt_mixed_prep": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "s2vt_mixed_prep": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_double, _f32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_mixed_loss": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "s2vt_step_scalars": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_grad_finalize": (C.c_int, [_vp, _vp, _i64, _vp, _f32, _vp, _vp]),
@@ -112,6 +112,7 @@ SIGNATURES = {
     "s2vt_attn_decode_greedy": (C.c_int, [_DP, _AP, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "s2vt_attr_head_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "s2vt_attr_head_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "s2vt_attr_head_scores": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "s2vt_create": (C.c_int, [_DP, _i32, _i32, C.POINTER(_vp)]),
     "s2vt_destroy": (C.c_int, [_vp]),
     "s2vt_encode_fwd": (C.c_int, [_vp, _PP, _vp, _i32, _vp]),

@@ -293,6 +293,13 @@ __global__ void sigmoid_bce_kernel(const float* z, const float* y, float* bce, f
     if (dz) dz[i] = scale * (dm_sigmoidf(zz) - yy);
 }
 
+// scores = sigmoid(z): evaluate_multilabel (reinforce_multitask_e2e_attribute_loss.py:624)
+__global__ void sigmoid_kernel(const float* z, float* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dm_sigmoidf(z[i]);
+}
+
 }  // namespace
 
 namespace s2vt {
@@ -398,6 +405,17 @@ int s2vt_attr_head_fwd(const float* video, int32_t B, int32_t Tv, int32_t D, con
         hipLaunchKernelGGL(sigmoid_bce_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, z, labels, bce, nullptr, 0.f, B * A);
         HIP_TRY(hipGetLastError());
     }
+    return S2VT_OK;
+}
+
+int s2vt_attr_head_scores(const float* video, int32_t B, int32_t Tv, int32_t D, const float* attr_W, const float* attr_b,
+                          int32_t A, float* mean_feat, float* z, float* scores, s2vt_stream stream)
+{
+    if (!scores) return S2VT_E_BADARG;
+    const int rc = s2vt_attr_head_fwd(video, B, Tv, D, attr_W, attr_b, A, nullptr, mean_feat, z, nullptr, stream);
+    if (rc != S2VT_OK) return rc;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((B * A + 255) / 256), dim3(256), 0, S(stream), z, scores, B * A);
+    HIP_TRY(hipGetLastError());
     return S2VT_OK;
 }
 

@@ -10,6 +10,7 @@
 #include "detmath.h"
 #include "gemm_tn.h"
 #include "internal.h"
+#include "chain_common.h"
 
 namespace s2vt {
 
@@ -683,20 +684,36 @@ hipError_t launch_gather_rows(const float* src, int ld, const int32_t* idx, int 
 // the *_live entry points -- the rows sorted by length, longest first (stable: equal lengths keep their order), and the number
 // of rows still live at every step of the recurrence (every row during the Tv encode steps).  One workgroup, N <= 1024.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void row_order_kernel(const int32_t* live_rows, int n_live, int N, int Tv, int Tc, int32_t* perm, int32_t* nlive)
+// The list is VALIDATED here (the *_live contract: time-major indices, strictly ascending, every row's live steps a PREFIX of the
+// decode steps -- what a mask up to a first <eos> gives; model.live_rows() checks the same on the host): len[n] entries of row n
+// must be steps 0 .. len[n]-1.  A list with a hole, a duplicate or an index out of range would make LSTM2 stop a row too early and
+// the gathered gradient products miss rows -- silently.  So: the recurrences get the DENSE order (perm = identity, every row live at
+// every step: nothing stops early), and the sticky fault of chain_common.h is raised (device word: queued Adam launches skip their
+// update; host-mapped counter: every later entry point returns S2VT_E_CHAIN_TIMEOUT until s2vt_chain_ack, model.check_health()
+// raises); word 1 of the fault buffer says why (1 = invalid live list).
+__global__ __launch_bounds__(1024) void row_order_kernel(const int32_t* live_rows, int n_live, int N, int Tv, int Tc, int32_t* perm, int32_t* nlive,
+                                                         unsigned* fault, unsigned* status)
 {
     __shared__ int len[1024];
+    __shared__ int maxt[1024];
     __shared__ int cnt[128];
+    __shared__ int bad;
     const int tid = threadIdx.x;
     len[tid] = 0;
+    maxt[tid] = -1;
     if (tid < 128) cnt[tid] = 0;
+    if (tid == 0) bad = 0;
     __syncthreads();
     for (int r = tid; r < n_live; r += 1024) {
         const int idx = live_rows[r];
         const int t = idx / N, n = idx - t * N;
-        if (t >= 0 && t < Tc && t < 128) { atomicAdd(&len[n], 1); atomicAdd(&cnt[t], 1); }
+        if (idx < 0 || t >= Tc || t >= 128 || (r > 0 && live_rows[r - 1] >= idx)) { bad = 1; continue; }
+        atomicAdd(&len[n], 1); atomicAdd(&cnt[t], 1); atomicMax(&maxt[n], t);
     }
     __syncthreads();
+    if (tid < N && len[tid] != maxt[tid] + 1) bad = 1;
+    __syncthreads();
+    const bool invalid = bad != 0;
     if (tid < N) {
         const int mine = len[tid];
         int rank = 0;
@@ -704,14 +721,24 @@ __global__ __launch_bounds__(1024) void row_order_kernel(const int32_t* live_row
             const int o = len[m];
             rank += (o > mine || (o == mine && m < tid)) ? 1 : 0;
         }
-        perm[rank] = tid;
+        if (invalid) perm[tid] = tid; else perm[rank] = tid;
     }
-    for (int t = tid; t < Tv + Tc; t += 1024) nlive[t] = t < Tv ? N : cnt[t - Tv];
+    for (int t = tid; t < Tv + Tc; t += 1024) nlive[t] = (t < Tv || invalid) ? N : cnt[t - Tv];
+    if (invalid && tid == 0) {
+        if (fault) {
+            __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fault + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (status) __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 hipError_t launch_row_order(const int32_t* live_rows, int n_live, int N, int Tv, int Tc, int32_t* perm, int32_t* nlive, hipStream_t st)
 {
     if (!live_rows || n_live < 0 || N <= 0 || N > 1024 || Tv < 0 || Tc <= 0 || Tc > 128 || !perm || !nlive) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(row_order_kernel, dim3(1), dim3(1024), 0, st, live_rows, n_live, N, Tv, Tc, perm, nlive);
+    ChainHost h;
+    const bool have = chain_host(&h);              // (no persistent-launch state on this device: nothing to raise the fault on; the order is still made dense)
+    hipLaunchKernelGGL(row_order_kernel, dim3(1), dim3(1024), 0, st, live_rows, n_live, N, Tv, Tc, perm, nlive, have ? h.fault : nullptr,
+                       have ? h.status_dev : nullptr);
     return hipGetLastError();
 }
 

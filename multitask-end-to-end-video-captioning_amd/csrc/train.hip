@@ -396,7 +396,9 @@ int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const
     // 257-384 rows: a row behind its <eos> stops stepping (rows by length, live rows per step -- its histories there are not
     // written and not read: every consumer below and in the backward pass gathers the live pairs)
     const bool rec_live = live_rows && Tc <= 128 && chain_live_capable(N, H);
-    if (rec_live) HIP_TRY(launch_row_order(live_rows, n_live, N, Tv, Tc, w.perm, w.nlive, st));
+    // (the kernel also VALIDATES the list -- per-row prefix, strictly ascending -- and raises the sticky fault otherwise, so it runs for
+    //  every live pass it can take, whether or not the recurrences of this shape use the order)
+    if (live_rows && Tc <= 128 && N <= 1024) HIP_TRY(launch_row_order(live_rows, n_live, N, Tv, Tc, w.perm, w.nlive, st));
     HIP_TRY(lstm_recurrence(p->lstm2_W, H + E, p->lstm2_b, w.G2, (size_t)4 * NH, 4 * H, T, w.C2, w.H2, NH, w.G2, (size_t)4 * NH,
                             w.O2, NH, N, H, T, keep, ids, 512u, w.chain_abuf, w.chain_sync, st, rec_live ? w.perm : nullptr,
                             rec_live ? w.nlive : nullptr));
@@ -431,12 +433,12 @@ int s2vt_xe_prep(const float* mask, const int32_t* caption, int32_t N, int32_t T
 }
 
 int s2vt_mixed_prep(const float* mask, const float* gt_mask, const float* rewards, const float* baseline, const int32_t* sampled,
-                    const int32_t* gt_caption, int32_t Ns, int32_t B, int32_t Tc, float lambda_loss, float loss_weight, int32_t q1,
+                    const int32_t* gt_caption, int32_t Ns, int32_t B, int32_t Tc, double lambda_loss, float loss_weight, int32_t q1,
                     float smoothing, float n_global_b, float* coef_tm, float* smooth_tm, int32_t* caption_all, int32_t* target_tm, float* sums, s2vt_stream stream)
 {
     if (!mask || !gt_mask || !rewards || !baseline || !sampled || !gt_caption || !coef_tm || !smooth_tm || !caption_all || !target_tm || !sums) return S2VT_E_BADARG;
     if (Ns <= 0 || B <= 0 || Tc <= 0 || Tc > 128 || !(n_global_b > 0.0f)) return S2VT_E_BADARG;
-    HIP_TRY(launch_mixed_prep(mask, gt_mask, rewards, baseline, sampled, gt_caption, Ns, B, Tc, (float)(1.0 - (double)lambda_loss), lambda_loss,
+    HIP_TRY(launch_mixed_prep(mask, gt_mask, rewards, baseline, sampled, gt_caption, Ns, B, Tc, (float)(1.0 - lambda_loss), (float)lambda_loss,
                               loss_weight, q1, smoothing, n_global_b, coef_tm, smooth_tm, caption_all, target_tm, sums, S(stream)));
     return S2VT_OK;
 }
@@ -590,7 +592,7 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         BwdScratch sc{w.slab, w.dc, w.bimg, w.bex, w.bsync};
         // (live rows: the forward pass of this workspace stopped the rows behind their <eos>, see there -- the same order here)
         const bool rec_live = live_rows && Tc <= 128 && chain_live_capable(N, H);
-        if (rec_live) HIP_TRY(launch_row_order(live_rows, n_live, N, Tv, Tc, w.perm, w.nlive, st));
+        if (live_rows && Tc <= 128 && N <= 1024) HIP_TRY(launch_row_order(live_rows, n_live, N, Tv, Tc, w.perm, w.nlive, st));
         HIP_TRY(lstm_recurrence_bwd(p->lstm2_W, H + E, w.G2, w.C2, w.dO2, NH, H, Tv, w.dZ2, N, H, T, keep, seed, 512u, video_id, sample_id, sc, -1, st,
                                     rec_live ? w.perm : nullptr, rec_live ? w.nlive : nullptr));
     }

@@ -47,6 +47,8 @@ class EndToEnd:
             p.grad = self.grad[off:off + k].view_as(p)
             off += k
         self.params = params
+        self.adam_t = 0          # Adam's count of updates applied to the CNN's moments: its own, not the captioner's -- a captioner restored
+                                 # with its optimizer state (large t) beside fresh CNN moments would otherwise bias-correct zeros at step t
 
     # ---------------------------------------------------------------- features
     def _feature_dropout(self, f, B, Tv, video_base, draw):
@@ -95,19 +97,38 @@ class EndToEnd:
             return torch.dot(self.grad, self.grad).reshape(1)
         return extra
 
+    def _cnn_decay_only(self, weight_decay):
+        """The CNN half of fix_e2e_tf_s2vt.py's update: `net = tf.stop_gradient(net)` (:120) cuts the data gradient, but the
+        weight-decay term sums l2_loss over ALL tf.trainable_variables() (:199, always-true predicate) and compute_gradients(tf_loss)
+        (:534) covers them, so every CNN variable receives decay_value * theta, counts toward clip_by_global_norm(10) (:535) and is
+        moved by Adam.  Identical on every rank: no all-reduce."""
+        def extra(gscale):
+            torch.mul(self.theta, float(weight_decay), out=self.grad)
+            return torch.dot(self.grad, self.grad).reshape(1)
+        return extra
+
     def _cnn_apply(self, lr, clip_norm):
         m = self.model
-        ops.adam_tf(self.theta, self.grad, self.m, self.v, m._sumsq, clip_norm, lr, m.adam_t)
+        self.adam_t += 1
+        ops.adam_tf(self.theta, self.grad, self.m, self.v, m._sumsq, clip_norm, lr, self.adam_t)
 
     # ---------------------------------------------------------------- training steps
-    def xe_step(self, frames, caption, caption_mask, lr, clip_norm=10.0, video_base=0, freeze_cnn=False):
+    def xe_step(self, frames, caption, caption_mask, lr, clip_norm=10.0, video_base=0, freeze_cnn=False, cnn_weight_decay=True):
         """One step of train() in e2e_tf_s2vt.py:482-700: label-smoothed XE through the CNN; weight decay on EVERY
         trainable variable (the always-true predicate at :199).
         freeze_cnn: the variant of fix_e2e_tf_s2vt.py (:120, :284: `net = tf.stop_gradient(net)`) -- the CNN runs in the loop,
-        feature dropout and all, but no gradient reaches it and its variables stay: only the captioner is clipped and updated."""
+        feature dropout and all, and no DATA gradient reaches it (no backward through the CNN).  As in that script its variables
+        still receive the weight-decay gradient decay_value * theta (:199 sums over every trainable variable), are part of the
+        joint clip norm and are moved by Adam (_cnn_decay_only).  cnn_weight_decay=False is the literal freeze instead -- a
+        deviation from the reference, for callers that want the CNN untouched: only the captioner is clipped and updated."""
         if freeze_cnn:
             video, _ = self.extract(frames, dropout=True, track=False, video_base=video_base)
-            return self.model.xe_update(video, caption, caption_mask, lr, clip_norm=clip_norm, video_base=video_base, decay_all=True)
+            if not cnn_weight_decay:
+                return self.model.xe_update(video, caption, caption_mask, lr, clip_norm=clip_norm, video_base=video_base, decay_all=True)
+            st = self.model.xe_update(video, caption, caption_mask, lr, clip_norm=clip_norm, video_base=video_base,
+                                      extra_sumsq=self._cnn_decay_only(self.model.decay_value), decay_all=True)
+            self._cnn_apply(lr, clip_norm)
+            return st
         video, h = self.extract(frames, dropout=True, track=True, video_base=video_base)
         st = self.model.xe_update(video, caption, caption_mask, lr, clip_norm=clip_norm, video_base=video_base,
                                   extra_sumsq=self._cnn_grads(h, self.model.decay_value, False), decay_all=True)
@@ -132,6 +153,13 @@ class EndToEnd:
         self._cnn_apply(lr, clip_norm)
         st.samples, st.greedy = samples, greedy
         return st
+
+    def evaluate_multilabel(self, frames, threshold=0.5):
+        """evaluate_multilabel of reinforce_multitask_e2e_attribute_loss.py:606-626 through the CNN (batch norm and dropout in
+        inference mode, :613-620): sigmoid(mean_t(video) . attr_W + attr_b) [B, label_dim] (device tensor).  `threshold` is accepted
+        and unused, as there."""
+        video, _ = self.extract(frames, dropout=False)
+        return self.model.attribute_scores(video)
 
     def generate(self, frames, video_base=0):
         """build_generator / build_sampler through the CNN (dropout off): greedy ids [B, Tc]."""

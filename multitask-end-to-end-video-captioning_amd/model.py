@@ -124,6 +124,9 @@ class ParamStore:
         loaded = []
         self.restored_step = None
         self.restored_adam_t = None
+        sd = dict(sd)
+        if "_s2vt/adam_t" in sd:                                 # the TF-format files' private name for the same count
+            sd.setdefault("adam_t", sd.pop("_s2vt/adam_t"))
         explicit_t = "adam_t" in sd and np.ndim(sd["adam_t"]) == 0
         if explicit_t:
             self.restored_adam_t = int(sd["adam_t"])
@@ -701,7 +704,7 @@ class Video_Caption_Generator:
         return StepStats(self._loss[0], self._sumsq, msum[0])
 
     def mixed_update(self, video, sampled, mask, rewards, baseline, gt_caption, gt_mask, lr, lambda_loss=0.5, clip_norm=5.0,
-                     video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None, active_steps="auto"):
+                     video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None, active_steps="auto", decay_all=False):
         """The mixed objective of reinforce_multitask_e2e_attribute_s2vt.py:850 (BASELINE configs[3]):
             sum_loss = -(1 - lambda) * PG / sum(mask_pg)  +  lambda * model_loss
         with PG the reward-scaled log-likelihood of the SAMPLED captions (build_loss) and model_loss the
@@ -712,7 +715,11 @@ class Video_Caption_Generator:
         mask sum), so the unrolls, the vocabulary products and the backward run once -- at B = 32, K = 1 that is 64 rows
         for the price of 32.  With true_labels [B, label_dim] (and a model built with label_dim > 0) the attribute head's
         term of reinforce_multitask_e2e_attribute_loss.py:957 is added: + alpha * sum(bce) / (label_dim * B_global) --
-        the per-GPU shape of BASELINE configs[3] (attribute FC + XE mix + REINFORCE, K = 1)."""
+        the per-GPU shape of BASELINE configs[3] (attribute FC + XE mix + REINFORCE, K = 1).
+        decay_all: SURVEY Q3, second half -- the weight-decay predicate of the multitask / e2e scripts,
+        `if 'bias' or 'BatchNorm' not in v.name` (reinforce_multitask_e2e_attribute_s2vt.py:222), is always true, so model_loss
+        decays EVERY variable, the LSTM `biases` included: their gradients carry lambda * decay_value * b.  False keeps
+        tf_s2vt.py:163's filter (names without 'bias')."""
         if active_steps == "auto":          # both blocks decide: the longest sample and the longest ground-truth caption
             sa, sb = self.active_steps(mask), self.active_steps(gt_mask)
             active_steps = None if (sa is None or sb is None or (q1 and self.world_size > 1)) else max(sa, sb)
@@ -750,14 +757,19 @@ class Video_Caption_Generator:
             adv = self._dev(rewards, torch.float32) - self._dev(baseline, torch.float32)
             sums = torch.stack([mask.sum(), gmask.sum()])
             dp.allreduce_small(sums)                                           # global sum(mask) of both objectives
-            coef_pg = mask * (adv * (1.0 - lam))[:, None] / sums[0]            # [rep*B, Tc] policy gradient on the sampled captions
+            # (lambda enters as fp32 device scalars -- fl32(1 - lambda) rounded once from the double, fl32(lambda) -- and every
+            #  division below is an fp32 tensor division: the very operations of s2vt_mixed_prep, so the fused single-process path
+            #  and this data-parallel one give the same bits for any lambda, whatever the tensor library does with Python scalars)
+            one_minus = torch.full((), 1.0 - lam, dtype=torch.float32, device=self.device)
+            lam_t = torch.full((), lam, dtype=torch.float32, device=self.device)
+            coef_pg = mask * (adv * one_minus)[:, None] / sums[0]              # [rep*B, Tc] policy gradient on the sampled captions
             if q1:                                                             # cross entropy on the ground truth (tf_s2vt.py:150-166, as xe_update)
                 colsum = gmask.sum(0)
                 dp.allreduce_small(colsum)
                 coef_xe = (colsum[None, :] / float(B * self.world_size)).expand(B, -1) * self.loss_weight
             else:
                 coef_xe = gmask * self.loss_weight
-            coef_xe = coef_xe * (lam / sums[1])                                # [B, Tc]
+            coef_xe = coef_xe * (lam_t / sums[1])                              # [B, Tc]
             coef = torch.cat([coef_pg, coef_xe], 0).t().contiguous().view(-1)  # time-major over the (rep+1)*B rows
             smooth = torch.zeros((rep + 1) * B, dtype=torch.float32, device=self.device)
             smooth[rep * B:] = float(smoothing)
@@ -784,10 +796,29 @@ class Video_Caption_Generator:
         one = getattr(self, "_one_over_world", None)                      # the bucket is already normalised: global "sum(mask)" = 1
         if one is None or one[1] != self.world_size:
             one = self._one_over_world = (torch.full((), 1.0 / self.world_size, device=self.device), self.world_size)
-        self.apply_gradients(one[0], lr, clip_norm, weight_decay=lam * self.decay_value, attr_scale=attr_scale)
+        self.apply_gradients(one[0], lr, clip_norm, weight_decay=lam * self.decay_value, attr_scale=attr_scale, decay_all=decay_all)
         st = StepStats(loss_total, self._sumsq, sums[0])
         st.attr_loss = attr_loss
         return st
+
+    def attribute_scores(self, video):
+        """sigmoid(mean_t(video) . attr_W + attr_b) [B, label_dim] on the device -- the scores of evaluate_multilabel
+        (reinforce_multitask_e2e_attribute_loss.py:621-624) for a feature block already in HBM."""
+        if not self.label_dim:
+            raise ValueError("attribute_scores / evaluate_multilabel need a model built with label_dim > 0")
+        return ops.attr_head_scores(self._dev(video, torch.float32), self.store.p["attr_W"], self.store.p["attr_b"])[1]
+
+    def evaluate_multilabel(self, threshold=0.5):
+        """evaluate_multilabel(threshold) -> (video, scores) of reinforce_multitask_e2e_attribute_loss.py:606-626:
+        scores = sigmoid(xw_plus_b(reduce_mean(video, axis=1), attr_W, attr_b)), [batch, label_num].  The reference's
+        placeholder takes frames and runs the CNN in inference mode first (:608-620); with precomputed features the feed is
+        the feature block [n, Tv, dim_image] (e2e.EndToEnd.evaluate_multilabel goes through the CNN).  `threshold` is
+        accepted and unused, exactly as there (the caller thresholds the scores)."""
+        video = Placeholder("video", (None, self.n_video_lstm_step, self.dim_image), np.float32)
+
+        def fn(v):
+            return {"scores": self.attribute_scores(v).cpu().numpy()}
+        return video, Output("scores", fn, [video])
 
     def build_model(self):
         """(loss, video, caption, caption_mask, probs) as tf_s2vt.py:90-167.  Fetching `loss`

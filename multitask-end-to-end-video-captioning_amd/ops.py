@@ -590,6 +590,19 @@ def attr_head_fwd(video, attr_W, attr_b, labels=None):
     return mean, z, bce
 
 
+def attr_head_scores(video, attr_W, attr_b):
+    """evaluate_multilabel (reinforce_multitask_e2e_attribute_loss.py:606-626): (z, sigmoid(z)) [B, A]."""
+    _chk_f32(video, attr_W, attr_b)
+    B, Tv, D = video.shape
+    A = attr_W.shape[1]
+    mean = torch.empty((B, D), dtype=torch.float32, device=video.device)
+    z = torch.empty((B, A), dtype=torch.float32, device=video.device)
+    scores = torch.empty_like(z)
+    check(lib().s2vt_attr_head_scores(_ptr(video), B, Tv, D, _ptr(attr_W), _ptr(attr_b), A, _ptr(mean), _ptr(z), _ptr(scores), _stream()),
+          "s2vt_attr_head_scores")
+    return z, scores
+
+
 def attr_head_bwd(mean, z, labels, scale, d_attr_W, d_attr_b):
     _chk_f32(mean, z, labels, d_attr_W, d_attr_b)
     B, D = mean.shape

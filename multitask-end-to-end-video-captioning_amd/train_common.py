@@ -33,7 +33,11 @@ class Config:
     model_path: str = "./models"
     model_name: str = "s2vt_model"
     max_steps_per_epoch: int = 0       # 0 = the whole epoch (tests bound it)
-    checkpoint_format: str = "npz"     # "npz" (name -> array dump) or "tf" (a TensorFlow V2 checkpoint: <name>-<epoch>.index / .data-00000-of-00001)
+    checkpoint_format: str = "npz"     # "npz" (name -> array dump), "tf" (a TensorFlow checkpoint in the format the mirrored script's own Saver writes:
+                                       # V2 -- <name>-<epoch>.index / .data-00000-of-00001 -- for the REINFORCE / e2e / attention drivers, ONE V1 file
+                                       # <name>-<epoch> for train_xe, whose reference saver is write_version=1, tf_s2vt.py:440) or "tf_v1" (V1 everywhere).
+                                       # TF-format files are a SUPERSET of the reference's: besides its names they carry the Adam slots / beta powers /
+                                       # counter (the XE reference saver holds the model variables only) and one private int64 '_s2vt/adam_t'.
     step_log: str = ""                 # path of a JSONL step log ("" = none)
     stop_at_eos: bool = False          # RL: samples leave the decode loop at their first <eos> (opt-in; the reference samples all Tc steps and masks
                                        # afterwards -- same update, shorter loop: model.sample(stop_at_eos=True))
@@ -232,6 +236,8 @@ def save_checkpoint(model, cfg: Config, epoch: int, step_name: str = "g_step", t
         from . import tfckpt
         path = os.path.join(cfg.model_path, f"{cfg.model_name}-{epoch}")
         sd.pop("global_step", None)                        # (this repository's alias; the graph's counter is `step_name`)
+        if "adam_t" in sd:                                 # not a variable of the reference's graph: kept under a clearly private name
+            sd["_s2vt/adam_t"] = sd.pop("adam_t")
         arrays = {k: np.asarray(v) for k, v in sd.items()}
         if cfg.checkpoint_format == "tf_v1" or tf_version == 1:    # tf_s2vt.py:440: tf.train.Saver(write_version=1) -- ONE file, the V1 tensor-slice format
             tfckpt.write_checkpoint_v1(path, arrays)
@@ -268,7 +274,7 @@ def optimistic_restore(model, path, restore_step: bool = True, step_names=("glob
     # slots (for --resume), and loading them here would drive the first REINFORCE updates with XE-scale moments.
     keep_opt = optimizer_state is True or (optimizer_state == "auto" and any(k in raw for k in step_names))
     if not keep_opt:
-        sd = {k: v for k, v in sd.items() if not (k.endswith("/Adam") or k.endswith("/Adam_1") or k in ("beta1_power", "beta2_power", "adam_t"))}
+        sd = {k: v for k, v in sd.items() if not (k.endswith("/Adam") or k.endswith("/Adam_1") or k in ("beta1_power", "beta2_power", "adam_t", "_s2vt/adam_t"))}
     loaded = model.store.load_state_dict(sd)
     st = model.store
     if restore_step and (st.restored_step is not None or st.restored_adam_t is not None):

@@ -35,9 +35,13 @@ def save_cnn(trainer, cfg: Config, epoch: int):
 
 
 def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, width=299, height=299, restore=None,
-          cnn_variables=None, log=print, freeze_cnn=False):
+          cnn_variables=None, log=print, freeze_cnn=False, resume=None):
     """freeze_cnn: fix_e2e_tf_s2vt.py's variant (:120, :284 -- the CNN in the loop behind tf.stop_gradient; that script also runs
-    batch 64 at lr 1e-3: the caller's cfg)."""
+    batch 64 at lr 1e-3: the caller's cfg).
+    restore: initialise the captioner's VARIABLES from a checkpoint of another run (an XE model, as the reference's saver.restore of
+    tf_s2vt's file, which holds neither optimizer slots nor a counter, tf_s2vt.py:440): Adam starts from zero moments and the staircase
+    from step 0 -- inheriting the XE run's moments and update count beside a CNN whose moments start at zero would bias-correct the
+    latter as if they had seen t updates.  resume: continue THIS run -- slots, update count and step counter are taken over."""
     import torch
     from . import e2e, irv2, model as M
     par = DataParallel(model.device if model is not None else None)      # cfg.batch_size is the GLOBAL batch (16 in the reference)
@@ -50,7 +54,9 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
                                           cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed, device=par.device)
     par.attach(model)
     if restore:
-        log(f"restored: {optimistic_restore(model, restore)}")
+        log(f"restored: {optimistic_restore(model, restore, step_names=(), optimizer_state=False)}")
+    if resume:
+        log(f"resumed: {optimistic_restore(model, resume, optimizer_state=True)}")
     if cnn is None:
         cnn = irv2.InceptionResnetV2()
         if cnn_variables is not None:
@@ -87,7 +93,9 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train-sents", required=True); ap.add_argument("--frames", required=True)
-    ap.add_argument("--vocab", required=True); ap.add_argument("--cnn-npz"); ap.add_argument("--restore")
+    ap.add_argument("--vocab", required=True); ap.add_argument("--cnn-npz")
+    ap.add_argument("--restore", help="variables only, from another run's checkpoint (e.g. the XE model)")
+    ap.add_argument("--resume", help="a checkpoint of this run: variables, Adam slots, update count, step counter")
     ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=16)
     ap.add_argument("--model-path", default="./new_e2e_models")
     ap.add_argument("--freeze-cnn", action="store_true", help="fix_e2e_tf_s2vt.py: no gradient into the CNN")
@@ -98,7 +106,7 @@ def main():
     if a.cnn_npz:
         with np.load(a.cnn_npz) as z:
             variables = {k: z[k] for k in z.files}
-    train(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, cnn_variables=variables, freeze_cnn=a.freeze_cnn)
+    train(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, resume=a.resume, cnn_variables=variables, freeze_cnn=a.freeze_cnn)
 
 
 if __name__ == "__main__":

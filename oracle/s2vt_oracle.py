@@ -322,12 +322,14 @@ def teacher_forced(p, d: Dims, video, caption, drop=None, keep=1.0):
     return logits
 
 
-def xe_loss(p, d: Dims, logits, caption, mask, smoothing=0.05, loss_weight=1.0, decay=5e-5, q1=True):
+def xe_loss(p, d: Dims, logits, caption, mask, smoothing=0.05, loss_weight=1.0, decay=5e-5, q1=True, decay_all=False):
     """build_model's loss (tf_s2vt.py:150-166).  q1=True reproduces TF-1.1
     tf.losses.softmax_cross_entropy returning the batch MEAN (a scalar) that is then multiplied
     by the mask column; q1=False is the conventional per-row masked CE.
     Weight decay: sum l2_loss(v) for variables whose name lacks 'bias' (Q3: LSTM `biases` are
-    skipped, encode_image_b / embed_word_b are decayed)."""
+    skipped, encode_image_b / embed_word_b are decayed).  decay_all: the multitask / e2e scripts' predicate
+    `if 'bias' or 'BatchNorm' not in v.name` (reinforce_multitask_e2e_attribute_s2vt.py:222, e2e_tf_s2vt.py:199) is always true:
+    every variable is decayed."""
     N, Tc, V = logits.shape
     mask = np.asarray(mask, np.float64)
     tot = 0.0
@@ -340,7 +342,7 @@ def xe_loss(p, d: Dims, logits, caption, mask, smoothing=0.05, loss_weight=1.0, 
             tot += loss_weight * (nll * mask[:, t]).sum()
     wd = 0.0
     for k, v in p.items():
-        if k in ("lstm1_b", "lstm2_b"):
+        if k in ("lstm1_b", "lstm2_b") and not decay_all:
             continue
         wd += 0.5 * float((v.astype(np.float64) ** 2).sum())
     return tot / mask.sum() + decay * wd
@@ -471,6 +473,12 @@ def attr_head(p, video, labels=None):
     y = _f32(labels); bce = np.empty_like(z)
     lib().orc_sigmoid_bce(_fp(z), _fp(y), _fp(bce), C.c_int64(z.size))
     return z, bce
+
+
+def attr_scores(p, video):
+    """evaluate_multilabel (reinforce_multitask_e2e_attribute_loss.py:621-624): scores = sigmoid(z), z as attr_head."""
+    z, _ = attr_head(p, video)
+    return det_sigmoid(z)
 
 
 def num_threads() -> int:

@@ -70,8 +70,9 @@ def teacher_forced(p, video, caption, drop=None, keep=1.0):
     return unroll(p, video, lambda t, _: bos if t == 0 else caption[:, t - 1], Tc, drop, keep)
 
 
-def xe_loss(p, logits, caption, mask, smoothing=0.05, loss_weight=1.0, decay=5e-5, q1=True):
-    """tf_s2vt.py:150-166 with TF-1.1 tf.losses.softmax_cross_entropy semantics."""
+def xe_loss(p, logits, caption, mask, smoothing=0.05, loss_weight=1.0, decay=5e-5, q1=True, decay_all=False):
+    """tf_s2vt.py:150-166 with TF-1.1 tf.losses.softmax_cross_entropy semantics.  decay_all: the always-true
+    predicate of reinforce_multitask_e2e_attribute_s2vt.py:222 / e2e_tf_s2vt.py:199 -- the LSTM biases are decayed too."""
     caption = torch.as_tensor(caption).long()
     mask = torch.as_tensor(mask).to(logits.dtype)
     N, Tc, V = logits.shape
@@ -83,7 +84,7 @@ def xe_loss(p, logits, caption, mask, smoothing=0.05, loss_weight=1.0, decay=5e-
         tot = (ce.mean(0, keepdim=True) * mask).sum()
     else:
         tot = (ce * mask).sum()
-    wd = sum(0.5 * (v ** 2).sum() for k, v in p.items() if k not in ("lstm1_b", "lstm2_b"))
+    wd = sum(0.5 * (v ** 2).sum() for k, v in p.items() if decay_all or k not in ("lstm1_b", "lstm2_b"))
     return loss_weight * tot / mask.sum() + decay * wd
 
 

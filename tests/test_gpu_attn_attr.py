@@ -84,3 +84,38 @@ def test_multitask_reinforce_gradients(gpu, oracle):
         ref = pt[n].grad.numpy()
         got = mdl.store.g[n].cpu().numpy()
         assert np.abs(got - ref).max() <= 2e-4 * (np.abs(ref).max() + 1e-12) + 1e-9, n
+
+
+@pytest.mark.parametrize("B,Tv,D,A", [(4, 5, 96, 40), (32, 5, 1536, 400), (3, 10, 130, 7)])
+def test_evaluate_multilabel_scores_bit_exact(gpu, oracle, B, Tv, D, A):
+    """evaluate_multilabel (reinforce_multitask_e2e_attribute_loss.py:606-626): scores = sigmoid(mean_t(video) . attr_W + attr_b),
+    through the C ABI (s2vt_attr_head_scores), the drop-in class (evaluate_multilabel -> Session.run) and the CNN wrapper (dropout off)."""
+    import torch
+    from s2vt_amd import e2e, model as M
+    rng = np.random.default_rng(B * 7 + A)
+    video = np.abs(rng.standard_normal((B, Tv, D)) * 0.5).astype(np.float32)
+    p = {"attr_W": rng.uniform(-.1, .1, (D, A)).astype(np.float32), "attr_b": rng.uniform(-.5, .5, A).astype(np.float32)}
+    ref = oracle.attr_scores(p, video)
+    assert ref.shape == (B, A) and ref.min() > 0 and ref.max() < 1 and abs(float(ref.mean()) - 0.5) < 0.2
+    z, sc = gpu.attr_head_scores(_dev(video), _dev(p["attr_W"]), _dev(p["attr_b"]))
+    assert np.array_equal(z.cpu().numpy(), oracle.attr_head(p, video)[0])
+    assert np.array_equal(sc.cpu().numpy(), ref)
+    mdl = M.Video_Caption_Generator(D, 50, 8, 16, B, 0, Tv, 4, label_dim=A, alpha=0.05)
+    mdl.store.load(p)
+    tf_video, tf_scores = mdl.evaluate_multilabel(0.5)
+    got = M.Session(mdl).run(tf_scores, feed_dict={tf_video: video})
+    assert got.shape == (B, A) and np.array_equal(got, ref)
+    assert np.array_equal(got > 0.5, oracle.attr_head(p, video)[0] > 0)             # the caller's threshold (sigmoid(z) > .5 <=> z > 0)
+    # through a CNN (e2e.EndToEnd.evaluate_multilabel): inference mode -- no feature dropout (:613-620) -- so frames whose
+    # "CNN" is the identity on [n, D] give the same scores
+    class Ident(torch.nn.Module):
+        def __init__(self):
+            super().__init__(); self.w = torch.nn.Parameter(torch.ones(1))
+        def forward(self, x):
+            return x.reshape(x.shape[0], -1) * self.w
+    tr = e2e.EndToEnd(mdl, Ident(), feature_keep=0.5)
+    got2 = tr.evaluate_multilabel(torch.as_tensor(video).reshape(B, Tv, D, 1, 1)).cpu().numpy()
+    assert np.array_equal(got2, ref)
+    mdl0 = M.Video_Caption_Generator(D, 50, 8, 16, B, 0, Tv, 4)
+    with pytest.raises(ValueError):
+        mdl0.attribute_scores(video)

@@ -108,8 +108,10 @@ def test_e2e_xe_step_wiring_vs_float64_autograd(gpu, oracle):
 
 
 def test_e2e_xe_step_with_frozen_cnn(gpu, oracle):
-    """fix_e2e_tf_s2vt.py (:120, :284): the CNN in the loop behind tf.stop_gradient -- its variables never move, the captioner sees the
-    same features and gets the gradients model.xe_update gives on them (weight decay on every captioner variable, its norm alone)."""
+    """fix_e2e_tf_s2vt.py (:120, :284): the CNN in the loop behind tf.stop_gradient.  No data gradient reaches it, but the script's
+    weight-decay term sums over every trainable variable (:199, always-true predicate) and compute_gradients(tf_loss) covers them
+    (:534-535): the CNN variables get decay_value * theta, count toward the joint clip norm and are moved by Adam.  The captioner sees
+    the same features and gets the gradients model.xe_update gives on them.  cnn_weight_decay=False is the literal freeze."""
     import torch
     import s2vt_amd
     from s2vt_amd import e2e, model as M
@@ -119,25 +121,41 @@ def test_e2e_xe_step_with_frozen_cnn(gpu, oracle):
     cap = rng.integers(0, 97, (B, 6)).astype(np.int32); cap[:, -2:] = 0
     mask = s2vt_amd.hostglue.masks_from_ids(cap)
     outs = []
-    for frozen in (True, False):
+    for mode in ("frozen", "literal", "captioner"):
         mdl = M.Video_Caption_Generator(24, 97, 12, 20, B, 0, 3, 6, dropout_rate=keep)
         mdl.store.load(p)
         tr = e2e.EndToEnd(mdl, _tiny_cnn(24), feature_keep=keep, seed=11)
         theta0 = tr.theta.clone()
-        if frozen:
+        if mode == "frozen":
             st = tr.xe_step(frames, cap, mask, lr=0.0, freeze_cnn=True)
+            # the CNN half of the gradient list is decay * theta, nothing else, and it is part of the ONE global norm
+            assert torch.equal(tr.grad, theta0 * mdl.decay_value)
+            cnn_sq = float((theta0.double() * mdl.decay_value).pow(2).sum())
+        elif mode == "literal":
+            st = tr.xe_step(frames, cap, mask, lr=0.0, freeze_cnn=True, cnn_weight_decay=False)
         else:                                                                                   # what the captioner alone does on the same features
             video, _ = tr.extract(frames, dropout=True, track=False)
             st = mdl.xe_update(video, cap, mask, 0.0, decay_all=True)
         outs.append((float(st.loss), float(st.grad_sumsq), mdl.store.grad[:mdl.store.numel].clone()))
-        if frozen:                                                                              # and a real step: the CNN half stays, the captioner moves
+        if mode != "captioner":                                                                 # and a real step
             w0 = mdl.store.p["lstm1_W"].clone()
-            tr.xe_step(frames, cap, mask, lr=1e-2, freeze_cnn=True)
-            assert torch.equal(tr.theta, theta0) and float(tr.grad.abs().max()) == 0.0
+            tr.xe_step(frames, cap, mask, lr=1e-2, freeze_cnn=True, cnn_weight_decay=(mode == "frozen"))
             assert not torch.equal(mdl.store.p["lstm1_W"], w0)
-    assert outs[0][0] == outs[1][0]                                                             # the same forward, bit for bit
-    assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * outs[1][1]                                    # (gradients: order-free reductions)
-    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-5 * float(outs[1][2].abs().max())
+            if mode == "frozen":
+                # TF-form Adam on the CNN half, two updates with g = decay * theta0 (the first at lr = 0 moved only the moments; the joint
+                # norm is far below the clip): its own update count (2), not the captioner's
+                g = theta0.double() * mdl.decay_value
+                m2, v2 = 0.19 * g, (1 - 0.999 ** 2) * g * g
+                want = theta0.double() - 1e-2 * (1 - 0.999 ** 2) ** 0.5 / (1 - 0.9 ** 2) * m2 / (v2.sqrt() + 1e-8)
+                assert tr.adam_t == 2 and float((tr.theta.double() - want).abs().max()) <= 1e-5 * 1e-2 + 1e-7
+                assert float((tr.theta - theta0).abs().max()) > 1e-3
+            else:
+                assert torch.equal(tr.theta, theta0) and float(tr.grad.abs().max()) == 0.0 and tr.adam_t == 0
+    assert outs[0][0] == outs[1][0] == outs[2][0]                                               # the same forward, bit for bit
+    assert abs(outs[1][1] - outs[2][1]) <= 1e-5 * outs[2][1]                                    # (gradients: order-free reductions)
+    assert abs(outs[0][1] - (outs[2][1] + cnn_sq)) <= 1e-5 * outs[0][1]                         # joint norm = captioner's + ||decay theta_cnn||^2
+    for k in (0, 1):
+        assert float((outs[k][2] - outs[2][2]).abs().max()) <= 1e-5 * float(outs[2][2].abs().max())
 
 
 def test_e2e_reinforce_multitask_step(gpu, oracle):

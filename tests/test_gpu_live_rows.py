@@ -214,3 +214,51 @@ def test_reinforce_update_at_320_rows_live_against_dense(gpu, oracle):
     assert torch.isfinite(g1).all()
     assert float((g0 - g1).abs().max()) <= 5e-5 * float(g0.abs().max())
     assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * max(1.0, abs(outs[0][0]))
+
+
+@pytest.mark.parametrize("defect", ["hole", "duplicate"])
+def test_invalid_live_list_is_refused_loudly(gpu, oracle, defect):
+    """The *_live contract: the list is time-major, strictly ascending, and every row's live steps are a PREFIX of the decode steps
+    (masks up to a first <eos>).  model.live_rows() checks that on the host; a C-API caller's device list is checked by the library's
+    row_order_kernel -- a list with a hole (an unmasked position behind a masked one), or a duplicate would
+    make LSTM2 stop a row too early and the gathered gradient products miss rows, silently.  It raises the sticky fault instead:
+    queued updates skip on the device, every later entry point refuses, until s2vt_chain_ack."""
+    import torch
+    import s2vt_amd
+    from s2vt_amd import hostglue
+    d, p, video, cap, vid, sid, N = _case(oracle, B=4, rep=3)
+    Tc = d.n_caption_lstm_step
+    mask = hostglue.masks_from_ids(cap)
+    steps = int(np.flatnonzero(mask.any(0))[-1]) + 1
+    on = mask[:, :steps] != 0
+    n0 = int(np.argmax(on.sum(1)))                                    # the longest row: has >= 3 live steps
+    assert on[n0].sum() >= 3
+    if defect == "hole":
+        on[n0, 1] = False                                             # steps {0, 2, ...}: position 2 sits behind a masked one
+    live = np.flatnonzero(on.T.reshape(-1)).astype(np.int32)
+    if defect == "duplicate":
+        live = np.sort(np.concatenate([live, live[:1]])).astype(np.int32)
+    gd = gpu.make_dims(d.dim_image, d.n_words, d.word_dim, d.lstm_dim, d.n_video_lstm_step, Tc)
+    dp_ = {k: _dev(v) for k, v in p.items()}
+    params = gpu.make_params(dp_)
+    assert not gpu.chain_fault()
+    before = gpu.chain_timeouts()
+    try:
+        gpu.teacher_forced_fwd(gd, params, _dev(video), _dev(cap), N, 1.0, 99, _dev(vid), _dev(sid), steps=steps, live=_dev(live))
+        torch.cuda.synchronize()
+        assert gpu.chain_fault() and gpu.chain_timeouts() == before + 1
+        with pytest.raises(s2vt_amd._lib.S2VTChainTimeout):          # later passes are refused while the fault is pending
+            gpu.teacher_forced_fwd(gd, params, _dev(video), _dev(cap), N, 1.0, 99, _dev(vid), _dev(sid), steps=steps)
+        theta = torch.ones(64, device="cuda"); g = torch.ones(64, device="cuda"); m = torch.zeros(64, device="cuda"); v = torch.zeros(64, device="cuda")
+        sq = torch.full((1,), 64.0, device="cuda")
+        with pytest.raises(s2vt_amd._lib.S2VTChainTimeout):
+            gpu.adam_tf(theta, g, m, v, sq, 5.0, 0.1, 1)
+        assert float(theta.min()) == 1.0                              # no update went through
+    finally:
+        gpu.chain_ack(False)
+    assert not gpu.chain_fault()
+    # a valid list on the same shapes runs as before
+    ok = np.flatnonzero((mask[:, :steps] != 0).T.reshape(-1)).astype(np.int32)
+    logits, _ = gpu.teacher_forced_fwd(gd, params, _dev(video), _dev(cap), N, 1.0, 99, _dev(vid), _dev(sid), steps=steps, live=_dev(ok))
+    torch.cuda.synchronize()
+    assert not gpu.chain_fault() and logits.shape[0] == ok.size

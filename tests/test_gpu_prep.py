@@ -23,8 +23,9 @@ def test_xe_prep_equals_the_tensor_expressions(gpu, N, Tc, q1):
     assert float(msum) == float(mask.sum())
 
 
-@pytest.mark.parametrize("B,rep,Tc,q1", [(32, 1, 20, True), (32, 1, 20, False), (5, 3, 7, True)])
-def test_mixed_prep_and_loss_equal_the_tensor_expressions(gpu, B, rep, Tc, q1):
+@pytest.mark.parametrize("lam", [0.5, 0.1, 0.7, 0.9])          # non-dyadic: 1 - lambda must be rounded ONCE, from the double
+@pytest.mark.parametrize("B,rep,Tc,q1", [(32, 1, 20, True), (32, 1, 20, False), (5, 3, 7, True), (6, 2, 9, True)])
+def test_mixed_prep_and_loss_equal_the_tensor_expressions(gpu, B, rep, Tc, q1, lam):
     import torch
     rng = np.random.default_rng(B * 10 + rep)
     Ns, N = B * rep, B * (rep + 1)
@@ -33,12 +34,14 @@ def test_mixed_prep_and_loss_equal_the_tensor_expressions(gpu, B, rep, Tc, q1):
     r = torch.as_tensor(rng.random(Ns).astype(np.float32) * 2).cuda(); b = torch.as_tensor(rng.random(Ns).astype(np.float32)).cuda()
     cap = torch.as_tensor(rng.integers(0, 1000, (Ns, Tc)).astype(np.int32)).cuda()
     gcap = torch.as_tensor(rng.integers(0, 1000, (B, Tc)).astype(np.int32)).cuda()
-    lam, lw, sm = 0.5, 1.0, 0.05
+    lw, sm = 1.0, 0.05
     coef, smooth, cap_all, tgt, sums = gpu.mixed_prep(mask, gmask, r, b, cap, gcap, lam, lw, q1, sm, float(B))
     s = torch.stack([mask.sum(), gmask.sum()])
-    coef_pg = mask * ((r - b) * (1.0 - lam))[:, None] / s[0]
+    one_minus = torch.full((), 1.0 - lam, dtype=torch.float32, device="cuda")       # model.mixed_update's data-parallel branch, verbatim
+    lam_t = torch.full((), lam, dtype=torch.float32, device="cuda")
+    coef_pg = mask * ((r - b) * one_minus)[:, None] / s[0]
     coef_xe = ((gmask.sum(0)[None, :] / float(B)).expand(B, -1) * lw) if q1 else (gmask * lw)
-    coef_xe = coef_xe * (lam / s[1])
+    coef_xe = coef_xe * (lam_t / s[1])
     ref = torch.cat([coef_pg, coef_xe], 0).t().contiguous().view(-1)
     assert torch.equal(sums, s)
     assert torch.equal(coef, ref)

@@ -205,11 +205,14 @@ def test_config0_xe_b4_full_dims_vs_float64_autograd(gpu, oracle):
     assert mdl.global_step == 1 and float((mdl.store.theta - before).abs().max()) > 5e-4
 
 
-def test_config3_multitask_b32_full_dims_vs_float64_autograd(gpu, oracle):
+@pytest.mark.parametrize("decay_all", [True, False])
+def test_config3_multitask_b32_full_dims_vs_float64_autograd(gpu, oracle, decay_all):
     """BASELINE configs[3], per-GPU shape (B=32 of the 256 over 8 GPUs, K=1, 400 attribute labels, full dimensions): the
     objective -(1-lambda) PG / sum(mask) + lambda XE(ground truth) + alpha BCE / (A B)
     (reinforce_multitask_e2e_attribute_s2vt.py:850, reinforce_multitask_e2e_attribute_loss.py:375-380, 957) through
-    mixed_update(true_labels=...): loss and every gradient, attribute head included, vs float64 autograd."""
+    mixed_update(true_labels=...): loss and every gradient, attribute head included, vs float64 autograd.
+    decay_all=True is the script's own weight decay (the predicate at reinforce_multitask_e2e_attribute_s2vt.py:222 is
+    always true, the LSTM biases -- non-zero here -- then carry lambda * 5e-5 * b in their gradients); False = tf_s2vt.py:163's filter."""
     import torch
     from s2vt_amd import hostglue, model as M
     from oracle import s2vt_torch as T
@@ -239,10 +242,15 @@ def test_config3_multitask_b32_full_dims_vs_float64_autograd(gpu, oracle):
     vt = torch.as_tensor(video).double()
     lg1 = T.teacher_forced(pt, vt, cap, drop1, keep)
     lg2 = T.teacher_forced(pt, vt, gcap, drop2, keep)
-    xe = T.xe_loss({k: v for k, v in pt.items()}, lg2, gcap, gmask, q1=True)        # decays every non-LSTM-bias variable, attr_W / attr_b included
+    xe = T.xe_loss({k: v for k, v in pt.items()}, lg2, gcap, gmask, q1=True, decay_all=decay_all)   # attr_W / attr_b are decayed either way
     ref = (1 - lam) * T.pg_loss(lg1, cap, mask, r, b) + lam * xe + alpha * T.attr_bce(pt, vt, labels, normalise=True)
     ref.backward()
-    st = mdl.mixed_update(dv, s, mask, r, b, gcap, gmask, lr=0.0, lambda_loss=lam, true_labels=labels)
-    wd = sum(0.5 * float((mdl.store.p[n].double() ** 2).sum()) for n in mdl.store.names if n not in M.UNDECAYED)
+    st = mdl.mixed_update(dv, s, mask, r, b, gcap, gmask, lr=0.0, lambda_loss=lam, true_labels=labels, decay_all=decay_all)
+    wd = sum(0.5 * float((mdl.store.p[n].double() ** 2).sum()) for n in mdl.store.names if decay_all or n not in M.UNDECAYED)
+    if decay_all:                           # the decay term is the ONLY source of the difference between the two modes' bias gradients
+        gb = mdl.store.g["lstm2_b"].cpu().numpy().astype(np.float64)
+        rb = pt["lstm2_b"].grad.numpy()
+        dec = lam * mdl.decay_value * mdl.store.p["lstm2_b"].cpu().numpy().astype(np.float64)
+        assert np.abs(dec).max() > 1e-7 and np.abs((gb - dec) - (rb - dec)).max() <= 2e-4 * np.abs(rb).max()
     loss = float(st.loss) + float(st.attr_loss) + lam * mdl.decay_value * wd
     _compare(mdl, st, loss, float(ref.detach()), {k: v.grad.numpy() for k, v in pt.items()})
