@@ -66,6 +66,11 @@ WORKLOADS = {
                              "reference) so that samples end after ~7 words, and the opt-in early-exit sampler (s2vt_sample_ex, S2VT_SAMPLE_STOP_AT_EOS) drops a row "
                              "from the decode loop at its first <eos> (ids up to it bit-identical; the reference samples all T_cap steps and masks afterwards); "
                              "tokens/s still counts K*B*T_cap nominal positions per step"),
+    "rl_ref": dict(B=256, K=8, tc=35, v=9972, seqfwd=lambda B, K: (4 * K + 1) * B, tokens=lambda B, K: K * B * 35,
+                   metric="sampled caption tokens/sec (REINFORCE step, the reference script's own default configuration)",
+                   desc="reinforcement_multisampling_tf_s2vt.py's OWN defaults (:505-517, :743-753): batch 256, K=8 samples per video, T_cap=35, "
+                        "|V|=9972 (msvd_vocabulary1.txt + <bos>/<eos>), T_vid=5, d=1536, E=500, H=1000 -- 2304 sampler rows and N=2048 update rows "
+                        "(beyond every persistent form: per-step recurrences), 2.9 GB of logits per pass; synthetic rewards"),
     "xe": dict(B=64, K=0, seqfwd=lambda B, K: 3 * B, tokens=lambda B, K: B * TC,
                metric="caption tokens/sec (XE train step)",
                desc="tf_s2vt XE train step (BASELINE configs[1]): B=64, T_vid=5, T_cap=20, d=1536, E=500, H=1000, |V|=12000; "
@@ -166,6 +171,30 @@ def stored_traffic(kernel_class, name, workload="rl"):
     return None, None
 
 
+def stored_sq(kernel_class, name, workload="rl"):
+    """SQ-counter figures of (class:tile) from the newest stamped summary under profiles/ (<tag>_sq_counters[_<workload>].json, written by
+    tools/sq_to_json.py from separate rocprofv3 --pmc passes, tools/collect_round.sh) -- or None when there is none for THIS build of the
+    kernels.  mfma_busy_pct = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x the dispatch's cycles, GRBM_GUI_ACTIVE / 8): the share of the
+    chip's matrix-pipe cycles that issued MFMAs, i.e. MFMA utilisation against the peak at the clock the launch ran at."""
+    prof = os.path.join(ROOT, "profiles")
+    sig = kernel_signature()
+    sfx = "_sq_counters.json" if workload == "rl" else f"_sq_counters_{workload}.json"
+    for f in sorted((x for x in os.listdir(prof) if x.endswith(sfx)), reverse=True):
+        try:
+            d = json.load(open(os.path.join(prof, f)))
+        except Exception:
+            continue
+        if d.get("_stamp", {}).get("kernel_signature") != sig:
+            continue
+        ent = d.get(f"{kernel_class}:{name}")
+        if ent:
+            return ent, f
+    return None, None
+
+
+PEAK_HBM_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
 def cpu_baseline():
     """The reference-structured step (K sampler passes + greedy pass + fwd/bwd at K*B + clip + Adam,
     reward excluded) on the host cores with torch-CPU fp32 -- oracle/s2vt_torch.py ("port").
@@ -262,6 +291,7 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
         return make_e2e_step(workload, mdl, dev, rank, B, K, info if info is not None else {})
     g = torch.Generator().manual_seed(1234 + rank)                                        # per-rank data shard
     tv = WORKLOADS[workload].get("tv", TV)
+    TC, V = WORKLOADS[workload].get("tc", globals()["TC"]), WORKLOADS[workload].get("v", globals()["V"])
     video = (torch.randn(B, tv, D, generator=g) * 0.5).abs().to(dev)                      # post-ReLU IRv2 pool features
     rewards = (torch.rand(max(K, 1) * B, generator=g) * 2).to(dev)
     baseline = (torch.rand(B, generator=g) * 2).repeat(max(K, 1)).to(dev)
@@ -270,7 +300,7 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
         is_eos = (s == 0)
         return ((torch.cumsum(is_eos.int(), 1) - is_eos.int()) == 0).float()   # 1 up to and incl. first <eos>
 
-    if workload == "rl":
+    if workload in ("rl", "rl_ref"):
         def step(i):
             s, _greedy = mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
             return mdl.reinforce_update(video, s, None, rewards, baseline, lr=1e-6, clip_norm=5.0, video_base=rank * B,      # mask None: PG mask from the ids, in the library
@@ -370,15 +400,39 @@ def main():
     s2vt_amd.lib()                                   # no fallback: raises if the HIP library is missing
 
     multitask = args.workload == "multitask"
+    tc_w, v_w = wl.get("tc", TC), wl.get("v", V)
     if args.workload.startswith("attention"):
         from s2vt_amd import attention as A
         mdl = A.Attention_Caption_Generator(D, V, H, B, wl["tv"], TC, 0.9, device=dev, seed=1234)
     else:
-        mdl = M.Video_Caption_Generator(D, V, E, H, B, 0, TV, TC, device=dev, seed=1234, multisample=max(K, 1),
+        mdl = M.Video_Caption_Generator(D, v_w, E, H, B, 0, TV, tc_w, device=dev, seed=1234, multisample=max(K, 1),
                                         label_dim=400 if multitask else 0, alpha=0.05 if multitask else 0.0)   # identical replicas
     mdl.world_size, mdl.rank = world, rank
     info = {}
     step = make_step(args.workload, mdl, dev, rank, B, K, info)
+
+    # Data parallel: let the run choose between the blocking bucket exchange and the overlapped slices (S2VT_DP_OVERLAP / model.dp_overlap)
+    # by itself -- the driver runs one fixed command.  3 steps each way, timed as the timed region is (barrier + synchronize, MAX over
+    # ranks, so every rank takes the same decision); the replicas must not drift in either mode (0.0 exactly).  An explicit S2VT_DP_OVERLAP
+    # in the environment is respected and not probed.
+    probe = None
+    if world > 1 and hasattr(mdl, "dp_overlap") and args.workload in ("rl", "rl_ref", "rl_msvd", "rl_msvd_eos", "xe") and "S2VT_DP_OVERLAP" not in os.environ:
+        probe = {}
+        it = 0
+        for mode in (False, True):
+            mdl.dp_overlap = mode
+            step(1000 + it); it += 1                                  # one untimed step in this mode (first-use allocations, communicator warm-up)
+            dist.barrier(); torch.cuda.synchronize()
+            t0p = time.perf_counter()
+            for _ in range(3):
+                step(1000 + it); it += 1
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            tp = torch.tensor([(time.perf_counter() - t0p) / 3 * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            probe["on" if mode else "off"] = round(float(tp), 3)
+            d_ = dp.replica_drift(mdl.store.theta)
+            assert d_ == 0.0, f"replicas drifted by {d_} with dp_overlap={mode}"
+        mdl.dp_overlap = probe["on"] < probe["off"]
 
     # Warm-up: every contraction launch is bracketed by HIP events (in-library, on the launching stream) to get the
     # per-kernel table and find the dominant kernel; inside the timed region only THAT kernel keeps its events
@@ -435,6 +489,8 @@ def main():
         tc_eff = info.get("active_steps", TC) if args.workload in ("xe", "attention", "attention32") else TC
         if "tv" in wl:
             f_seq = 2.0 * wl["tv"] * D * H + 2.0 * wl["tv"] * H * H + tc_eff * (f_att_seq(wl["tv"]) - 2.0 * wl["tv"] * D * H - 2.0 * wl["tv"] * H * H) / TC
+        elif "tc" in wl:          # another T_cap / |V|: the decode step's vocabulary term 2 H |V| and the step count follow the workload
+            f_seq = 7.68e6 + 5 * 28e6 + tc_w * (28e6 + 2.0 * H * v_w)
         else:
             f_seq = 7.68e6 + 5 * 28e6 + tc_eff * 52e6
         flops_step = f_seq * wl["seqfwd"](B, K)
@@ -454,10 +510,18 @@ def main():
             executed = sum(r["total_flops"] for r in warm_rows) / max(args.warmup, 1) if warm_rows else None
             if args.workload == "rl_msvd_eos":
                 executed = None        # (the launch profiler prices a live-row launch at its full row count: only the device knows how many rows ran)
+            avg_us = dom["total_ms"] * 1e3 / dom["launches"]
+            sq, sq_src = stored_sq(dom["kernel_class"], dom["name"], args.workload)
+            # north_star: "rocprof HBM GB/s and MFMA utilisation reported against peak" -- both for the dominant kernel, from the stamped
+            # counter summaries of THIS build (null when stale): HBM-side bytes per launch / this run's average launch time, and the share
+            # of the chip's matrix-pipe cycles that issued MFMAs
+            hbm_gbps = round(traffic / (avg_us * 1e-6) / 1e9, 1) if traffic else None
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "hbm_gbps": hbm_gbps, "hbm_peak_gbps": PEAK_HBM_GBPS, "hbm_frac": round(hbm_gbps / PEAK_HBM_GBPS, 4) if hbm_gbps else None,
+                    "mfma_busy_pct": sq["mfma_busy_pct"] if sq else None, "mfma_busy_source": sq_src,
                     "kernel": f"{cls}, tile {dom['name']}", "launches": dom["launches"],
-                    "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
+                    "avg_launch_us": round(avg_us, 2),
                     "share_of_step": round(dom["total_ms"] / (dt * 1e3), 3),
                     "algorithmic_flops_per_step": flops_step if dense_defined else None,
                     "whole_step_frac": round(flops_step * args.steps / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if dense_defined else None,
@@ -471,7 +535,7 @@ def main():
                "step_ms": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "how": "HIP events per step on the launching stream"},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": wl["desc"], "global_batch": B * world, "samples_per_video": K, "parallelism": f"dp{world}",
-                          "dp_overlap": bool(mdl.dp_overlap), "loss": float(st.loss),
+                          "dp_overlap": bool(getattr(mdl, "dp_overlap", False)), "dp_overlap_probe_ms": probe, "loss": float(st.loss),
                           "persistent_recurrence_timeouts": ops.chain_timeouts()},      # grid-wide waits that gave up: must be 0
                "roofline": roof}
         if world > 1:

@@ -146,6 +146,77 @@ def test_attention_fullsize_bit_exact_and_gradients(gpu, oracle, Tv):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
 
 
+def _hold(gpu, on):
+    import contextlib
+    return gpu.chain_hold() if on else contextlib.nullcontext()
+
+
+@pytest.mark.parametrize("hold", [False, True])
+def test_attention32_benched_shape_forward_bit_exact(gpu, oracle, hold):
+    """The shape `bench.py --workload attention32` times and profiles -- the '32img' model of original_attention.py:287-290 at B = 64,
+    Tv = 32, H = 1000, Tc = 20, |V| = 12000: frame chunking at 20 frames per chunk, 64 attention workgroups -- logits, alphas and greedy
+    ids array_equal vs the C oracle, in the persistent form (attn_chain.hip) and in the per-step launches (`chain_hold`)."""
+    f = dict(FULL)
+    Tv = 32
+    d, p, m, video, cap, rng = _setup(oracle, f["D"], f["V"], f["H"], Tv, f["Tc"], f["B"], 33)
+    B, Tc, H = f["B"], f["Tc"], f["H"]
+    ln = 1 + np.minimum(rng.poisson(6, B), Tc - 2)
+    for i in range(B):
+        cap[i, ln[i]:] = 0
+    keep, seed = 0.9, m.dropout_seed
+    drop = _drop(oracle, seed, B, H, Tc, keep)
+    ref_l, ref_a, _ = oracle.attention_forward(p, d, video, cap, drop, keep)
+    assert ref_a.shape[1] == Tv and (ref_a[:, :8, :].sum(1) < m.m).any()        # the regulariser's hinge is open on this shape
+    gpu.prof_filter(-1, -1); gpu.prof_enable(True)
+    with _hold(gpu, hold):
+        lg, al, _ = m.forward(video, cap, keep=keep, seed=seed)
+        _, ga, ids = m.forward(video, None, greedy=True)
+    import torch
+    torch.cuda.synchronize()
+    classes = {r["kernel_class"] for r in gpu.prof_collect()}; gpu.prof_enable(False)
+    assert (9 in classes) != hold, classes                                         # the form this case is about really ran
+    assert np.array_equal(al.cpu().numpy(), ref_a)
+    assert np.array_equal(lg.cpu().numpy(), ref_l)
+    _, ref_ga, ref_ids = oracle.attention_forward(p, d, video, None, greedy=True)
+    assert np.array_equal(ids.cpu().numpy(), ref_ids) and np.array_equal(ga.cpu().numpy(), ref_ga)
+    assert gpu.chain_timeouts() == 0
+
+
+def test_attention32_benched_rows_gradients_vs_float64_autograd(gpu, oracle):
+    """Gradients at the benched shape's rows, frames and width -- B = 64, Tv = 32, H = 1000 (|V| = 2000, Tc = 6 bound the float64 autograd
+    pass): the backward recurrence's 20-frames-per-chunk path and attn_dpdv_kernel run at 64 rows.  Loss (regulariser live) and every gradient
+    vs float64 autograd in the persistent form; the per-step form (`chain_hold`) gives the same update up to the order-free reductions."""
+    import torch
+    from s2vt_amd import hostglue
+    D, V, H, Tv, Tc, B, keep = 1536, 2000, 1000, 32, 6, 64, 0.9
+    d, p, m, video, cap, rng = _setup(oracle, D, V, H, Tv, Tc, B, 34)
+    ln = 1 + np.minimum(rng.poisson(3, B), Tc - 2)
+    for i in range(B):
+        cap[i, ln[i]:] = 0
+    mask = hostglue.masks_from_ids(cap)
+    seed = m.dropout_seed
+    ref_loss, ref_g, alphas = _ref_loss_grads(oracle, p, video, cap, mask, _drop(oracle, seed, B, H, Tc, keep), keep, m.beta, m.m)
+    assert (alphas[:, :8, :].sum(1) < m.m).any(), "the test must exercise the open hinge"
+    gpu.prof_filter(-1, -1); gpu.prof_enable(True)
+    st = m.xe_update(video, cap, mask, lr=0.0, keep=keep, active_steps=None)
+    torch.cuda.synchronize()
+    classes = {r["kernel_class"] for r in gpu.prof_collect()}; gpu.prof_enable(False)
+    assert 9 in classes and 10 in classes, classes
+    assert abs(float(st.loss) - ref_loss) <= 1e-3 * max(1.0, abs(ref_loss))
+    _check_grads(m, ref_g)
+    gn = sum(float((g ** 2).sum()) for g in ref_g.values())
+    assert abs(float(st.grad_sumsq) - gn) <= 1e-3 * gn
+    g_pers = {k: m.store.g[k].clone() for k in m.store.names}
+    m.global_step = 0
+    with gpu.chain_hold():
+        st2 = m.xe_update(video, cap, mask, lr=0.0, keep=keep, active_steps=None)
+    assert abs(float(st2.loss) - float(st.loss)) <= 1e-6 * abs(float(st.loss))
+    for k in m.store.names:
+        a, b = m.store.g[k], g_pers[k]
+        assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-10, k
+    assert gpu.chain_timeouts() == 0
+
+
 def test_attention_replay_train_statements(gpu, oracle):
     """original_attention.py train() (:403-470): model, build_model, exponential_decay + Adam + clip 10 -> train_op, build_sampler,
     sess.run([train_op, tf_loss], feed_dict), sess.run(learning_rate), sess.run(greedy_captions, feed_dict); test() (:539):
