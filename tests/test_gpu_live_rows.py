@@ -216,16 +216,16 @@ def test_reinforce_update_at_320_rows_live_against_dense(gpu, oracle):
     assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * max(1.0, abs(outs[0][0]))
 
 
-@pytest.mark.parametrize("defect", ["hole", "duplicate"])
-def test_invalid_live_list_is_refused_loudly(gpu, oracle, defect):
-    """The *_live contract: the list is time-major, strictly ascending, and every row's live steps are a PREFIX of the decode steps
-    (masks up to a first <eos>).  model.live_rows() checks that on the host; a C-API caller's device list is checked by the library's
-    row_order_kernel -- a list with a hole (an unmasked position behind a masked one), or a duplicate would
-    make LSTM2 stop a row too early and the gathered gradient products miss rows, silently.  It raises the sticky fault instead:
-    queued updates skip on the device, every later entry point refuses, until s2vt_chain_ack."""
-    import torch
-    import s2vt_amd
-    from s2vt_amd import hostglue
+_INVALID_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["S2VT_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["S2VT_ROOT"], "tests"))
+import numpy as np, torch, pytest
+import s2vt_amd
+from s2vt_amd import hostglue, ops as gpu
+from oracle import s2vt_oracle as oracle
+from test_gpu_live_rows import _case, _dev
+for defect in ("hole", "duplicate"):
     d, p, video, cap, vid, sid, N = _case(oracle, B=4, rep=3)
     Tc = d.n_caption_lstm_step
     mask = hostglue.masks_from_ids(cap)
@@ -246,7 +246,7 @@ def test_invalid_live_list_is_refused_loudly(gpu, oracle, defect):
     try:
         gpu.teacher_forced_fwd(gd, params, _dev(video), _dev(cap), N, 1.0, 99, _dev(vid), _dev(sid), steps=steps, live=_dev(live))
         torch.cuda.synchronize()
-        assert gpu.chain_fault() and gpu.chain_timeouts() == before + 1
+        assert gpu.chain_fault() and gpu.chain_timeouts() == before + 1, defect
         with pytest.raises(s2vt_amd._lib.S2VTChainTimeout):          # later passes are refused while the fault is pending
             gpu.teacher_forced_fwd(gd, params, _dev(video), _dev(cap), N, 1.0, 99, _dev(vid), _dev(sid), steps=steps)
         theta = torch.ones(64, device="cuda"); g = torch.ones(64, device="cuda"); m = torch.zeros(64, device="cuda"); v = torch.zeros(64, device="cuda")
@@ -262,3 +262,20 @@ def test_invalid_live_list_is_refused_loudly(gpu, oracle, defect):
     logits, _ = gpu.teacher_forced_fwd(gd, params, _dev(video), _dev(cap), N, 1.0, 99, _dev(vid), _dev(sid), steps=steps, live=_dev(ok))
     torch.cuda.synchronize()
     assert not gpu.chain_fault() and logits.shape[0] == ok.size
+print("child ok")
+'''
+
+
+def test_invalid_live_list_is_refused_loudly(gpu):
+    """The *_live contract: the list is time-major, strictly ascending, and every row's live steps are a PREFIX of the decode steps
+    (masks up to a first <eos>).  model.live_rows() checks that on the host; a C-API caller's device list is checked by the library's
+    row_order_kernel -- a list with a hole (an unmasked position behind a masked one) or a duplicate would make LSTM2 stop a row too
+    early and the gathered gradient products miss rows, silently.  It raises the sticky fault instead: queued updates skip on the device,
+    every later entry point refuses, until s2vt_chain_ack.  (In a child process: the fault counter is process-wide and other tests assert
+    that it reads 0.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _INVALID_CHILD], env=dict(os.environ, S2VT_ROOT=root), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "child ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
