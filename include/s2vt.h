@@ -74,6 +74,8 @@ typedef struct s2vt_params {
 
 /* ---- library info / errors --------------------------------------------------------------- */
 int s2vt_version(void);
+/* bit 0: built with EXPERIMENTAL=1 (the opt-in decode-loop experiments decode4.hip / decode_loop.hip are linked in). */
+int s2vt_build_flags(void);
 int s2vt_last_hip_error(void);
 /* Up to 8 device buffers set to zero by ONE launch (4-byte aligned, byte counts multiples of 4): the gradient bucket and the
  * other buffers a step must find zeroed -- each hipMemsetAsync / tensor-library fill is a ~5-20 us launch of its own. */

@@ -62,6 +62,7 @@ _AP = C.POINTER(AttnParams)
 # name -> (restype, argtypes); every symbol include/s2vt.h declares
 SIGNATURES = {
     "s2vt_version": (C.c_int, []),
+    "s2vt_build_flags": (C.c_int, []),
     "s2vt_last_hip_error": (C.c_int, []),
     "s2vt_zero_regions": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _i32, _vp]),
     "s2vt_error_string": (C.c_char_p, [C.c_int]),

@@ -16,8 +16,9 @@
 //     fragment-order image;
 //   * (Q) is one 16 x 16 tile per workgroup -- its own row tile and units: the K = H reduction is cut over the four waves (order-
 //     free), each wave's quarter of Wa[16j .., :] in 4 NG / 4 registers per lane;
-//   * hand-offs per iteration: dz images (all, sharded counter), the 4-workgroup exchange (cluster counter), dctx (all, a second
-//     sharded counter), dhWa (attention workgroups); the sc1 form of chain_common.h.
+//   * hand-offs per iteration, three in series: dz images (all, sharded counter); the partial tiles of (M) -- ONE arrival for the 4-workgroup
+//     exchange (cluster counter: dh_rec) and for the attention role (a second sharded counter), which sums the four gate partials of the
+//     context block itself; dhWa (attention workgroups); the sc1 form of chain_common.h.
 // The embedding block of dz @ W3^T does not feed the recurrence: the caller computes it for all steps at once afterwards.
 // Gradients are order-free fp32 (checked against float64 autograd, tests/test_gpu_attention_model.py).
 #include <hip/hip_runtime.h>
@@ -250,19 +251,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_wave_barrier();
                 bstore16_sc1(rsEx, __builtin_bit_cast(u32x4v, row), (int)(((exc + (size_t)gate * 8 + (size_t)pwave * 2 + c) * 256 + lane * 4) * 4), 0);
             }
-            gs.arrive_one(ccount, tid);
-            gs.wait_one(ccount, 4u * (it + 1u), pwave, lane);
-            float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s0 += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * 8 + gate * 2) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                s1 += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * 8 + gate * 2 + 1) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            // ONE arrival serves both consumers of the partial tiles (round 5: three hand-offs per iteration in series instead of four): the
+            // unit group's exchange (dh_rec, below) and the attention role, which used to wait for the exchanged SUM of the context block
+            // -- exchange, sum, store, drain, a second arrival -- and now sums the four gate partials itself, in the same gate order
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(gd.sync + (blockIdx.x & (kShards - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(ccount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            AB_STAMP(5);                                       // partial tiles published (exchange + dctx arrival)
+            gs.wait_one(ccount, 4u * (it + 1u), pwave, lane);
+            float s0 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                s0 += __uint_as_float(__hip_atomic_load((const gu32*)(g.ex + (exc + (size_t)q * 8 + gate * 2) * 256 + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             AB_STAMP(4);                                       // 4-workgroup exchange
             dh_rec = s0;                                       // gradient w.r.t. h_{t-1} through step t's recurrent rows
-            if (pok) __hip_atomic_store((gu32*)(g.dctxs + (size_t)pm * H + pu), __float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gd.arrive(tid);
-            AB_STAMP(5);                                       // dctx published
         }
         // ---- (A) attention backward of step t for batch row brow (attn.hip::attn_bwd_kernel's arithmetic)
         if (roleA) {
@@ -278,8 +283,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (tid < Tv) all_[tid] = g.alpha[((size_t)t * Tv + tid) * M + brow];
             gd.wait_all(it, pwave, lane);
             {
-                const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(g.dctxs + (size_t)brow * H, 0, H * 4, 0x00020000);
-                const f32x4 v = bload16_sc1(rsD, q4 * 16, 0);
+                // the recurrence's part of d(ctx_t) of this row: the context-block partials of the four gate workgroups of unit group
+                // q4 / 4, row brow of row tile brow / 16, summed in gate order from +0 (the sum the exchange used to publish)
+                const int jx = q4 >> 2;
+                f32x4 pq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = qok ? (int)(((((size_t)jx * 4 + q) * 8 + (size_t)(brow >> 4) * 2 + 1) * 256 + (size_t)(brow & 15) * 16 + (size_t)(q4 & 3) * 4) * 4)
+                                        : (int)0x80000000u;
+                    pq[q] = bload16_sc1(rsEx, off, 0);
+                }
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[0] += pq[q][0]; v[1] += pq[q][1]; v[2] += pq[q][2]; v[3] += pq[q][3]; }
                 dense[0] += v[0]; dense[1] += v[1]; dense[2] += v[2]; dense[3] += v[3];
             }
             if (aregs) {

@@ -1088,6 +1088,34 @@ bool chain_operands_ok(const float* W, int ldw, const float* abuf)
 }
 
 
+// ---- gated overlap (internal.h ChainGate)
+namespace {
+__global__ void chain_gate_kernel(const unsigned* sync, unsigned arrivals, unsigned limit)
+{
+    if (threadIdx.x != 0) return;
+    for (unsigned spins = 0; spins < limit; ++spins) {
+        unsigned sum = 0;
+        for (int s = 0; s < kShards; ++s) sum += __hip_atomic_load((const gu32*)(sync + s * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sum >= arrivals) break;                            // every workgroup of the grid has run up to its first hand-off: all resident
+        __builtin_amdgcn_s_sleep(8);
+    }                                                          // (a grid that never arrives -- a failed launch -- costs ~10 ms here, nothing else)
+}
+thread_local ChainGate* t_gate = nullptr;
+}  // namespace
+void chain_gate_arm(ChainGate* g) { t_gate = g; if (g) g->fired = false; }
+hipError_t chain_gate_zeroed(hipStream_t st) { return t_gate ? hipEventRecord(t_gate->ev, st) : hipSuccess; }
+hipError_t chain_gate_launched(const unsigned* sync, unsigned arrivals)
+{
+    ChainGate* g = t_gate;
+    if (!g) return hipSuccess;
+    t_gate = nullptr;
+    hipError_t e = hipStreamWaitEvent(g->side, g->ev, 0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chain_gate_kernel, dim3(1), dim3(64), 0, g->side, sync, arrivals, 1u << 15);
+    g->fired = true;
+    return hipGetLastError();
+}
+
 // ---- the launch state chain_bwd.hip shares (chain_common.h)
 bool chain_host(ChainHost* out)
 {

@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     constexpr int ZS = 20;
     constexpr int PS = NC * TMW;                               // (row tile, column tile) slots one workgroup finishes per step, at most
+#ifdef S2VT_BCHAIN_PRIO
+    __builtin_amdgcn_s_setprio(S2VT_BCHAIN_PRIO);              // (dev) beside a co-resident contraction (train.hip, gated overlap): issue the recurrence's instructions first
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;                                          // [NG][NC][64 lanes][4]: B fragments of this workgroup's slice
     const int tid = threadIdx.x, lane = tid & 63;
@@ -916,6 +919,8 @@ hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
     z.add(a.sync, syncb); z.add(a.img, imgf * 4);              // (rows >= M and k >= H of the images must read as zeros)
     hipError_t e = launch_zero_regions(z, st);
     if (e != hipSuccess) return e;
+    e = chain_gate_zeroed(st);                                 // (gated overlap: a side stream may poll the counters from here on)
+    if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((k.ncg + 7) / 8 * 32 * nc_));
     const double flops = 2.0 * a.M * (double)a.H * 4.0 * a.H * (a.T - 1);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -932,6 +937,8 @@ hipError_t launch_lstm_bwd_chain(const BwdChainLaunch& a, hipStream_t st)
         prof_record(6, pci, live ? c.name_live : c.name, live ? 0.0 : flops, e0, e1);     // (live rows: the executed count lives on the device -- no rate is claimed)
     }
     e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = chain_gate_launched(a.sync, 4u * (unsigned)nc_ * (unsigned)k.ncg);     // every active workgroup arrives once per iteration
     if (e != hipSuccess) return e;
     return order.after(st, dev);
 }

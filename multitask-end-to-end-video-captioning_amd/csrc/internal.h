@@ -138,6 +138,17 @@ bool chain_fault();                                    // a timeout has happened
 const unsigned* chain_fault_word();                    // device word of the current device (1 = fault), NULL when the persistent form is unavailable
 hipError_t chain_ack(bool disable);                    // acknowledge (device idle!); disable: per-step launches for the rest of the process
 
+// ---- gated overlap (train.hip, S2VT_OVERLAP=2): a side stream that is released once a persistent grid is RESIDENT.  A persistent recurrence at
+// <= 256 rows holds one wave per SIMD at <= 380 VGPRs and spends half its time in hand-offs: an independent weight-gradient contraction can
+// share the CUs with it -- provided the recurrence's workgroups got their slots first (a contraction that fills the chip first leaves no
+// room for them: the grid would be partly resident and spin until the contraction drains).  The next persistent launch of the arming thread
+// records g->ev behind its counter-zeroing kernel and, behind the grid's launch, queues on g->side {wait for g->ev; a one-wave kernel that
+// polls the grid's first arrival until every workgroup has arrived, bounded}.  What the caller then launches on g->side starts beside the grid.
+struct ChainGate { hipStream_t side; hipEvent_t ev; bool fired; };
+void chain_gate_arm(ChainGate* g);                   // nullptr disarms; consumed (fired = true) by the next persistent launch of this thread
+hipError_t chain_gate_zeroed(hipStream_t st);        // (launchers) behind the zeroing kernel
+hipError_t chain_gate_launched(const unsigned* sync, unsigned arrivals);   // (launchers) behind the grid's launch; arrivals = workgroups arriving at the first hand-off
+
 // ---- the backward recurrence of one cell in one persistent launch (chain.hip): dZ[t] for t = T-1 .. 0
 struct BwdChainLaunch {
     const float* W; int ldw; int kw0;                  // cell matrix [*, 4H]; the recurrent rows start at kw0

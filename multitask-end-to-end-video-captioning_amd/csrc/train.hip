@@ -4,6 +4,8 @@
 // global-norm clip + TF-form Adam.
 #include <hip/hip_runtime.h>
 
+#include <functional>
+
 #include <cstdlib>
 
 #include "api_util.h"
@@ -150,6 +152,7 @@ struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ok = false;
+    int mode = 0;          // 1: S2VT_OVERLAP=1 (ungated, below); 2: gated overlap with the persistent backward recurrences (round 5)
 };
 SideStream& side_stream()
 {
@@ -158,8 +161,13 @@ SideStream& side_stream()
         // Opt-in (S2VT_OVERLAP=1).  Measured on MI355X: the two streams do run concurrently, but the kernels
         // only slow each other down (TN 724 -> 1462 us, slab GEMM 28 -> 46 us per launch) for a net 0.1 ms of
         // 15.6, and per-launch durations stop meaning anything for the roofline, so one stream is the default.
+        // Mode 2 (round 5, the default; S2VT_OVERLAP=0 switches it off): the weight-gradient contractions that do not feed a recurrence run
+        // on the side stream BESIDE the persistent backward recurrence they are independent of -- dWout beside LSTM2's, LSTM2's three beside
+        // LSTM1's -- released by a gate once the recurrence's grid is resident (internal.h ChainGate).  A persistent recurrence at <= 256 rows
+        // is one wave per SIMD at <= 380 VGPRs that waits in hand-offs half the time; the contraction fills the other half of the pipe.
         const char* on = getenv("S2VT_OVERLAP");
-        if (!(on && on[0] == '1')) return t;
+        t.mode = on ? atoi(on) : 2;
+        if (t.mode < 1 || t.mode > 2) { t.mode = 0; return t; }
         if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return t;
         for (auto& e : t.ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return t;
@@ -555,10 +563,19 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
     const bool do_vocab = phase == 0 || phase == 1, do_l2 = phase == 0 || phase == 2 || phase == 3,
                do_rest = phase == 0 || phase == 2 || phase == 4;
     SideStream& ss = side_stream();
-    hipStream_t sd = (ss.ok && phase == 0) ? ss.s : st;      // weight-gradient work that may run beside a recurrence (whole-pass calls only)
+    // gated overlap (mode 2): only beside recurrences that run as ONE-part persistent grids (<= 256 rows: room for a second wave per SIMD)
+    const bool gate2 = ss.ok && ss.mode == 2 && phase == 0 && N <= 256 && bwd_chain_auto(N, H) && !(reinterpret_cast<uintptr_t>(p->lstm2_W) & 15);
+    // (LSTM1's recurrence is gated only where LSTM2's is: at N > 256 rows -- the REINFORCE step's 320 -- LSTM2's three contractions are 0.6 ms
+    //  each and lose more beside the 64-row recurrence than it gains: 12.26 -> 12.28 ms measured, profiles/r05_overlap_ab.jsonl)
+    const bool gate1 = ss.ok && ss.mode == 2 && phase == 0 && N <= 256 && B <= 256 && bwd_chain_auto(B, H) && !(reinterpret_cast<uintptr_t>(p->lstm1_W) & 15);
+    const bool side_on = ss.ok && phase == 0 && (ss.mode == 1 || gate1 || gate2);
+    hipStream_t sd = side_on ? ss.s : st;                    // weight-gradient work that may run beside a recurrence (whole-pass calls only)
+    ChainGate gate{ss.s, ss.ev[3], false};
+    TnArgs dwout;                                            // (mode 2: the vocabulary projection's weight gradient is launched behind LSTM2's recurrence)
+    bool dwout_deferred = false;
     if (do_vocab) {
         // transposed weight copy for the data-gradient product + the vocab projection
-        hipStream_t sv = phase == 0 ? sd : st;              // (phase 1: its gradients must be final on the caller's stream)
+        hipStream_t sv = (phase == 0 && ss.ok && ss.mode == 1) ? sd : st;     // (phase 1: its gradients must be final on the caller's stream)
         if (sv != st) HIP_TRY(fork_to(st, sv, ss.ev[0]));
         // rows of the vocabulary-side products: every unrolled (step, row) pair, or the LIVE ones only (dlogits is then
         // [n_live, V], row r belonging to row live_rows[r] of the unroll; the masked rows' dlogits are exact zeros in the full
@@ -567,7 +584,8 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         TnArgs a{w.O2 + (size_t)Tv * NH, live_rows, H, dlogits, V, grads->embed_word_W, V, R, H, V, 1};
         a.gather_rows = live_rows ? Tc * N : 0;
         a.colsum = grads->embed_word_b;                     // the bias gradient rides in the same pass over dlogits
-        HIP_TRY(launch_gemm_tn(a, sv));
+        if (gate2 && do_l2) { dwout = a; dwout_deferred = true; }
+        else HIP_TRY(launch_gemm_tn(a, sv));
         float* const dO2t = live_rows ? w.dO2p : w.dO2;     // where the product lands: packed rows are scattered afterwards
         int s2 = w.dO2s ? do2_splits(R, H, V) : 1;
         if ((size_t)s2 * R > w.dO2s_rows) s2 = 1;            // (a live-row count between two step counts the carve did not see)
@@ -586,6 +604,8 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
             HIP_TRY(launch_scatter_rows(w.dO2p, H, live_rows, R, H, w.dO2, H, st));
         }
     }
+    bool l2_deferred = false;
+    std::function<int()> l2_grads_fn;
     if (do_l2) {
     // ---- LSTM2 back through time (one persistent launch up to 128 rows: chain.hip)
     {
@@ -593,8 +613,18 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         // (live rows: the forward pass of this workspace stopped the rows behind their <eos>, see there -- the same order here)
         const bool rec_live = live_rows && Tc <= 128 && chain_live_capable(N, H);
         if (live_rows && Tc <= 128 && N <= 1024) HIP_TRY(launch_row_order(live_rows, n_live, N, Tv, Tc, w.perm, w.nlive, st));
-        HIP_TRY(lstm_recurrence_bwd(p->lstm2_W, H + E, w.G2, w.C2, w.dO2, NH, H, Tv, w.dZ2, N, H, T, keep, seed, 512u, video_id, sample_id, sc, -1, st,
-                                    rec_live ? w.perm : nullptr, rec_live ? w.nlive : nullptr));
+        if (dwout_deferred) chain_gate_arm(&gate);
+        const hipError_t re = lstm_recurrence_bwd(p->lstm2_W, H + E, w.G2, w.C2, w.dO2, NH, H, Tv, w.dZ2, N, H, T, keep, seed, 512u, video_id, sample_id, sc, -1, st,
+                                                  rec_live ? w.perm : nullptr, rec_live ? w.nlive : nullptr);
+        chain_gate_arm(nullptr);
+        HIP_TRY(re);
+        if (dwout_deferred) {
+            // dWout = O2^T dlogits beside the recurrence (reads dlogits and O2, writes embed_word_W's gradient: nothing the recurrence touches);
+            // the gate has put the side stream behind "every workgroup of the grid resident" -- or, when the recurrence took its per-step
+            // form after all (a hold, a fault), the side stream simply follows the caller's
+            if (!gate.fired) HIP_TRY(fork_to(st, sd, ss.ev[3]));
+            HIP_TRY(launch_gemm_tn(dwout, sd));
+        }
     }
     // Live rows: the packed copies of the live dZ2 rows / previous words are read on BOTH streams (weight gradients on the side
     // stream, dX2 and the embedding scatter on the caller's), so they are made on the caller's stream, ahead of the fork
@@ -602,8 +632,10 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         HIP_TRY(launch_gather_rows(w.dZ2 + (size_t)Tv * 4 * NH, 4 * H, live_rows, n_live, 4 * H, w.dZ2p, 4 * H, st));
         HIP_TRY(launch_gather_i32(w.prev, live_rows, n_live, w.prevp, st));
     }
-    // dZ2 is complete: LSTM2's weight gradients go to the side stream, beside dX2 and LSTM1's recurrence
+    // dZ2 is complete: LSTM2's weight gradients go to the side stream, beside dX2 and LSTM1's recurrence (mode 2: beside LSTM1's recurrence
+    // only -- launched from the lambda below once that grid is resident; dX2 keeps the chip to itself)
     if (sd != st) HIP_TRY(fork_to(st, sd, ss.ev[1]));
+    auto l2_weight_grads = [&]() -> int {
     if (!live_rows) {
         TnArgs a{w.O1, nullptr, H, w.dZ2, 4 * H, grads->lstm2_W, 4 * H, T * N, H, 4 * H, 1};
         HIP_TRY(launch_gemm_tn(a, sd));
@@ -635,6 +667,11 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
         e1.colsum = grads->lstm2_b;
         HIP_TRY(launch_gemm_tn(e1, sd));
     }
+    return S2VT_OK;
+    };
+    l2_deferred = gate1 && do_rest && sd != st;
+    if (!l2_deferred) { const int rc = l2_weight_grads(); if (rc != S2VT_OK) return rc; }
+    else l2_grads_fn = l2_weight_grads;
     }
     if (!do_rest) return S2VT_OK;
     // d[out1 ; embed] for every step at once -- with live rows: the encode steps, then the live decode rows (from the packed dZ2
@@ -656,7 +693,14 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
     HIP_TRY(launch_reduce_dropout(w.dX2, H + E, w.dH1, T, B, N, H, keep, seed, 256u, video_id, sample_id, st));
     {
         BwdScratch sc{w.slab, w.dc, w.bimg, w.bex, w.bsync};
-        HIP_TRY(lstm_recurrence_bwd(p->lstm1_W, E, w.G1, w.C1, w.dH1, BH, H, 0, w.dZ1, B, H, T, 1.0f, seed, 0u, nullptr, nullptr, sc, -1, st));
+        if (l2_deferred) chain_gate_arm(&gate);
+        const hipError_t re = lstm_recurrence_bwd(p->lstm1_W, E, w.G1, w.C1, w.dH1, BH, H, 0, w.dZ1, B, H, T, 1.0f, seed, 0u, nullptr, nullptr, sc, -1, st);
+        chain_gate_arm(nullptr);
+        HIP_TRY(re);
+        if (l2_deferred) {                                   // LSTM2's three weight-gradient contractions, beside LSTM1's recurrence (they read dZ2: final since ev[1])
+            const int rc = l2_grads_fn();
+            if (rc != S2VT_OK) return rc;
+        }
     }
     HIP_TRY(nn_bwd_slabs(w.dZ1, 4 * H, p->lstm1_W, 4 * H, w.dX1, E, Tv * B, E, 4 * H, w.dXs, st, w.dXs_floats));
 

@@ -1,4 +1,6 @@
-"""decode_loop.hip (S2VT_DECLOOP=1): the sampler's Tc decode steps -- LSTM2, vocabulary logits, multinomial / argmax pick --
+"""(Experimental build only: `make -C multitask-end-to-end-video-captioning_amd/csrc EXPERIMENTAL=1` -> libs2vt_hip_experimental.so; skipped when that
+library has not been built -- the kernel is a recorded negative result, DESIGN.md 11, and not part of the product library.)
+decode_loop.hip (S2VT_DECLOOP=1): the sampler's Tc decode steps -- LSTM2, vocabulary logits, multinomial / argmax pick --
 in ONE persistent launch.  Same chains, same keys: the token ids are those of the per-step launches, bit for bit, at the
 bench dimensions (B = 64, K = 5: R = 384), at 320 rows (five row tiles per part), with a vocabulary that leaves workgroups
 idle in the pick phase, and with a batch that is not a power of two."""
@@ -36,13 +38,22 @@ print("child ok")
 '''
 
 
+def experimental_lib():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = os.path.join(root, "multitask-end-to-end-video-captioning_amd", "libs2vt_hip_experimental.so")
+    if not os.path.exists(p):
+        pytest.skip("libs2vt_hip_experimental.so not built (make EXPERIMENTAL=1): the opt-in decode-loop experiments are not in the product library")
+    return p
+
+
 def test_persistent_decode_loop_draws_the_same_ids(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = experimental_lib()
     res = {}
     with tempfile.TemporaryDirectory() as td:
         for flag in ("0", "1"):
             f = os.path.join(td, f"ids{flag}.npz")
-            r = subprocess.run([sys.executable, "-c", CODE, f], env=dict(os.environ, S2VT_ROOT=root, S2VT_DECLOOP=flag), capture_output=True,
+            r = subprocess.run([sys.executable, "-c", CODE, f], env=dict(os.environ, S2VT_ROOT=root, S2VT_DECLOOP=flag, S2VT_LIB=lib), capture_output=True,
                                text=True, timeout=900)
             assert r.returncode == 0 and "child ok" in r.stdout, r.stderr[-3000:]
             res[flag] = dict(np.load(f))

@@ -13,7 +13,7 @@ done
 wait
 for spec in "$@"; do
   name=${spec%%:*}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api.o train.o attn.o attn_model.o session.o chain.o chain_bwd.o decode4.o decode_loop.o \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api.o train.o attn.o attn_model.o session.o chain.o chain_bwd.o \
      /tmp/acvar_$name/attn_chain.o /tmp/acvar_$name/attn_chain_bwd.o
 done
 ls -la ../../variants

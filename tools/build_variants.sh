@@ -8,7 +8,7 @@ rm -f ../../variants/*.so
 build() { # name flags...
   local name=$1; shift
   local d=/tmp/var_$name; mkdir -p $d
-  for f in fwd aux api train attn attn_model attn_chain attn_chain_bwd session chain chain_bwd decode4 decode_loop; do
+  for f in fwd aux api train attn attn_model attn_chain attn_chain_bwd session chain chain_bwd; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 "$@" -c $f.hip -o $d/$f.o &
   done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so $d/*.o
