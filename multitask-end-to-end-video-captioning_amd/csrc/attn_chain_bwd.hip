@@ -93,6 +93,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lin = jj * 4 + gate;
     const int brow = 4 * g.ncg - 1 - lin;                      // attention role: batch row
     const bool roleA = brow < M;
+    // Every workgroup of a row tile reads the SAME dhWa image at the same moment: walked in the same k-group order by all of them, the 63
+    // readers of a 1-KB block queue on the few L2 channels that hold it (s_memtime stamps, round 5: the 16 fragment loads of the query product
+    // took 10 000 cycles; 3 500 with the rotation).  The product is order-free (a gradient), so every unit group starts its walk at a different
+    // k-group: register slot j of the wave's quarter of Wa holds group (j + rotq) mod QG.  (The same rotation on the dz images of phase (M)
+    // measured SLOWER, 19 300 -> 22 600 cycles for the 512 MFMAs: there the readers of a block are spread over the ring's 16 loads in flight
+    // anyway, and walking together is what lets 31 of an XCD's 32 readers hit the line the first one fetched.)
+    const int rotq = jj & (QG - 1);
 
     // ---- this workgroup's two slices -> LDS, once.  B[k][n] = W3[base + u0 + n][gate * H + k]
     for (int idx = tid; idx < 2 * 16 * NG * 4; idx += 256) {
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float wa[4 * QG];
 #pragma unroll
     for (int s = 0; s < 4 * QG; ++s) {
-        const int k = 16 * (QG * pwave + (s >> 2)) + 4 * (s & 3) + lq;
+        const int k = 16 * (QG * pwave + (((s >> 2) + rotq) & (QG - 1))) + 4 * (s & 3) + lq;
         wa[s] = (u0 + l15 < H && k < H) ? g.Wa[(size_t)(u0 + l15) * g.ldwa + k] : 0.0f;
     }
 
@@ -281,6 +288,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 wh = *reinterpret_cast<const f32x4*>(g.w + 4 * q4);
             }
             if (tid < Tv) all_[tid] = g.alpha[((size_t)t * Tv + tid) * M + brow];
+            // few frames: tanh(hWa_t + P_f) of this thread's columns does not depend on this iteration's recurrence either -- computed while the
+            // other workgroups finish their products, not behind the wait (20 tanh per thread: ~3 000 cycles of the iteration's critical path)
+            float tnR[TVR][4];
+            if (aregs) {
+#pragma unroll
+                for (int f = 0; f < TVR; ++f)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tnR[f][i] = (f < Tv && qok) ? dm_tanhf(hv[i] + pR[f][i]) : 0.0f;
+            }
             gd.wait_all(it, pwave, lane);
             {
                 // the recurrence's part of d(ctx_t) of this row: the context-block partials of the four gate workgroups of unit group
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             const float d = del[f], alt = all_[f];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const float Tn = dm_tanhf(hv[i] + pR[f][i]);
+                                const float Tn = tnR[f][i];
                                 const float s_ = d * wh[i] * (1.f - Tn * Tn);
                                 accq[i] += s_;
                                 dwl[i] += d * Tn;
@@ -440,7 +456,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qt), 0, QG * 1024, 0x00020000);
             const int vq = gate * 16 < M ? lane * 16 : (int)0x80000000u;
             f32x4 aq[QG];
-            static_for<0, QG>([&](auto j_) { constexpr int j = decltype(j_)::value; aq[j] = bload16_sc1(rsQ, vq, j * 1024); });
+            static_for<0, QG>([&](auto j_) { constexpr int j = decltype(j_)::value; aq[j] = bload16_sc1(rsQ, vq, ((j + rotq) & (QG - 1)) * 1024); });
             // all 16 fragments first: left to its own waits hipcc interleaved them with the MFMAs in a way that cost 2.4 us here (stamps)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             AB_STAMP(12);                                      // query product: fragments landed
