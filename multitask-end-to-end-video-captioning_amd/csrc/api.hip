@@ -286,7 +286,7 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
     t.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
     t.wemb_p = t.w2_p = t.himg[0] = t.himg[1] = nullptr;
 #ifdef S2VT_EXPERIMENTAL       // (decode4.hip / decode_loop.hip: opt-in negative results, built by `make EXPERIMENTAL=1` only)
-    if (R > 256 && R <= 384 && (size_t)d->n_words * ((E + 15) / 16 * 16) * 4 < (1ull << 31)) {      // (sized by shape alone: the same carve whatever the device says)
+    if ((R <= 64 || (R > 256 && R <= 384)) && (size_t)d->n_words * ((E + 15) / 16 * 16) * 4 < (1ull << 31)) {      // (sized by shape alone: the same carve whatever the device says)
         Dec4Geom q;
         decode4_geometry(R, (int)H, (int)E, &q);
         t.wemb_p = c.take<float>((size_t)d->n_words * q.erow);

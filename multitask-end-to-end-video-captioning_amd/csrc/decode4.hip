@@ -382,7 +382,7 @@ void decode4_geometry(int R, int H, int E, Dec4Geom* o)
     o->ngt = (o->ech + o->hch) * kCG;
     o->ncg = (H + 15) / 16;
     const int tiles = (R + 15) / 16;
-    o->tpp = (tiles + 3) / 4 <= 5 ? 5 : 6;
+    o->tpp = tiles <= 4 ? 1 : ((tiles + 3) / 4 <= 5 ? 5 : 6);       // (R <= 64: one row tile per row part -- the persistent decode loop only)
     o->img_tiles = 4 * o->tpp;
 }
 

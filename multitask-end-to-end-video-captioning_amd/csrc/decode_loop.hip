@@ -77,8 +77,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int GPW = CG / 4;
     constexpr int YOUNGER = (NBUF - 2) * GPW * TPP + (NBUF - 1) * CG;
     static_assert(YOUNGER <= 63, "vmcnt range");
-    constexpr int NB = kNB, RING = kRING, TNC = kTNC;
-    constexpr int TMW = 3;                                     // phase B: row tiles per wave (8 waves x 3 >= 4 TPP)
+    // (R <= 64: a k-group is 12 MFMAs per wave instead of 108 -- the W stages and the A fragments must be requested 3x as many groups
+    //  ahead to cover the same latency: with the 384-row depths the loop ran 1070 cycles per group against 384 of MFMAs, round-5 stamps)
+    constexpr int NB = TPP == 1 ? 8 : kNB, RING = TPP == 1 ? 6 : kRING, TNC = kTNC;
+    constexpr int ZA0 = NB * 16 * 48 > 4096 ? NB * 16 * 48 : 4096;   // floats: the accumulator slots of the pick epilogue start behind the W stages
+    constexpr int TMW = TPP >= 5 ? 3 : 1;                      // phase B: row tiles per wave (8 waves x 3 >= 4 TPP; R <= 64: waves 0-3 one tile each)
     static_assert(8 * TMW >= 4 * TPP, "phase B covers every row tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ab = smem;                                          // phase A: [NBUF][CG][PPG][64][4]
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // A fragments of this wave's row tiles: image block (tile, group) = 1 KB, lane-linear; sc1 (another XCD wrote it)
             // (wave w: row tiles 3w .. 3w+2; a tile beyond the 4 TPP of the image reads zeros through the bounds check)
             const int tvalid = 4 * TPP - wave * TMW;               // tiles of this wave inside the image
+            const bool bw = tvalid > 0;                            // (R <= 64: waves 4-7 hold no row tile -- they keep the barriers and leave the matrix pipe to waves 0-3)
             const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(him_out + (size_t)wave * TMW * g.hgp * 256, 0,
                                                                                  (tvalid <= 0 ? 0 : (tvalid < TMW ? tvalid : TMW)) * g.hgp * 1024, 0x00020000);
             f32x4 a[RING][TMW];
@@ -350,6 +354,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                             for (int j = 0; j < TNC; ++j) bvn[e][j] = b[e * 4 * 48 + j * 16];
                         __builtin_amdgcn_sched_barrier(0);
+                        if (bw) {
                         static_for<0, 4>([&](auto e_) {
                             constexpr int e = decltype(e_)::value;
 #pragma unroll
@@ -357,6 +362,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                                 for (int j = 0; j < TNC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][i][e], bvc[e][j], acc[i][j], 0, 0, 0);
                         });
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         const int gn = gi + RING < kg ? gi + RING : kg - 1;
 #pragma unroll
@@ -385,13 +391,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // The tile loop below stays ROLLED (its body -- three Philox blocks, the two-tier keys, the lane reduction -- is ~1500
             // instructions; unrolled six times it leaves the instruction cache): the accumulators go through a lane-private LDS
             // slot (each lane reads back what it wrote: no barrier), beyond the W stages other waves may still be reading.
-            f32x4* const za = reinterpret_cast<f32x4*>(smem + 4096) + wave * (TMW * TNC * 64) + lane;
+            f32x4* const za = reinterpret_cast<f32x4*>(smem + ZA0) + wave * (TMW * TNC * 64) + lane;
 #pragma unroll
             for (int i = 0; i < TMW; ++i)
 #pragma unroll
                 for (int j = 0; j < TNC; ++j) za[(i * TNC + j) * 64] = acc[i][j];
 #pragma nounroll
-            for (int i = 0; i < TMW; ++i) {
+            for (int i = 0; i < (bw ? TMW : 0); ++i) {
                 f32x4 ac[TNC];
 #pragma unroll
                 for (int j = 0; j < TNC; ++j) ac[j] = za[(i * TNC + j) * 64];
@@ -494,10 +500,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 typedef void (*DecLoopFn)(const DecLoopArgs);
 struct DecLoopCfg { int tpp; DecLoopFn fn; const char* name; };
-const DecLoopCfg kDecLoop[] = {{5, decode_loop_kernel<5>, "decloop(m320)"}, {6, decode_loop_kernel<6>, "decloop(m384)"}};
+const DecLoopCfg kDecLoop[] = {{5, decode_loop_kernel<5>, "decloop(m320)"}, {6, decode_loop_kernel<6>, "decloop(m384)"}, {1, decode_loop_kernel<1>, "decloop(m64)"}};
 int decloop_lds_bytes(int tpp)
 {
-    const int a = (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4, b = 4096 * 4 + 8 * 3 * kTNC * 64 * 16;      // phase A ring + gate tiles | phase B stages + accumulator slots
+    const int nb = tpp == 1 ? 8 : kNB, za0 = nb * 16 * 48 > 4096 ? nb * 16 * 48 : 4096;
+    const int a = (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4, b = za0 * 4 + 8 * 3 * kTNC * 64 * 16;      // phase A ring + gate tiles | phase B stages + accumulator slots
     return a > b ? a : b;
 }
 std::once_flag g_dl_once;
@@ -511,7 +518,7 @@ constexpr int kDecLoopGrid = 256;
 bool decode_loop_eligible(int R, int H, int E, int V)
 {
     static const int on = [] { const char* e = getenv("S2VT_DECLOOP"); return e ? atoi(e) : 0; }();
-    if (!on || R <= 256 || R > 384 || (H & 3) || H < 132 || H > 1008 || E < 1 || (V & 3) || (V + 15) / 16 > kDecLoopGrid * kTNC) return false;
+    if (!on || !(R <= 64 || (R > 256 && R <= 384)) || (H & 3) || H < 132 || H > 1008 || E < 1 || (V & 3) || (V + 15) / 16 > kDecLoopGrid * kTNC) return false;
     if (chain_persistent_disabled()) return false;
     ChainHost h;
     if (!chain_host(&h) || h.num_cus < kDecLoopGrid) return false;
@@ -541,14 +548,14 @@ hipError_t launch_decode_loop(const DecLoopLaunch& a, const Dec4Geom& q, hipStre
     k.R = a.R; k.H = a.H; k.V = a.V; k.Tc = a.Tc;
     k.eg = q.eg; k.hg = q.hg; k.hgp = q.hgp; k.ncg = q.ncg; k.ech = q.ech; k.hch = q.hch;
     k.sync = a.sync; k.status = h.status_dev; k.fault = h.fault; k.spin_limit = h.spin_limit;
-    const DecLoopCfg& c = kDecLoop[q.tpp == 5 ? 0 : 1];
+    const DecLoopCfg& c = kDecLoop[q.tpp == 5 ? 0 : (q.tpp == 6 ? 1 : 2)];
     ChainLaunchOrder order;                                     // one persistent grid at a time per process
     hipError_t e = order.before(st, h.device);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(a.sync, 0, kChainSyncBytes, st);
     if (e != hipSuccess) return e;
     const double flops = (2.0 * a.R * (double)(a.E + a.H) * 4.0 * a.H + 2.0 * a.R * (double)a.H * a.V) * a.Tc;
-    const int ci = 14 + (q.tpp == 5 ? 0 : 1);                   // profiler slot: class 2 (vocabulary pick), beyond the gemm_kernel table
+    const int ci = 14 + (q.tpp == 5 ? 0 : (q.tpp == 6 ? 1 : 2));                   // profiler slot: class 2 (vocabulary pick), beyond the gemm_kernel table
     if (!prof_wants(2, ci)) {
         hipLaunchKernelGGL(c.fn, dim3(kDecLoopGrid), dim3(512), decloop_lds_bytes(c.tpp), st, k);
         e = hipGetLastError();

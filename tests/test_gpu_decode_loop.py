@@ -22,7 +22,8 @@ import s2vt_amd
 from s2vt_amd import ops
 from oracle import s2vt_oracle as orc
 out = {}
-for (B, K, V, H, E, Tc) in ((64, 5, 12000, 1000, 500, 7), (64, 4, 12000, 1000, 500, 4), (48, 6, 9972, 1000, 500, 5), (64, 5, 2000, 992, 300, 5)):
+for (B, K, V, H, E, Tc) in ((64, 5, 12000, 1000, 500, 7), (64, 4, 12000, 1000, 500, 4), (48, 6, 9972, 1000, 500, 5), (64, 5, 2000, 992, 300, 5),
+                           (32, 1, 12000, 1000, 500, 6), (16, 3, 9972, 1000, 500, 5), (16, 1, 2000, 992, 300, 4), (64, 0, 12000, 1000, 500, 5)):   # R <= 64: one row tile per row part
     d = orc.Dims(256, V, E, H, 5, Tc, 0)
     dims = ops.make_dims(256, V, E, H, 5, Tc)
     p = {k: torch.as_tensor(v).cuda() for k, v in orc.init_params(d, 3).items()}

@@ -6,13 +6,14 @@ sys.path.insert(0, os.environ["S2VT_ROOT"])
 import torch, numpy as np
 import s2vt_amd
 from s2vt_amd import model as M
-mdl = M.Video_Caption_Generator(1536, 12000, 500, 1000, 64, 0, 5, 20, seed=1234)
-video = (torch.randn(64, 5, 1536, generator=torch.Generator().manual_seed(1)) * 0.5).abs().cuda()
-for _ in range(5): s, g = mdl.sample(video, 5, True, seed=3)
+B, K = int(os.environ.get("DL_B", "64")), int(os.environ.get("DL_K", "5"))
+mdl = M.Video_Caption_Generator(1536, 12000, 500, 1000, B, 0, 5, 20, seed=1234)
+video = (torch.randn(B, 5, 1536, generator=torch.Generator().manual_seed(1)) * 0.5).abs().cuda()
+for _ in range(5): s, g = mdl.sample(video, K, True, seed=3)
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record()
-for i in range(30): s, g = mdl.sample(video, 5, True, seed=3 + i)
+for i in range(30): s, g = mdl.sample(video, K, True, seed=3 + i)
 e1.record(); torch.cuda.synchronize()
 print("DECLOOP", os.environ.get("S2VT_DECLOOP"), "sample() ms", e0.elapsed_time(e1) / 30, "timeouts", s2vt_amd.ops.chain_timeouts(), "ids", int(s.sum()))
 '''

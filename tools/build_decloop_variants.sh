@@ -12,6 +12,6 @@ done
 wait
 for spec in "$@"; do
   name=${spec%%:*}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api_exp.o train.o attn.o session.o chain.o chain_bwd.o decode4.o /tmp/lvar_$name/decode_loop.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api_exp.o train.o attn.o attn_model.o attn_chain.o attn_chain_bwd.o session.o chain.o chain_bwd.o decode4.o /tmp/lvar_$name/decode_loop.o
 done
 ls ../../variants

@@ -7,7 +7,7 @@ import s2vt_amd
 from s2vt_amd import ops
 L = s2vt_amd.lib()
 from oracle import s2vt_oracle as orc
-B, K, TC = 64, 5, 20
+B, K, TC = int(os.environ.get("DL_B", "64")), int(os.environ.get("DL_K", "5")), 20
 dims = ops.make_dims(1536, 12000, 500, 1000, 5, TC)
 d = orc.Dims(1536, 12000, 500, 1000, 5, TC, 0)
 p = {k: torch.as_tensor(v).cuda() for k, v in orc.init_params(d, 1).items()}
