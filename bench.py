@@ -342,8 +342,10 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
         if info is not None:
             info["active_steps"] = mdl._active_steps(mask_host, TC)
 
+        steps_att = mdl._active_steps(mask_host, TC)          # ... the host reads the unroll length off its mask once; the mask itself is resident
+                                                               # in HBM like every other input of the timed region (no per-step upload in the trace)
         def step(i):
-            return mdl.xe_update(video, gt, mask_host, lr=1e-4, clip_norm=10.0, video_base=rank * B)
+            return mdl.xe_update(video, gt, gt_mask, lr=1e-4, clip_norm=10.0, video_base=rank * B, active_steps=steps_att)
         return step
     if workload == "xe":
         # as train_xe does: the steps behind the longest caption of the GLOBAL batch (its <eos> included) are padding on

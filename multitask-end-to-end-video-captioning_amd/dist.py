@@ -72,10 +72,15 @@ def _all_reduce_sum(t: torch.Tensor, group=None):
 def allreduce_bucket(grad_flat: torch.Tensor, n_params: int, local_mask_sum, group=None):
     """In place: grad_flat[:n_params] <- sum over ranks, returns the GLOBAL sum(mask) as a 1-element
     view of the bucket's tail slot (so one collective carries both).  local_mask_sum None: the slot already holds it."""
+    if not active(group):
+        # one process: nothing travels -- the local sum IS the global one, and copying it into the bucket's tail would be a 4-byte
+        # runtime blit kernel per step (the only non-library launch the XE step's trace still showed, profiles/r04_xe_kernel_stats.md)
+        if local_mask_sum is not None:
+            return local_mask_sum.reshape(1) if isinstance(local_mask_sum, torch.Tensor) else grad_flat.new_full((1,), float(local_mask_sum))
+        return grad_flat[n_params:n_params + 1]
     if local_mask_sum is not None:
         grad_flat[n_params] = local_mask_sum
-    if active(group):
-        _all_reduce_sum(grad_flat, group)
+    _all_reduce_sum(grad_flat, group)
     return grad_flat[n_params:n_params + 1]
 
 

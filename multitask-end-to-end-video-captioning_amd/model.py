@@ -236,6 +236,25 @@ class Session:
         return out[0] if single else out
 
 
+class LazyScalar:
+    """A device-side scalar that is only computed when somebody reads it (float(x), x.item()): the multitask steps' attribute-loss term
+    bce.sum() * scale is a reporting value -- two tensor-library launches per step when formed eagerly, none when nobody asks."""
+
+    def __init__(self, fn):
+        self._fn, self._val = fn, None
+
+    def tensor(self):
+        if self._val is None:
+            self._val = self._fn()
+        return self._val
+
+    def __float__(self):
+        return float(self.tensor())
+
+    def item(self):
+        return float(self)
+
+
 @dataclass
 class StepStats:
     loss: torch.Tensor          # device scalar
@@ -550,7 +569,10 @@ class Video_Caption_Generator:
         a0 = st.offsets.get("attr_W", nd)
         ops.grad_finalize(st.grad[:a0], st.theta[:a0], self._gscale, weight_decay, self._sumsq)
         if a0 < nd:
-            self._ascale.fill_(1.0 if attr_scale is None else float(attr_scale))
+            want = 1.0 if attr_scale is None else float(attr_scale)
+            if getattr(self, "_ascale_val", None) != want:          # (a constant of the run: one fill, not one per step)
+                self._ascale.fill_(want)
+                self._ascale_val = want
             ops.grad_finalize(st.grad[a0:nd], st.theta[a0:nd], self._ascale, weight_decay, self._sumsq)
         ops.grad_finalize(st.grad[nd:st.numel], st.theta[nd:], self._gscale, weight_decay if decay_all else 0.0, self._sumsq)
         if extra_sumsq is not None:
@@ -658,7 +680,7 @@ class Video_Caption_Generator:
             dz = ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
             attr_scale = self.alpha / float(self.label_dim * Bg)
             self._attr_ctx = (dz, attr_scale)                   # for callers that differentiate through `video` (e2e.py)
-            attr_loss = bce.sum() * attr_scale
+            attr_loss = LazyScalar(lambda bce=bce, sc=attr_scale: bce.sum() * sc)
         self.apply_gradients(None if fused else msum, lr, clip_norm, attr_scale=attr_scale, extra_sumsq=extra_sumsq, loss_terms=(coef, nll, msum))
         st = StepStats(self._loss[0], self._sumsq, msum[0])
         st.attr_loss = attr_loss
@@ -792,7 +814,7 @@ class Video_Caption_Generator:
             dz = ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
             attr_scale = self.alpha / float(self.label_dim * B * self.world_size)
             self._attr_ctx = (dz, attr_scale)
-            attr_loss = bce.sum() * attr_scale
+            attr_loss = LazyScalar(lambda bce=bce, sc=attr_scale: bce.sum() * sc)
         one = getattr(self, "_one_over_world", None)                      # the bucket is already normalised: global "sum(mask)" = 1
         if one is None or one[1] != self.world_size:
             one = self._one_over_world = (torch.full((), 1.0 / self.world_size, device=self.device), self.world_size)
