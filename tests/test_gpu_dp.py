@@ -127,7 +127,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "S2VT_DP_OVERLAP")}
     nccl = torch.cuda.device_count() >= 2
     env["S2VT_DIST_BACKEND"] = "nccl" if nccl else "gloo"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
@@ -142,6 +142,9 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert cfg["replica_max_abs_diff"] == 0.0
     assert cfg["allreduce_ms"] > 0.0 and cfg["persistent_recurrence_timeouts"] == 0
     assert "cpu_baseline" not in out                       # rank 0 at N = 1 only
+    # the run probed both exchange modes (3 steps each, replicas identical after each) and took the faster one
+    pr = cfg["dp_overlap_probe_ms"]
+    assert set(pr) == {"off", "on"} and pr["off"] > 0 and pr["on"] > 0 and cfg["dp_overlap"] == (pr["on"] < pr["off"])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
