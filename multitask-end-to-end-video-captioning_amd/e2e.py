@@ -27,7 +27,15 @@ from . import ops
 
 
 class EndToEnd:
-    def __init__(self, model, cnn: torch.nn.Module, feature_keep: float | None = None, seed: int = 0, channels_last: bool = False):
+    def __init__(self, model, cnn: torch.nn.Module, feature_keep: float | None = None, seed: int = 0, channels_last: bool = False,
+                 miopen_find: bool | None = None):
+        # miopen_find (env S2VT_MIOPEN_FIND=1): let MIOpen time its convolution algorithms per shape on first use
+        # (torch.backends.cudnn.benchmark) instead of taking the immediate-mode heuristic -- fp32 either way; costs seconds at the first step
+        import os
+        if miopen_find is None:
+            miopen_find = os.environ.get("S2VT_MIOPEN_FIND", "0") == "1"
+        if miopen_find:
+            torch.backends.cudnn.benchmark = True
         self.model, self.cnn = model, cnn.to(model.device)
         self.channels_last = channels_last                   # feed the CNN NHWC activations (MIOpen picks its NHWC kernels)
         self.keep = model.dropout_rate if feature_keep is None else feature_keep      # slim.dropout(net, self.dropout_rate, ..)
