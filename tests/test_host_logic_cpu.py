@@ -249,3 +249,81 @@ def test_untile_checks_host_feeds_on_the_host():
     assert B == 6 and v.shape[0] == 6
     v, B = m._untile(torch.as_tensor(distinct), 6)               # a device feed is taken at the feed contract's word
     assert B == 2
+
+
+# ---- round 5 ---------------------------------------------------------------------------------------------------------------------
+def test_single_process_bucket_exchange_copies_nothing():
+    """dist.allreduce_bucket in ONE process: the local sum(mask) IS the global one -- it is returned as given (no 4-byte copy into the
+    bucket's tail: that was the last non-library launch in the XE step's trace), the tail view when the caller says the slot holds it."""
+    from s2vt_amd import dist as dp
+    g = torch.arange(8, dtype=torch.float32)
+    tail0 = float(g[6])
+    ms = torch.tensor([5.0])
+    out = dp.allreduce_bucket(g, 6, ms)
+    assert out.shape == (1,) and out.data_ptr() == ms.data_ptr() and float(g[6]) == tail0
+    out = dp.allreduce_bucket(g, 6, torch.tensor(7.0))                # 0-dim tensors (mixed_update's 1 / world) come back with one element
+    assert out.shape == (1,) and float(out) == 7.0
+    out = dp.allreduce_bucket(g, 6, None)
+    assert out.data_ptr() == g[6:7].data_ptr()
+    assert float(dp.allreduce_bucket(g, 6, 3.0)) == 3.0
+
+
+def test_lazy_scalar_is_computed_once_and_only_when_read():
+    from s2vt_amd.model import LazyScalar
+    n = {"calls": 0}
+
+    def fn():
+        n["calls"] += 1
+        return torch.tensor(2.5)
+    x = LazyScalar(fn)
+    assert n["calls"] == 0
+    assert float(x) == 2.5 and x.item() == 2.5 and float(x.tensor()) == 2.5 and n["calls"] == 1
+
+
+def test_oracle_decay_all_and_attribute_scores():
+    """The multitask / e2e scripts' always-true weight-decay predicate (reinforce_multitask_e2e_attribute_s2vt.py:222): decay_all adds
+    exactly decay * (l2_loss(lstm1_b) + l2_loss(lstm2_b)) in both oracles; evaluate_multilabel's scores are sigmoid(z) of the head's z."""
+    from oracle import s2vt_oracle as orc
+    from oracle import s2vt_torch as T
+    d = orc.Dims(24, 61, 8, 12, 3, 4, 5)
+    p = orc.init_params(d, seed=2, attr=True)
+    rng = np.random.default_rng(0)
+    for k in ("lstm1_b", "lstm2_b"):
+        p[k] = rng.uniform(-.3, .3, p[k].shape).astype(np.float32)
+    video = np.abs(rng.standard_normal((3, 3, 24))).astype(np.float32)
+    cap = rng.integers(0, 61, (3, 4)).astype(np.int32)
+    mask = np.ones((3, 4), np.float32)
+    logits = orc.teacher_forced(p, d, video, cap)
+    extra = 5e-5 * 0.5 * float((p["lstm1_b"].astype(np.float64) ** 2).sum() + (p["lstm2_b"].astype(np.float64) ** 2).sum())
+    a, b = orc.xe_loss(p, d, logits, cap, mask), orc.xe_loss(p, d, logits, cap, mask, decay_all=True)
+    assert extra > 1e-8 and abs((b - a) - extra) <= 1e-12 + 1e-9 * extra
+    pt = T.to_torch(p, torch.float64, False)
+    lt = torch.as_tensor(logits).double()
+    ta, tb = T.xe_loss(pt, lt, cap, mask), T.xe_loss(pt, lt, cap, mask, decay_all=True)
+    assert abs(float(tb - ta) - extra) <= 1e-12 + 1e-9 * extra
+    z, _ = orc.attr_head(p, video)
+    sc = orc.attr_scores(p, video)
+    assert sc.shape == (3, 5) and np.abs(sc - 1.0 / (1.0 + np.exp(-z.astype(np.float64)))).max() <= 2e-7
+
+
+def test_bench_workload_table_and_profile_keys():
+    """bench.py's workload table (the reference's own default configuration is a workload) and the rocprofv3-name -> class:tile mapping
+    the stamped traffic / SQ summaries are keyed by."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench
+    from prof_keys import prof_key
+    w = bench.WORKLOADS["rl_ref"]
+    assert (w["B"], w["K"], w["tc"], w["v"]) == (256, 8, 35, 9972) and w["tokens"](256, 8) == 256 * 8 * 35 and w["seqfwd"](256, 8) == 33 * 256
+    assert bench.WORKLOADS["rl"]["tokens"](64, 5) == 6400 and abs(bench.F_SEQ - 1187.68e6) < 1
+    assert len(bench.kernel_signature()) == 16
+    assert prof_key("void s2vt::gemm_tn_dma_kernel<false, 16, 2>(s2vt::TnKArgs)") == "3:tn128x128(dma)"
+    assert prof_key("void s2vt::gemm_kernel<2, 2, 2, 3, 1, 2, true, 32, 0, false, false>(s2vt::GemmArgs)") == "2:64x96(2x2)"
+    assert prof_key("void s2vt::gemm_kernel<1, 4, 6, 1, 4, 3, true, 32, 4, false, false>(s2vt::GemmArgs)") == "1:gw96x16u(1x4)+4"
+    assert prof_key("void s2vt::(anonymous namespace)::lstm_bwd_chain4_kernel<64, 5>(s2vt::(anonymous namespace)::BwdChainArgs)") == "6:bchain4(ng64,m320)"
+    assert prof_key("void s2vt::(anonymous namespace)::attn_chain_kernel<64>(x)") == "9:attn_chain(ng64)"
+    # a stamped summary of another build is not this build's: the lookup says None rather than lend a stale figure
+    t, src = bench.stored_traffic(3, "no-such-tile", "rl")
+    assert t is None and src is None
