@@ -363,7 +363,8 @@ def make_step(workload, mdl, dev, rank, B, K, info=None):
     def step(i):
         s, _greedy = mdl.sample(video, K, True, seed=2024 + i, video_base=rank * B)
         return mdl.mixed_update(video, s, ops.caption_mask(s, want_target=False)[0], rewards, baseline, gt, gt_mask, lr=1e-6, lambda_loss=0.5, clip_norm=5.0,
-                                video_base=rank * B, true_labels=labels, decay_all=True)     # (the script's always-true decay predicate, :222)
+                                video_base=rank * B, true_labels=labels, decay_all=True,     # (the script's always-true decay predicate, :222)
+                                reuse_sampler_state=True)                                    # LSTM1 trajectory of the sampler pass, as the rl workload
     return step
 
 

@@ -338,8 +338,10 @@ int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const
         z.add(w.C2, NH * 4); z.add(w.H2, NH * 4);
         HIP_TRY(launch_zero_regions(z, st));
     }
-    int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
-    if (rc != S2VT_OK) return rc;
+    if (!sampler_workspace) {                     // (with the sampler's workspace the frame embedding is taken from there too, below)
+        int rc = s2vt_frame_embed_fwd(d, p, video, B, w.emb, stream);
+        if (rc != S2VT_OK) return rc;
+    }
 
     NoiseIds none{nullptr, nullptr, 0};
     NoiseIds ids{video_id, sample_id, seed};
@@ -356,9 +358,12 @@ int s2vt_teacher_forced_fwd_live(const s2vt_dims* d, const s2vt_params* p, const
         carve_sample(sc, d, B, sampler_rows, &sw);
         if (!sc.ok() || sampler_rows <= 0) return S2VT_E_WORKSPACE;
         CopyList cl;
-        if (cl.add(w.C1, sw.c1, (size_t)(T + 1) * BH * 4) && cl.add(w.H1, sw.h1, (size_t)(T + 1) * BH * 4) && cl.add(w.G1, sw.G1, (size_t)T * 4 * BH * 4)) {
+        // (the frame embedding the backward's dW1 product reads: the same product of the same operands in the sampler pass)
+        if (cl.add(w.C1, sw.c1, (size_t)(T + 1) * BH * 4) && cl.add(w.H1, sw.h1, (size_t)(T + 1) * BH * 4) && cl.add(w.G1, sw.G1, (size_t)T * 4 * BH * 4) &&
+            cl.add(w.emb, sw.emb, (size_t)B * Tv * E * 4)) {
             HIP_TRY(launch_copy_regions(cl, st));                                  // one library launch
         } else {                                                                   // (B * H not a multiple of 4: the runtime's copies)
+            HIP_TRY(hipMemcpyAsync(w.emb, sw.emb, (size_t)B * Tv * E * 4, hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.C1, sw.c1, (size_t)(T + 1) * BH * 4, hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.H1, sw.h1, (size_t)(T + 1) * BH * 4, hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.G1, sw.G1, (size_t)T * 4 * BH * 4, hipMemcpyDeviceToDevice, st));

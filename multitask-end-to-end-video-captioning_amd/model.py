@@ -726,7 +726,8 @@ class Video_Caption_Generator:
         return StepStats(self._loss[0], self._sumsq, msum[0])
 
     def mixed_update(self, video, sampled, mask, rewards, baseline, gt_caption, gt_mask, lr, lambda_loss=0.5, clip_norm=5.0,
-                     video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None, active_steps="auto", decay_all=False):
+                     video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None, active_steps="auto", decay_all=False,
+                     reuse_sampler_state=False):
         """The mixed objective of reinforce_multitask_e2e_attribute_s2vt.py:850 (BASELINE configs[3]):
             sum_loss = -(1 - lambda) * PG / sum(mask_pg)  +  lambda * model_loss
         with PG the reward-scaled log-likelihood of the SAMPLED captions (build_loss) and model_loss the
@@ -741,7 +742,10 @@ class Video_Caption_Generator:
         decay_all: SURVEY Q3, second half -- the weight-decay predicate of the multitask / e2e scripts,
         `if 'bias' or 'BatchNorm' not in v.name` (reinforce_multitask_e2e_attribute_s2vt.py:222), is always true, so model_loss
         decays EVERY variable, the LSTM `biases` included: their gradients carry lambda * decay_value * b.  False keeps
-        tf_s2vt.py:163's filter (names without 'bias')."""
+        tf_s2vt.py:163's filter (names without 'bias').
+        reuse_sampler_state: as reinforce_update -- the sample() call that produced `sampled` ran just before on this very video tensor with the
+        current weights; LSTM1 never sees a word or a dropout mask, so its trajectory is the same for the sampled AND the ground-truth rows of
+        the pass and is taken from the sampler's workspace instead of being recomputed (one 25-step recurrence less per step)."""
         if active_steps == "auto":          # both blocks decide: the longest sample and the longest ground-truth caption
             sa, sb = self.active_steps(mask), self.active_steps(gt_mask)
             active_steps = None if (sa is None or sb is None or (q1 and self.world_size > 1)) else max(sa, sb)
@@ -772,7 +776,7 @@ class Video_Caption_Generator:
             # library launch (the expressions of the branch below, in their order); the loss terms in one more
             coef, smooth_tm, cap_all, target_tm, sums = ops.mixed_prep(mask.contiguous(), gmask.contiguous(), self._dev(rewards, torch.float32), self._dev(baseline, torch.float32),
                                                             cap.contiguous(), gcap.contiguous(), lam, self.loss_weight, q1, smoothing, float(B * self.world_size))
-            nll, _ = self._forward_loss(video, cap_all, coef, smooth_tm, rep + 1, video_base, keep, steps=steps, live=live, target_tm=target_tm)
+            nll, _ = self._forward_loss(video, cap_all, coef, smooth_tm, rep + 1, video_base, keep, reuse_sampler_state, steps=steps, live=live, target_tm=target_tm)
             losses = ops.mixed_loss(self._coef_used, nll, live, N, rep * B)
             loss_total = losses[2]
         else:
@@ -797,7 +801,7 @@ class Video_Caption_Generator:
             smooth[rep * B:] = float(smoothing)
             smooth_tm = smooth.repeat(self.n_caption_lstm_step).contiguous()
             nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, rep + 1, video_base, keep,
-                                        steps=steps, live=live)
+                                        reuse_sampler_state, steps=steps, live=live)
             terms = self._coef_used * nll
             if live is None:
                 per_row = terms.view(-1, N)

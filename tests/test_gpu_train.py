@@ -169,6 +169,22 @@ def test_sampler_state_reuse_is_equivalent(gpu, oracle):
     assert outs[0][0] == outs[1][0]
     scale = float(outs[0][1].abs().max())
     assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-5 * scale
+    # the mixed multitask objective (sampled + ground-truth rows in one pass): LSTM1's trajectory is per VIDEO, the same for both row blocks
+    gcap = rng.integers(2, d.n_words, (B, d.n_caption_lstm_step)).astype(np.int32); gcap[:, -2:] = 0
+    gmask = hostglue.masks_from_ids(gcap)
+    outs = []
+    for reuse in (False, True):
+        mdl = M.Video_Caption_Generator(d.dim_image, d.n_words, d.word_dim, d.lstm_dim, B, 0, d.n_video_lstm_step,
+                                        d.n_caption_lstm_step, dropout_rate=0.9, seed=5, multisample=K)
+        s, _ = mdl.sample(video, K, True, seed=78)
+        mask = hostglue.masks_from_ids(s.cpu().numpy())
+        st = mdl.mixed_update(video, s, mask, r, b, gcap, gmask, lr=0.0, reuse_sampler_state=reuse)
+        outs.append((float(st.loss), mdl.store.grad[:mdl.store.numel].clone()))
+    assert outs[0][0] == outs[1][0]
+    scale = float(outs[0][1].abs().max())
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-5 * scale
+    with pytest.raises(RuntimeError):                                  # no sampler call on THIS tensor with the current weights: refused
+        mdl.mixed_update(video.clone(), s, mask, r, b, gcap, gmask, lr=0.0, reuse_sampler_state=True)
 
 
 def test_mixed_pg_xe_objective_vs_float64_autograd(gpu, oracle):
