@@ -73,7 +73,8 @@ class EndToEnd:
 
     def extract(self, frames, dropout: bool, track: bool = False, video_base: int = 0, draws=(0,)):
         """frames [B, Tv, 3, H, W] fp32 in [-1, 1] -> (video [B, Tv, D] contiguous & detached, autograd handle or None).
-        With several `draws` the CNN runs ONCE and one (video, handle) pair per independent dropout mask is returned."""
+        With several `draws` the CNN runs ONCE and one (video, handle) pair per independent dropout mask is returned; a draw of None is the
+        pair without dropout (what the greedy graphs see: batch norm is in inference mode in every graph, so the pooled features are the same)."""
         B, Tv = frames.shape[:2]
         x = frames.to(self.model.device, torch.float32).reshape(B * Tv, *frames.shape[2:])
         if self.channels_last:
@@ -81,8 +82,8 @@ class EndToEnd:
         outs = []
         with torch.set_grad_enabled(track):
             raw = self.cnn(x)
-            for d in draws:
-                f = self._feature_dropout(raw, B, Tv, video_base, d) if dropout and self.keep < 1.0 else raw
+            for d in draws:                                  # (a draw of None: the features WITHOUT dropout -- the greedy graphs', from the same CNN forward)
+                f = self._feature_dropout(raw, B, Tv, video_base, d) if (dropout and d is not None and self.keep < 1.0) else raw
                 f = f.reshape(B, Tv, -1)
                 outs.append((f.detach().contiguous(), (f if track else None)))
         return outs[0] if len(outs) == 1 else outs
@@ -148,10 +149,11 @@ class EndToEnd:
         (OFF, :466) through the CNN, reward_fn(samples[K*B,Tc], greedy[B,Tc]) -> (r[K*B], b[B]) on the host, then the
         REINFORCE update through the CNN (dropout ON, :308), clip 10 over all variables, one Adam."""
         m = self.model
-        # one CNN forward, two independent feature-dropout masks: the sampler's (:399) and the loss graph's (:308)
-        (video_s, _), (video_u, h) = self.extract(frames, dropout=True, track=True, video_base=video_base, draws=(0, 1))
+        # ONE CNN forward for the step's three graphs (the reference runs the network in each of them; with batch norm in inference mode the
+        # pooled features are the same everywhere and only slim.dropout differs): two independent feature-dropout masks -- the sampler's (:399)
+        # and the loss graph's (:308) -- and the undropped features of the greedy graph (:466)
+        (video_s, _), (video_u, h), (video_g, _) = self.extract(frames, dropout=True, track=True, video_base=video_base, draws=(0, 1, None))
         samples, _ = m.sample(video_s, K, False, seed=sample_seed, video_base=video_base)
-        video_g, _ = self.extract(frames, dropout=False)
         _, greedy = m.sample(video_g, 0, True, video_base=video_base)
         r, b = reward_fn(samples, greedy)
         r = torch.as_tensor(r, dtype=torch.float32)
