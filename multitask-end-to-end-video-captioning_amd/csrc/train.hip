@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <functional>
+#include <mutex>
 
 #include <cstdlib>
 
@@ -575,6 +576,12 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
     const bool gate1 = ss.ok && ss.mode == 2 && phase == 0 && N <= 256 && B <= 256 && bwd_chain_auto(B, H) && !(reinterpret_cast<uintptr_t>(p->lstm1_W) & 15);
     const bool side_on = ss.ok && phase == 0 && (ss.mode == 1 || gate1 || gate2);
     hipStream_t sd = side_on ? ss.s : st;                    // weight-gradient work that may run beside a recurrence (whole-pass calls only)
+    // The side stream and its events are ONE per process: two host threads driving distinct workspaces must not interleave their
+    // record / wait pairs (a wait enqueued after the OTHER thread's record of the same event would order this call's side work behind
+    // the wrong point).  The lock covers this call's enqueueing only -- the launches themselves are asynchronous as ever.
+    static std::mutex side_mu;
+    std::unique_lock<std::mutex> side_lk(side_mu, std::defer_lock);
+    if (side_on) side_lk.lock();
     ChainGate gate{ss.s, ss.ev[3], false};
     TnArgs dwout;                                            // (mode 2: the vocabulary projection's weight gradient is launched behind LSTM2's recurrence)
     bool dwout_deferred = false;
