@@ -97,14 +97,49 @@ def tile_baseline(b, K: int):
 def get_multilabel(vid_sentence, vocabulary):
     """Bag-of-words attribute labels (reinforce_multitask_e2e_attribute_loss.py:874-893):
     label[v] = 1 iff attribute word v occurs in any caption of the video."""
-    index = {w: i for i, w in enumerate(vocabulary)}
+    index = {}
+    for i, w in enumerate(vocabulary):                 # (the reference scans the vocabulary per word: EVERY position holding the word is set,
+        index.setdefault(w, []).append(i)              #  should the attribute vocabulary list a word twice -- tests/golden/hostglue.json)
     out = {}
     for vid, sents in vid_sentence.items():
         lab = np.zeros(len(vocabulary), np.int64)
         for s in sents:
             for w in s.split():
-                i = index.get(w)
-                if i is not None:
+                for i in index.get(w, ()):
                     lab[i] = 1
         out[vid] = lab
     return out
+
+
+def read_sent_vocab_file(sent_file, vocab_file):
+    """(video -> list of its sentences, attribute vocabulary, label_num): reinforce_multitask_e2e_attribute_loss.py:852-869 (lines stripped,
+    sentences grouped per video in file order)."""
+    vid_sent, vocab = {}, []
+    with open(sent_file) as f:
+        for line in f:
+            a = line.strip().split("\t")
+            vid_sent.setdefault(a[0], []).append(a[1])
+    with open(vocab_file) as f:
+        for line in f:
+            vocab.append(line.strip())
+    return vid_sent, vocab, len(vocab)
+
+
+def get_metrics(scores, labels, threshold=0.5):
+    """(true_positive, true_negative, false_positive, false_negative, count_pos, count_neg) of the multilabel evaluation
+    (reinforce_multitask_e2e_attribute_loss.py:700-717): a label >= threshold is a positive, a score >= threshold a predicted positive.
+    scores / labels [num_videos, label_dim] (the scores of evaluate_multilabel, the bag-of-words labels of get_multilabel)."""
+    s = np.asarray(scores) >= threshold
+    pos = np.asarray(labels) >= threshold
+    return (int((s & pos).sum()), int((~s & ~pos).sum()), int((s & ~pos).sum()), int((~s & pos).sum()), int(pos.sum()), int((~pos).sum()))
+
+
+def multilabel_summary(true_positive, true_negative, false_positive, false_negative, count_pos, count_neg):
+    """sensitivity, specificity, their harmonic mean, precision and F1 as the reference's test loop forms them (:1066-1073), zero guards included
+    (like the reference, the harmonic mean divides by the true positives / negatives: no true positive or no true negative raises ZeroDivisionError)."""
+    sensitivity = true_positive / float(count_pos) if count_pos > 0 else 0
+    specificity = true_negative / float(count_neg) if count_neg > 0 else 0
+    harmmean = 2.0 / (count_pos / float(true_positive) + count_neg / float(true_negative)) if (count_pos + count_neg) > 0 else 0
+    precision = (true_positive / float(true_positive + false_positive)) if true_positive > 0 else 0
+    f1_score = 2.0 * true_positive / float(2 * true_positive + false_positive + false_negative) if true_positive > 0 else 0
+    return {"sensitivity": sensitivity, "specificity": specificity, "harmmean": harmmean, "precision": precision, "f1_score": f1_score}

@@ -85,3 +85,48 @@ def test_frame_ticks_and_image_pipeline(tmp_path):
     Image.new("RGB", (40, 40), (255, 0, 128)).save(tmp_path / "solid.png")
     y = data.image_reading_processing([[str(tmp_path / "solid.png")]], 8, 8)[0, 0]
     assert np.allclose(y[0], 1.0) and np.allclose(y[1], -1.0) and np.allclose(y[2], 2 * 128 / 255 - 1, atol=1e-6)
+
+
+def test_frame_ticks_match_the_reference_function(tmp_path):
+    """Which frames of a video feed the CNN (e2e_tf_s2vt.py:376-412), pinned to the reference's own get_video_feature_caption_pair executed in the
+    build container on a scratch tree (tools/make_fixtures.py -> tests/golden/hostglue.json): 17 video lengths x 3 values of num_frame_per_video,
+    incl. videos too short for the step (frame 1 repeated) and a single-frame video; and the same through the file-system entry point."""
+    import json
+    from s2vt_amd import data
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hostglue.json")))
+    cases = G["frame_tick_cases"]
+    assert len(cases) == 3
+    for c in cases:
+        n = c["num_frame_per_video"]
+        for cnt, ticks in c["ticks"].items():
+            assert data.frame_ticks(int(cnt), n) == ticks, (n, cnt)
+    c = cases[0]
+    sent = tmp_path / "sents.txt"
+    with open(sent, "w") as f:
+        for cnt in (3, 7, 11, 30):
+            d = tmp_path / "frames" / f"vid{cnt}"
+            d.mkdir(parents=True)
+            for k in range(1, cnt + 1):
+                (d / f"{k:06d}.jpg").touch()
+            f.write(f"vid{cnt}\ta caption of video {cnt}\n")
+    sents, frames = data.get_video_frame_caption_pair(str(sent), str(tmp_path / "frames"), c["num_frame_per_video"])
+    assert sents.shape == (4, 2) and sents[0].tolist() == ["vid3", "a caption of video 3"]
+    for cnt in (3, 7, 11, 30):
+        assert [int(os.path.basename(p)[:6]) for p in frames[f"vid{cnt}"]] == c["ticks"][str(cnt)]
+
+
+def test_feature_file_parser_matches_the_reference_function(tmp_path):
+    """The feature text file (writer tf_feature_extract.py:153-154) as the reference's own parser reads it (tf_s2vt.py:324-345, executed in the build
+    container): video id = the text before the first '_', frames in FILE order (interleaved videos, frame numbers out of order), and the values
+    bit for bit what feeding the parsed strings to a float32 placeholder gives -- incl. 0, a denormal, FLT_MAX, scientific notation, 17 digits."""
+    import json
+    from s2vt_amd import data
+    c = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hostglue.json")))["feature_file_case"]
+    f = tmp_path / "feats.txt"
+    f.write_text(c["file_text"])
+    fs = data.FeatureStore.from_csv(str(f), cache=False)
+    assert list(fs.video_ids) == c["video_order"]
+    for i, v in enumerate(c["video_order"]):
+        want = np.asarray(c["features_f32_bits"][v], np.uint32)
+        got = np.ascontiguousarray(fs.features[i]).view(np.uint32)
+        assert got.shape == want.shape and np.array_equal(got, want), v
