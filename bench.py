@@ -604,9 +604,12 @@ def main():
                 line_off["config"]["dp_overlap_probe_ms"] = {"off": probe["off"], "on": "stalled: the blocking-mode measurement is reported"}
                 print(json.dumps(line_off), flush=True)
             os._exit(0)
-        wd = threading.Timer(max(120.0, 40.0 * line_off["ms_per_step"] * args.steps / 1e3), bail)
+        deadline = float(os.environ.get("S2VT_BENCH_WATCHDOG_S", "0")) or max(120.0, 40.0 * line_off["ms_per_step"] * args.steps / 1e3)
+        wd = threading.Timer(deadline, bail)
         wd.daemon = True
         wd.start()
+        if os.environ.get("S2VT_BENCH_FAKE_STALL") == "1":      # test hook (tests/test_gpu_dp.py): the overlapped mode "hangs" -- the watchdog must deliver the line
+            time.sleep(1e6)
         probe["on"] = probe_mode(True, 100)
         if probe["on"] < probe["off"]:
             mdl.dp_overlap = True

@@ -250,3 +250,25 @@ def test_bench_gpus_8_functional_line():
         assert cfg["replica_max_abs_diff"] == 0.0 and cfg["persistent_recurrence_timeouts"] == 0
         assert cfg["allreduce_ms"] > 0.0 and cfg["allreduce_bytes_per_s"] > 0 and cfg["ms_per_step_if_exchange_hidden"] <= out["ms_per_step"]
         assert np.isfinite(cfg["loss"])
+
+
+def test_bench_watchdog_delivers_the_blocking_mode_line_when_the_overlapped_probe_stalls():
+    """The N > 1 bench measures the blocking exchange first and only then probes the overlapped one, behind a watchdog: should that mode stall on a
+    real multi-rank communicator (it has never run on one), the run must still end with rc 0 and ONE line -- the blocking-mode measurement.  The stall
+    is faked (S2VT_BENCH_FAKE_STALL), the deadline shortened (S2VT_BENCH_WATCHDOG_S)."""
+    import json
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "S2VT_DP_OVERLAP")}
+    env.update(S2VT_DIST_BACKEND="nccl" if torch.cuda.device_count() >= 2 else "gloo", S2VT_BENCH_FAKE_STALL="1", S2VT_BENCH_WATCHDOG_S="8")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["dp_overlap"] is False and cfg["replica_max_abs_diff"] == 0.0 and out["value"] > 0
+    assert cfg["dp_overlap_probe_ms"]["off"] > 0 and str(cfg["dp_overlap_probe_ms"]["on"]).startswith("stalled")
