@@ -101,15 +101,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // anyway, and walking together is what lets 31 of an XCD's 32 readers hit the line the first one fetched.)
     const int rotq = jj & (QG - 1);
 
-    // ---- this workgroup's two slices -> LDS, once.  B[k][n] = W3[base + u0 + n][gate * H + k]
-    for (int idx = tid; idx < 2 * 16 * NG * 4; idx += 256) {
-        const int blk = idx / (16 * NG * 4), rem = idx % (16 * NG * 4);
-        const int k4 = rem % (NG * 4), n = rem / (NG * 4);
+    // ---- this workgroup's two slices -> LDS, once.  B[k][n] = W3[base + u0 + n][gate * H + k]; fragment slot (group, block, lane L = i * 16 + n)
+    // holds k = 16 group + 4 e + i for e = 0 .. 3.  Destination-indexed: a thread fills whole 16-byte slots, consecutive threads consecutive slots
+    // (source-indexed, 4-byte writes of one loaded row vector landed 64 lanes on 4 banks: the bulk of this kernel's LDS bank conflicts)
+    for (int sl = tid; sl < NG * 2 * 64; sl += 256) {
+        const int L = sl & 63, blk = (sl >> 6) & 1, grp = sl >> 7;
+        const int i = L >> 4, n = L & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (u0 + n < H && 4 * k4 < H) v = *reinterpret_cast<const f32x4*>(g.W3 + (size_t)((blk == 0 ? 2 * H : 0) + u0 + n) * g.ldw + (size_t)gate * H + 4 * k4);
-        const int grp = k4 >> 2, e = k4 & 3;
+        if (u0 + n < H) {
+            const float* row = g.W3 + (size_t)((blk == 0 ? 2 * H : 0) + u0 + n) * g.ldw + (size_t)gate * H + 16 * grp + i;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Wl[(((grp * 2 + blk) * 64 + i * 16 + n) << 2) + e] = v[i];
+            for (int e = 0; e < 4; ++e)
+                if (16 * grp + 4 * e + i < H) v[e] = row[4 * e];
+        }
+        *reinterpret_cast<f32x4*>(Wl + (size_t)sl * 4) = v;
     }
     // this wave's quarter of Wa[u0 + l15][:] -> registers: k-step s of the quarter holds Wa[u0 + l15][16 (QG w + s / 4) + 4 (s % 4) + lq]
     float wa[4 * QG];
