@@ -41,6 +41,9 @@ class Config:
     step_log: str = ""                 # path of a JSONL step log ("" = none)
     stop_at_eos: bool = False          # RL: samples leave the decode loop at their first <eos> (opt-in; the reference samples all Tc steps and masks
                                        # afterwards -- same update, shorter loop: model.sample(stop_at_eos=True))
+    alpha: float = 0.05                # multitask scripts: weight of the attribute head's multilabel loss (reinforce_multitask_e2e_attribute_loss.py:697)
+    lambda_loss: float = 0.0           # multitask scripts: weight of the ground-truth XE term mixed into the REINFORCE objective
+                                       # (reinforce_multitask_e2e_attribute_s2vt.py:670,850: 0.5 there); 0 = the pure self-critical objective
 
 
 class Corpus:
@@ -119,6 +122,15 @@ class DataParallel:
         t = torch.tensor([total, count], dtype=torch.float64, device=self.device)
         dp.allreduce_small(t)
         return float(t[0] / t[1]) if float(t[1]) else None
+
+    def sum_ints(self, counts):
+        """Element-wise sum over all ranks of a small integer vector (the multilabel evaluation's confusion counts)."""
+        import torch
+        if self.world == 1:
+            return np.asarray(counts, np.int64)
+        t = torch.as_tensor(np.asarray(counts, np.float64), device=self.device)
+        dp.allreduce_small(t)
+        return t.cpu().numpy().round().astype(np.int64)
 
     def gather_dict(self, d: dict) -> dict:
         if self.world == 1:

@@ -90,6 +90,109 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
     return trainer, history
 
 
+def train_reinforce(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, width=299, height=299, restore=None, cnn_variables=None,
+                    log=print, resume=None, attr_vocabulary=None, test=None):
+    """The REINFORCE loop with the CNN in it: train() of reinforcement_e2e.py:1085-1140 (BASELINE configs[4]) and, with attr_vocabulary, of the
+    multitask scripts (reinforce_multitask_e2e_attribute_loss.py:1085-1140: bag-of-words labels per video, the attribute head's term in the objective,
+    the multilabel metrics of its test loop :1042-1073).  Per step: B x Tv jpgs -> ONE CNN forward -> cfg.multisample sampled + the greedy captions ->
+    CIDEr-D of both against the video's own references on the host (reward.CiderD on ids) -> e2e.EndToEnd.reinforce_step (policy gradient through
+    the CNN, clip cfg.clip_norm over all variables, Adam on both halves).
+    test: (sents, video_frames) of the evaluation split -- greedy CIDEr-D (and the multilabel metrics) per epoch.
+    restore / resume as train()."""
+    import torch
+    from . import e2e, irv2, model as M, reward
+    par = DataParallel(model.device if model is not None else None)
+    if not par.chief:
+        log = lambda *_: None
+    wordtoix, _ = hostglue.preProBuildWordVocab(vocabulary)
+    K, B = cfg.multisample, par.per_rank(cfg.batch_size)
+    multitask = attr_vocabulary is not None
+    if model is None:
+        model = M.Video_Caption_Generator(cfg.dim_image, len(wordtoix), cfg.word_dim, cfg.lstm_dim, B, cfg.n_video_lstm_step + cfg.n_caption_lstm_step,
+                                          cfg.n_video_lstm_step, cfg.n_caption_lstm_step, bias_init_vector=None, seed=cfg.seed, multisample=K, device=par.device,
+                                          label_dim=len(attr_vocabulary) if multitask else 0, alpha=cfg.alpha if multitask else 0.0)
+    par.attach(model)
+    if restore:
+        log(f"restored: {optimistic_restore(model, restore, step_names=(), optimizer_state=False)}")
+    if resume:
+        log(f"resumed: {optimistic_restore(model, resume, optimizer_state=True)}")
+    if cnn is None:
+        cnn = irv2.InceptionResnetV2()
+        if cnn_variables is not None:
+            log(f"cnn variables restored: {len(cnn.load_slim_checkpoint(cnn_variables))}")
+    trainer = e2e.EndToEnd(model, cnn, seed=cfg.seed)
+
+    def side(sents_, frames_):
+        index = data.CaptionIndex(sents_)
+        lab = None
+        if multitask:
+            d = hostglue.get_multilabel(index.by_video, attr_vocabulary)
+            lab = np.stack([d[v] for v in index.video_ids]).astype(np.float32)
+        return index, reward.CiderD(index.refs_by_video(), wordtoix), lab, frames_
+    index, scorer, labels, _ = side(sents, video_frames)
+    tside = side(*test) if test is not None else None
+
+    def evaluate():
+        tindex, tscorer, tlab, tframes = tside
+        vids = tindex.video_ids[par.rank::par.world] if par.world > 1 else tindex.video_ids
+        total, count, tot = 0.0, 0, np.zeros(6, np.int64)
+        for a in range(0, len(vids), B):
+            ids = vids[a:a + B]
+            rows = [tindex.row[v] for v in ids]
+            frames = torch.from_numpy(data.image_reading_processing([tframes[v] for v in ids], width, height))
+            g = trainer.generate(frames).cpu().numpy()
+            model.check_health()
+            sc = tscorer.score_ids(g, rows)
+            total += float(sc.sum()); count += len(sc)
+            if multitask:
+                tot += np.asarray(hostglue.get_metrics(trainer.evaluate_multilabel(frames).cpu().numpy(), tlab[rows], 0.5), np.int64)
+        out = {"ciderD": par.mean(total, count)}
+        if multitask:
+            tp, tn, fp, fn, cp, cn = (int(x) for x in par.sum_ints(tot))
+            out["multilabel"] = dict(true_positive=tp, true_negative=tn, false_positive=fp, false_negative=fn)
+            if tp and tn:
+                out["multilabel"].update(hostglue.multilabel_summary(tp, tn, fp, fn, cp, cn))
+        return out
+
+    if tside is not None:
+        log(f"before train: {evaluate()}")
+    rng = random.Random(cfg.seed)
+    history = []
+    for epoch in range(cfg.n_epochs):
+        losses, adv = [], []
+        for it, gidx in enumerate(epoch_batches(len(sents), cfg.batch_size, rng)):
+            if cfg.max_steps_per_epoch and it >= cfg.max_steps_per_epoch:
+                break
+            t0 = time.time()
+            idx, lo = par.shard(gidx)
+            vid = sents[idx, 0]
+            rows = np.asarray([index.row[v] for v in vid], np.int32)
+            frames = torch.from_numpy(data.image_reading_processing([video_frames[v] for v in vid], width, height))
+            rb = {}
+
+            def reward_fn(samples, greedy):
+                rb["r"] = scorer.score_ids(samples.cpu().numpy(), np.tile(rows, K))
+                rb["b"] = scorer.score_ids(greedy.cpu().numpy(), rows)
+                model.check_health()
+                return rb["r"], rb["b"]
+            st, loss = run_step(model, lambda: trainer.reinforce_step(frames, reward_fn, lr=learning_rate(cfg, model.global_step), K=K, clip_norm=cfg.clip_norm,
+                                                                      video_base=lo, true_labels=labels[rows] if multitask else None,
+                                                                      sample_seed=cfg.seed + 7919 * (model.global_step + 1)), log)
+            losses.append(loss); adv.append(float(rb["r"].mean() - rb["b"].mean()))
+            log(f"idx: {it * cfg.batch_size} rate: {learning_rate(cfg, model.global_step):g} Epoch: {epoch} loss: {loss:.5f} "
+                f"r: {rb['r'].mean():.4f} b: {rb['b'].mean():.4f} Elapsed time: {time.time() - t0:.3f}")
+        entry = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else None, "advantage": float(np.mean(adv)) if adv else None}
+        if tside is not None:
+            entry.update(evaluate())
+        ck = save_checkpoint_checked(model, cfg, epoch, step_name="Variable", chief=par.chief)
+        if par.chief:
+            entry["checkpoint"] = ck
+            entry["cnn_checkpoint"] = save_cnn(trainer, cfg, epoch)
+        history.append(entry)
+        log(f"Epoch {epoch} is done: {entry}")
+    return trainer, history
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train-sents", required=True); ap.add_argument("--frames", required=True)
@@ -99,13 +202,22 @@ def main():
     ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=16)
     ap.add_argument("--model-path", default="./new_e2e_models")
     ap.add_argument("--freeze-cnn", action="store_true", help="fix_e2e_tf_s2vt.py: no gradient into the CNN")
+    ap.add_argument("--reinforce", action="store_true", help="reinforcement_e2e.py: self-critical REINFORCE through the CNN")
+    ap.add_argument("--samples", type=int, default=1); ap.add_argument("--test-sents")
+    ap.add_argument("--attr-vocab", help="multitask scripts: one attribute word per line"); ap.add_argument("--alpha", type=float, default=0.05)
     a = ap.parse_args()
-    cfg = e2e_config(n_epochs=a.epochs, batch_size=a.batch_size, model_path=a.model_path)
+    cfg = e2e_config(n_epochs=a.epochs, batch_size=a.batch_size, model_path=a.model_path, multisample=a.samples, alpha=a.alpha)
     sents, frames = data.get_video_frame_caption_pair(a.train_sents, a.frames, cfg.n_video_lstm_step)
     variables = None
     if a.cnn_npz:
         with np.load(a.cnn_npz) as z:
             variables = {k: z[k] for k in z.files}
+    if a.reinforce:
+        test = data.get_video_frame_caption_pair(a.test_sents, a.frames, cfg.n_video_lstm_step) if a.test_sents else None
+        attr = [l.strip() for l in open(a.attr_vocab)] if a.attr_vocab else None
+        train_reinforce(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, resume=a.resume, cnn_variables=variables,
+                        attr_vocabulary=attr, test=test)
+        return
     train(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, resume=a.resume, cnn_variables=variables, freeze_cnn=a.freeze_cnn)
 
 

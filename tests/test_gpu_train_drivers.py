@@ -54,6 +54,38 @@ def test_xe_then_rl_drivers(tmp_path):
         assert "s2vt/LSTM1/basic_lstm_cell/weights" in z.files and "Wemb" in z.files
 
 
+@pytest.mark.parametrize("lam", [0.0, 0.5])
+def test_multitask_rl_driver(tmp_path, lam):
+    """train_rl.train(attr_vocabulary=...): the multitask scripts on precomputed features (BASELINE configs[3]) -- bag-of-words labels from the
+    corpus' own captions, the attribute head's term in the objective (lambda_loss = 0: reinforce_multitask_e2e_attribute_loss.py:957; 0.5: the XE mix of
+    ..._attribute_s2vt.py:850), the multilabel metrics of the test loop per epoch, attr_W / attr_b in the checkpoint."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import s2vt_amd
+    from s2vt_amd import hostglue, train_common as tc, train_rl
+    rng = np.random.default_rng(0)
+    sents, feats, vocab = _corpus(tmp_path, "train", rng)
+    corpus = tc.Corpus(sents, feats, vocabulary=vocab)
+    attrs = ["man", "woman", "dog", "cat", "guitar", "ball", "food", "zebra"]
+    cfg = train_rl.rl_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=12, batch_size=8,
+                             multisample=2, start_learning_rate=2e-2, model_path=str(tmp_path / "m"), model_name="mt", alpha=0.5, lambda_loss=lam)
+    model, hist = train_rl.train(cfg, corpus, corpus, log=lambda *_: None, attr_vocabulary=attrs)
+    assert model.label_dim == 8 and np.isfinite(hist[-1]["loss"]) and hist[-1]["ciderD"] is not None
+    # the head learns the corpus' attributes (each is a function of one feature column): scores against the labels get_multilabel forms
+    lab = hostglue.get_multilabel(corpus.index.by_video, attrs)
+    y = np.stack([lab[v] for v in corpus.index.video_ids])
+    assert y[:, 7].sum() == 0 and y[:, :4].sum(1).tolist() == [1] * 12
+    sc = model.attribute_scores(corpus.features.batch(corpus.index.video_ids)).cpu().numpy()
+    m = hist[-1]["multilabel"]
+    assert (m["true_positive"], m["true_negative"], m["false_positive"], m["false_negative"]) == hostglue.get_metrics(sc, y, 0.5)[:4]
+    assert m["true_positive"] + m["false_negative"] == int(y.sum()) and m["f1_score"] > 0.8 and m["f1_score"] > hist[0]["multilabel"].get("f1_score", 0.0)
+    if lam > 0:                                                          # the XE term teaches the captions too
+        assert hist[-1]["ciderD"] > 0.5
+    with np.load(hist[-1]["checkpoint"]) as z:
+        assert "attr_W" in z.files and "attr_b" in z.files and "attr_W/Adam" in z.files
+
+
 def test_attention_driver(tmp_path):
     """train_attention.train (original_attention.py's train(), :383-520) on the synthetic corpus: the loss falls, greedy evaluation scores,
     the checkpoint carries the TF variable names and resumes."""
@@ -109,6 +141,55 @@ def test_e2e_driver_frames_to_checkpoint(tmp_path):
     assert os.path.exists(hist[-1]["checkpoint"]) and os.path.exists(hist[-1]["cnn_checkpoint"])
     g = trainer.generate(torch.from_numpy(data.image_reading_processing([frames["vid0"], frames["vid1"]], 24, 24)))
     assert g.shape == (2, 8)
+
+
+def test_e2e_reinforce_driver(tmp_path):
+    """train_e2e.train_reinforce (reinforcement_e2e.py's loop; with attr_vocabulary the multitask scripts'): frames -> one CNN forward -> sampled +
+    greedy captions -> host CIDEr-D -> policy gradient through the CNN; after an XE warm start the greedy CIDEr-D holds up, the attribute head learns
+    the colour words, the CNN moves, both checkpoints are written."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from PIL import Image
+    import s2vt_amd
+    from s2vt_amd import data, train_e2e
+    rng = np.random.default_rng(1)
+    vocab = ["<en_unk>", "a", "red", "green", "blue", "square", "is", "shown"]
+    colours = {"red": (220, 30, 30), "green": (30, 220, 30), "blue": (30, 30, 220)}
+    sent = tmp_path / "sents.txt"
+    with open(sent, "w") as f:
+        for v in range(9):
+            name = list(colours)[v % 3]
+            os.makedirs(tmp_path / "frames" / f"vid{v}")
+            for k in range(1, 9):
+                img = np.clip(np.asarray(colours[name])[None, None, :] + rng.integers(-20, 20, (24, 24, 3)), 0, 255).astype(np.uint8)
+                Image.fromarray(img).save(tmp_path / "frames" / f"vid{v}" / f"{k:06d}.jpg")
+            f.write(f"vid{v}\ta {name} square is shown\nvid{v}\ta {name} square\n")
+    sents, frames = data.get_video_frame_caption_pair(str(sent), str(tmp_path / "frames"), 3)
+    torch.manual_seed(0)
+    cnn = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, stride=2), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
+                              torch.nn.Linear(8, 24), torch.nn.ReLU())
+    quiet = lambda *_: None
+    xe = train_e2e.e2e_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=10, batch_size=6,
+                              start_learning_rate=2e-2, model_path=str(tmp_path / "m"))
+    trainer, hist = train_e2e.train(xe, sents, frames, vocab, cnn=cnn, width=24, height=24, log=quiet)
+    theta0 = trainer.theta.clone()
+    rl = train_e2e.e2e_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=10, batch_size=6, multisample=2,
+                              start_learning_rate=1e-2, model_path=str(tmp_path / "m"), model_name="e2e_rl", alpha=0.5)
+    attrs = ["red", "green", "blue", "zebra"]
+    trainer2, hist2 = train_e2e.train_reinforce(rl, sents, frames, vocab, cnn=cnn, width=24, height=24, log=quiet, restore=hist[-1]["checkpoint"],
+                                                attr_vocabulary=attrs, test=(sents, frames))
+    assert trainer2.model.label_dim == 4 and all(np.isfinite(h["loss"]) for h in hist2)
+    assert hist2[-1]["ciderD"] is not None and hist2[-1]["ciderD"] > 0.3
+    m = hist2[-1]["multilabel"]
+    assert m["true_positive"] + m["false_negative"] == 9 and m["true_negative"] + m["false_positive"] == 27
+    vids = list(dict.fromkeys(sents[:, 0].tolist()))
+    sc = trainer2.evaluate_multilabel(torch.from_numpy(data.image_reading_processing([frames[v] for v in vids], 24, 24))).cpu().numpy()
+    assert (sc[:, :3].argmax(1) == np.arange(9) % 3).sum() >= 7 and (sc[:, 3] < 0.5).all() and m["true_positive"] >= 6      # the head ranks the video's own colour first
+    assert float((trainer2.theta - theta0).abs().max()) > 0               # the policy gradient reached the CNN
+    assert os.path.exists(hist2[-1]["checkpoint"]) and os.path.exists(hist2[-1]["cnn_checkpoint"])
+    with np.load(hist2[-1]["checkpoint"]) as z:
+        assert "attr_W" in z.files
 
 
 def test_checkpoint_resume_continues_adam_and_counters(tmp_path):
