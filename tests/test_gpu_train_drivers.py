@@ -263,7 +263,13 @@ tmp, out, which = sys.argv[1], sys.argv[2], sys.argv[3]
 rank = int(os.environ.get("RANK", "0"))
 corpus = tc.Corpus(os.path.join(tmp, "train_sents.txt"), os.path.join(tmp, "train_feat.txt"), vocabulary=eval(open(os.path.join(tmp, "vocab.txt")).read()))
 quiet = lambda *_: None
-if which == "rl":
+if which.startswith("multitask"):      # the multitask scripts' objective through train_rl (attribute labels sharded with the videos; lambda > 0: the XE mix)
+    cfg = train_rl.rl_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=1, batch_size=8,
+                             multisample=2, start_learning_rate=1e-2, max_steps_per_epoch=3, model_path=os.path.join(tmp, "m%d" % rank), model_name="mt",
+                             alpha=0.3, lambda_loss=0.5 if which == "multitask_mixed" else 0.0)
+    model, hist = train_rl.train(cfg, corpus, corpus, log=quiet, attr_vocabulary=["man", "woman", "dog", "cat", "guitar", "ball", "food"])
+    assert "multilabel" in hist[-1] or rank != 0
+elif which == "rl":
     cfg = train_rl.rl_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=1, batch_size=8,
                              multisample=3, start_learning_rate=1e-2, max_steps_per_epoch=3, model_path=os.path.join(tmp, "m%d" % rank), model_name="rl")
     model, hist = train_rl.train(cfg, corpus, corpus, log=quiet)
@@ -285,7 +291,7 @@ print("child ok", rank)
 """
 
 
-@pytest.mark.parametrize("which", ["rl", "xe"])
+@pytest.mark.parametrize("which", ["rl", "xe", "multitask", "multitask_mixed"])
 def test_data_parallel_drivers_two_ranks_equal_one(tmp_path, which):
     """train_rl.train / train_xe.train under two ranks (each B/2 of every shuffled global batch, both on this box's one GPU,
     collective over gloo -- the product's RCCL path differs only in the all_reduce call) for 3 steps end in the variables
