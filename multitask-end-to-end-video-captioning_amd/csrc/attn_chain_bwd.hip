@@ -643,6 +643,8 @@ hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st)
     z.add(a.sync, syncb); z.add(a.img, imgf * 4);              // (rows >= B and k >= H of the images must read as zeros)
     hipError_t e = launch_zero_regions(z, st);
     if (e != hipSuccess) return e;
+    e = chain_gate_zeroed(st);                                 // (gated overlap: a side stream may poll the counters from here on)
+    if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((ncg + 7) / 8 * 32));
     const double flops = (2.0 * a.B * (double)(2 * a.H) * 4.0 * a.H + 2.0 * a.B * (double)a.H * a.H) * a.T;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -658,6 +660,8 @@ hipError_t launch_attn_bwd_chain(const AttnBwdChainLaunch& a, hipStream_t st)
         prof_record(10, ci, kABCfg[ci].name, flops, e0, e1);
     }
     e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = chain_gate_launched(a.sync, 4u * (unsigned)ncg);       // every active workgroup arrives at the dz hand-off once per iteration
     if (e != hipSuccess) return e;
     e = order.after(st, hst.device);
     if (e != hipSuccess) return e;

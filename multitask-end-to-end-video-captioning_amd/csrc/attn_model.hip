@@ -16,6 +16,8 @@
 
 #include <cstring>
 
+#include <mutex>
+
 #include "api_util.h"
 #include "detmath.h"
 
@@ -382,28 +384,41 @@ int s2vt_attn_bptt_bwd(const s2vt_dims* d, const s2vt_attn_params* p, const s2vt
     const size_t BH = (size_t)B * H;
     const int R = Tc * B, R1 = (Tc - 1) * B;
 
+    const bool persistent = attn_bwd_chain_eligible(B, H, Tv) && !chain_fault() && !(reinterpret_cast<uintptr_t>(p->lstm3_W) & 15) &&
+                            !(reinterpret_cast<uintptr_t>(p->embed_att_Wa) & 15);
+    // Gated overlap (S2VT_OVERLAP=0 switches it off): the weight gradients of the vocabulary projection and of the output layer feed
+    // nothing in the recurrence -- with the persistent backward recurrence they are launched on the side stream once its grid is resident and
+    // run BESIDE it (a one-wave-per-SIMD grid that waits in hand-offs more than half of its time), joined at the end of the call.
+    // Measured (bench.py --workload attention / attention32, S2VT_OVERLAP=0 against 2, twice each): Tv = 5: 2.63 -> 2.57 ms per step; Tv = 32: 3.25 -> 3.27.
+    // This recurrence holds 150 KB of LDS per CU, so the LDS-staged contractions cannot share a CU with it (as they do with the LSTM recurrences'
+    // 64 KB): they fill the CUs its workgroups leave at the end and run beside the launches that follow it.  On for the register-frames form only.
+    SideStream& ss = side_stream();
+    const bool gated = ss.ok && ss.mode == 2 && persistent && Tv <= 5;
+    std::unique_lock<std::mutex> side_lk(side_stream_mutex(), std::defer_lock);
+    if (gated) side_lk.lock();
+    ChainGate gate{ss.s, ss.ev[3], false};
     // ---- vocabulary projection: dWout, dbout, d(output layer)
-    {
-        TnArgs a{w.Y, nullptr, H, dlogits, V, grads->embed_word_W, V, R, H, V, 1};
-        a.colsum = grads->embed_word_b;
-        HIP_TRY(launch_gemm_tn(a, st));
-    }
+    TnArgs dwout{w.Y, nullptr, H, dlogits, V, grads->embed_word_W, V, R, H, V, 1};
+    dwout.colsum = grads->embed_word_b;
+    if (!gated) HIP_TRY(launch_gemm_tn(dwout, st));
     HIP_TRY(nn_bwd_slabs(dlogits, V, p->embed_word_W, V, w.dY, H, R, H, V, w.bslab, st, w.bslab_floats));
     hipLaunchKernelGGL(attn_tanh_bwd_kernel, dim3((unsigned)(((size_t)R * H / 4 + 255) / 256)), dim3(256), 0, st, w.dY, w.Y, (size_t)R * H / 4);
     HIP_TRY(hipGetLastError());
     // ---- output layer: Wp rows [output1 ; atten ; current_embed], its bias, and d[out | ctx | emb] for every step at once
-    {
+    auto output_layer_grads = [&](hipStream_t s) -> int {
         TnArgs a{w.O3 + BH, nullptr, H, w.dY, H, grads->embed_nn_Wp, H, R, H, H, 1};
         a.colsum = grads->embed_nn_bp;
-        HIP_TRY(launch_gemm_tn(a, st));
+        HIP_TRY(launch_gemm_tn(a, s));
         TnArgs b{w.ctx, nullptr, H, w.dY, H, grads->embed_nn_Wp + (size_t)H * H, H, R, H, H, 1};
-        HIP_TRY(launch_gemm_tn(b, st));
+        HIP_TRY(launch_gemm_tn(b, s));
         if (Tc > 1) {
             TnArgs e{p->Wemb, w.prev + B, H, w.dY + BH, H, grads->embed_nn_Wp + (size_t)2 * H * H, H, R1, H, H, 1};
             e.gather_rows = V;
-            HIP_TRY(launch_gemm_tn(e, st));
+            HIP_TRY(launch_gemm_tn(e, s));
         }
-    }
+        return S2VT_OK;
+    };
+    if (!gated) { const int rc = output_layer_grads(st); if (rc != S2VT_OK) return rc; }
     HIP_TRY(nn_bwd_slabs(w.dY, H, p->embed_nn_Wp, H, w.dcat, 3 * H, R, 3 * H, H, w.bslab, st, w.bslab_floats));
     {
         ZeroList z;
@@ -411,7 +426,7 @@ int s2vt_attn_bptt_bwd(const s2vt_dims* d, const s2vt_attn_params* p, const s2vt
         HIP_TRY(launch_zero_regions(z, st));
     }
     // ---- the recurrence, back through time
-    if (attn_bwd_chain_eligible(B, H, Tv) && !chain_fault() && !(reinterpret_cast<uintptr_t>(p->lstm3_W) & 15) && !(reinterpret_cast<uintptr_t>(p->embed_att_Wa) & 15)) {
+    if (persistent) {
         // ONE persistent launch: cell backward, dz @ [W3 h rows ; W3 context rows]^T, attention backward, dhWa @ Wa^T, all Tc steps
         AttnBwdChainLaunch a;
         std::memset(&a, 0, sizeof(a));
@@ -426,7 +441,18 @@ int s2vt_attn_bptt_bwd(const s2vt_dims* d, const s2vt_attn_params* p, const s2vt
         a.keep = keep; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.drop_code0 = kDropCode3;
         a.video_id = video_id; a.sample_id = sample_id;
         a.img = w.bimg; a.ex = w.bex; a.dctxs = w.brow_; a.sync = w.bsync;
-        HIP_TRY(launch_attn_bwd_chain(a, st));
+        if (gated) chain_gate_arm(&gate);
+        const hipError_t re = launch_attn_bwd_chain(a, st);
+        chain_gate_arm(nullptr);
+        HIP_TRY(re);
+        if (gated) {
+            // (reads: dlogits, Y, dY, O3, ctx, Wemb -- final since before the launch; writes: the gradients of embed_word_W/b and embed_nn_Wp/bp,
+            //  which nothing else in this call touches.  A gate that did not fire -- a zero-step launch -- puts the side stream behind the caller's)
+            if (!gate.fired) HIP_TRY(fork_to(st, ss.s, ss.ev[3]));
+            HIP_TRY(launch_gemm_tn(dwout, ss.s));
+            const int rc = output_layer_grads(ss.s);
+            if (rc != S2VT_OK) return rc;
+        }
         // the embedding block of dz @ W3^T does not feed the recurrence: all steps >= 1 at once, on top of the output layer's block
         if (Tc > 1) {
             ASeg sz = make_seg(w.dZ3 + 4 * BH, 4 * H, 4 * H, 0);
@@ -499,6 +525,7 @@ int s2vt_attn_bptt_bwd(const s2vt_dims* d, const s2vt_attn_params* p, const s2vt
         v.colsum = grads->encode_image_b;
         HIP_TRY(launch_gemm_tn(v, st));
     }
+    if (gated) HIP_TRY(fork_to(ss.s, st, ss.ev[2]));        // join: the caller's stream waits for the side stream's gradients
     return S2VT_OK;
 }
 

@@ -13,6 +13,46 @@
 
 using namespace s2vt_api;
 
+namespace s2vt_api {
+// An optional second stream for the backward pass: the recurrences (25 dependent steps of small kernels, ~half the
+// matrix pipes idle) run on the caller's stream while weight-gradient contractions that do not depend on them
+// run here, forked / joined with events so the call keeps its stream semantics.  Created once per process.
+// (mode 1: S2VT_OVERLAP=1, ungated, below; 2: gated overlap with the persistent backward recurrences, round 5)
+SideStream& side_stream()
+{
+    static SideStream ss = [] {
+        SideStream t;
+        // Opt-in (S2VT_OVERLAP=1).  Measured on MI355X: the two streams do run concurrently, but the kernels
+        // only slow each other down (TN 724 -> 1462 us, slab GEMM 28 -> 46 us per launch) for a net 0.1 ms of
+        // 15.6, and per-launch durations stop meaning anything for the roofline, so one stream is the default.
+        // Mode 2 (round 5, the default; S2VT_OVERLAP=0 switches it off): the weight-gradient contractions that do not feed a recurrence run
+        // on the side stream BESIDE the persistent backward recurrence they are independent of -- dWout beside LSTM2's, LSTM2's three beside
+        // LSTM1's -- released by a gate once the recurrence's grid is resident (internal.h ChainGate).  A persistent recurrence at <= 256 rows
+        // is one wave per SIMD at <= 380 VGPRs that waits in hand-offs half the time; the contraction fills the other half of the pipe.
+        const char* on = getenv("S2VT_OVERLAP");
+        t.mode = on ? atoi(on) : 2;
+        if (t.mode < 1 || t.mode > 2) { t.mode = 0; return t; }
+        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return t;
+        for (auto& e : t.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return t;
+        t.ok = true;
+        return t;
+    }();
+    return ss;
+}
+// side waits for everything issued so far on `from`
+hipError_t fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev)
+{
+    hipError_t e = hipEventRecord(ev, from);
+    return e != hipSuccess ? e : hipStreamWaitEvent(to, ev, 0);
+}
+std::mutex& side_stream_mutex()
+{
+    static std::mutex mu;
+    return mu;
+}
+}  // namespace s2vt_api
+
 namespace {
 
 __global__ void enc_index_kernel(int32_t* idx, int B, int Tv)
@@ -144,44 +184,6 @@ size_t carve_train(Carver& c, const s2vt_dims* d, int B, int N, TrainWs* out)
     }
     if (out) *out = w;
     return c.off;
-}
-
-// An optional second stream for the backward pass: the recurrences (25 dependent steps of small kernels, ~half the
-// matrix pipes idle) run on the caller's stream while weight-gradient contractions that do not depend on them
-// run here, forked / joined with events so the call keeps its stream semantics.  Created once per process.
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ok = false;
-    int mode = 0;          // 1: S2VT_OVERLAP=1 (ungated, below); 2: gated overlap with the persistent backward recurrences (round 5)
-};
-SideStream& side_stream()
-{
-    static SideStream ss = [] {
-        SideStream t;
-        // Opt-in (S2VT_OVERLAP=1).  Measured on MI355X: the two streams do run concurrently, but the kernels
-        // only slow each other down (TN 724 -> 1462 us, slab GEMM 28 -> 46 us per launch) for a net 0.1 ms of
-        // 15.6, and per-launch durations stop meaning anything for the roofline, so one stream is the default.
-        // Mode 2 (round 5, the default; S2VT_OVERLAP=0 switches it off): the weight-gradient contractions that do not feed a recurrence run
-        // on the side stream BESIDE the persistent backward recurrence they are independent of -- dWout beside LSTM2's, LSTM2's three beside
-        // LSTM1's -- released by a gate once the recurrence's grid is resident (internal.h ChainGate).  A persistent recurrence at <= 256 rows
-        // is one wave per SIMD at <= 380 VGPRs that waits in hand-offs half the time; the contraction fills the other half of the pipe.
-        const char* on = getenv("S2VT_OVERLAP");
-        t.mode = on ? atoi(on) : 2;
-        if (t.mode < 1 || t.mode > 2) { t.mode = 0; return t; }
-        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return t;
-        for (auto& e : t.ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return t;
-        t.ok = true;
-        return t;
-    }();
-    return ss;
-}
-// side waits for everything issued so far on `from`
-hipError_t fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev)
-{
-    hipError_t e = hipEventRecord(ev, from);
-    return e != hipSuccess ? e : hipStreamWaitEvent(to, ev, 0);
 }
 
 bool params_ok(const s2vt_params* p)
@@ -579,8 +581,7 @@ int s2vt_bptt_bwd_live(const s2vt_dims* d, const s2vt_params* p, const s2vt_para
     // The side stream and its events are ONE per process: two host threads driving distinct workspaces must not interleave their
     // record / wait pairs (a wait enqueued after the OTHER thread's record of the same event would order this call's side work behind
     // the wrong point).  The lock covers this call's enqueueing only -- the launches themselves are asynchronous as ever.
-    static std::mutex side_mu;
-    std::unique_lock<std::mutex> side_lk(side_mu, std::defer_lock);
+    std::unique_lock<std::mutex> side_lk(side_stream_mutex(), std::defer_lock);
     if (side_on) side_lk.lock();
     ChainGate gate{ss.s, ss.ev[3], false};
     TnArgs dwout;                                            // (mode 2: the vocabulary projection's weight gradient is launched behind LSTM2's recurrence)

@@ -1,4 +1,4 @@
-"""Gated overlap (csrc/train.hip, S2VT_OVERLAP=2, the default): at <= 256 unrolled rows the weight-gradient contractions that do not feed a
+"""Gated overlap (csrc/train.hip and attn_model.hip, S2VT_OVERLAP=2, the default): at <= 256 unrolled rows the weight-gradient contractions that do not feed a
 recurrence -- dWout beside LSTM2's backward recurrence, LSTM2's three beside LSTM1's -- run on a side stream, released by a gate once the
 persistent grid is resident.  Same kernels, same operands, another ORDER of launches on two queues: the gradients must equal the single-stream
 one (S2VT_OVERLAP=0) up to the order-free reductions' noise (split-K atomics), with no grid-wide wait timing out, also when the step is
@@ -37,6 +37,18 @@ for (B, K, V, H, E, Tc) in ((64, 0, 3000, 1000, 500, 8), (32, 1, 2000, 1000, 500
             st = mdl.mixed_update(video, s, sm, r, b, cap, mask, lr=0.0, lambda_loss=0.5) if K == 1 else mdl.reinforce_update(video, s, sm, r, b, lr=0.0)
     torch.cuda.synchronize()
     out[f"theta_{B}_{K}"] = mdl.store.grad[:mdl.store.numel].cpu().numpy(); out[f"loss_{B}_{K}"] = np.asarray(float(st.loss)); out[f"gn_{B}_{K}"] = np.asarray(float(st.grad_sumsq))
+# the temporal-attention captioner (attn_model.hip): dWout and the output layer's three weight gradients behind the persistent backward recurrence (Tv <= 5)
+from s2vt_amd import attention as A
+for (B, Tv, V, H, Tc) in ((64, 5, 3000, 1000, 8), (16, 3, 500, 64, 5)):
+    am = A.Attention_Caption_Generator(128, V, H, B, Tv, Tc, 0.9, seed=5)
+    rng = np.random.default_rng(100 + B)
+    video = torch.as_tensor(np.abs(rng.standard_normal((B, Tv, 128)) * 0.5).astype(np.float32)).cuda()
+    cap = rng.integers(2, V, (B, Tc)).astype(np.int32); cap[:, -1] = 0
+    mask = hostglue.masks_from_ids(cap)
+    for rep in range(3):
+        st = am.xe_update(video, cap, mask, lr=0.0, keep=0.9)
+    torch.cuda.synchronize()
+    out[f"theta_att_{B}"] = am.store.grad[:am.store.numel].cpu().numpy(); out[f"loss_att_{B}"] = np.asarray(float(st.loss)); out[f"gn_att_{B}"] = np.asarray(float(st.grad_sumsq))
 out["timeouts"] = np.asarray(ops.chain_timeouts())
 np.savez(sys.argv[1], **out)
 print("child ok")
