@@ -27,6 +27,25 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def exec_module(self, module):
         pass
 
+    # `python -m s2vt_amd.train_rl` (runpy): the code of the real module, run as __main__ with __package__ = "s2vt_amd" -- its relative
+    # imports come back through this finder and resolve to the one real module object each
+    def _real_spec(self, fullname):
+        return importlib.util.find_spec(_REAL + fullname[len(_ALIAS):])
+
+    def get_code(self, fullname):
+        spec = self._real_spec(fullname)
+        return spec.loader.get_code(spec.name)
+
+    def get_source(self, fullname):
+        spec = self._real_spec(fullname)
+        return spec.loader.get_source(spec.name)
+
+    def get_filename(self, fullname):
+        return self._real_spec(fullname).origin
+
+    def is_package(self, fullname):
+        return self._real_spec(fullname).submodule_search_locations is not None
+
 
 if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
     sys.meta_path.insert(0, _AliasFinder())

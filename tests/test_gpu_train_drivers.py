@@ -328,3 +328,58 @@ def test_data_parallel_drivers_two_ranks_equal_one(tmp_path, which):
     a, b = outs[1], outs[2]
     assert np.abs(a[:-1] - b[:-1]).max() <= 5e-4, np.abs(a[:-1] - b[:-1]).max()     # 3 Adam steps at lr 1e-2: a wrong exchange moves entries by ~1e-2
     assert abs(a[-1] - b[-1]) <= 0.05 * max(1.0, abs(a[-1]))                          # CIDEr-D of the greedy captions, averaged over all videos
+
+
+@pytest.mark.parametrize("mod", ["train_xe", "train_attention"])
+def test_command_lines_xe_and_attention(tmp_path, mod):
+    """`python -m s2vt_amd.train_xe ...` / `train_attention ...` as INTEGRATION.md gives them, at the scripts' own model dimensions."""
+    import glob
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sents, feats, vocab = _corpus(tmp_path, "train", np.random.default_rng(0), n_videos=12, d=1536, tv=5)
+    open(tmp_path / "vocab.txt", "w").write("\n".join(vocab) + "\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "s2vt_amd." + mod, "--train-sents", sents, "--train-feats", feats, "--test-sents", sents, "--test-feats", feats,
+           "--vocab", str(tmp_path / "vocab.txt"), "--epochs", "2", "--batch-size", "8", "--model-path", str(tmp_path / "m")]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "Epoch 1 is done" in r.stdout and glob.glob(str(tmp_path / "m" / "*"))
+
+
+@pytest.mark.parametrize("launcher", ["python", "torchrun2"])
+def test_command_lines_of_integration_md(tmp_path, launcher):
+    """The command lines INTEGRATION.md gives: `python -m s2vt_amd.train_rl ...` (through the import alias: runpy needs the alias loader's get_code)
+    and the same under `python -m torch.distributed.run --nproc-per-node 2 -m s2vt_amd.train_rl ...` (both ranks on this box's one GPU: gloo),
+    at the scripts' own model dimensions, with the multitask flags: a checkpoint with the attribute head comes out, written by rank 0 alone."""
+    import glob
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    sents, feats, vocab = _corpus(tmp_path, "train", rng, n_videos=12, d=1536, tv=5)
+    open(tmp_path / "vocab.txt", "w").write("\n".join(vocab) + "\n")
+    open(tmp_path / "attrs.txt", "w").write("\n".join(["man", "woman", "dog", "cat", "guitar"]) + "\n")
+    args = ["-m", "s2vt_amd.train_rl", "--train-sents", sents, "--train-feats", feats, "--test-sents", sents, "--test-feats", feats, "--vocab", str(tmp_path / "vocab.txt"),
+            "--epochs", "1", "--batch-size", "8", "--samples", "2", "--model-path", str(tmp_path / "m"), "--attr-vocab", str(tmp_path / "attrs.txt"), "--lambda-loss", "0.5"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    if launcher == "python":
+        cmd = [sys.executable] + args
+    else:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env["S2VT_DIST_BACKEND"] = "gloo"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "Epoch 0 is done" in r.stdout and "multilabel" in r.stdout and r.stdout.count("Epoch 0 is done") == 1        # rank 0 alone logs
+    cks = glob.glob(str(tmp_path / "m" / "*"))
+    assert cks, "no checkpoint written"

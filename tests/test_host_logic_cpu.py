@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: the sess.run shim's evaluation order, checkpoints under the TF variable names with the
 Adam slots tf.train.Saver keeps, the JSONL step log, the data-parallel switches."""
 import json
+import os
 
 import numpy as np
 import torch
@@ -327,3 +328,13 @@ def test_bench_workload_table_and_profile_keys():
     # a stamped summary of another build is not this build's: the lookup says None rather than lend a stale figure
     t, src = bench.stored_traffic(3, "no-such-tile", "rl")
     assert t is None and src is None
+
+
+def test_python_dash_m_runs_the_drivers_through_the_import_alias():
+    """`python -m s2vt_amd.train_rl` (INTEGRATION.md's command lines): runpy asks the alias loader for the module's code; --help needs no GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mod, flag in (("train_rl", "--attr-vocab"), ("train_xe", "--train-sents"), ("train_e2e", "--reinforce"), ("train_attention", "--frames")):
+        r = subprocess.run([sys.executable, "-m", "s2vt_amd." + mod, "--help"], cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and flag in r.stdout, (mod, r.stderr[-1500:])
