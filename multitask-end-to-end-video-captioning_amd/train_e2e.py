@@ -206,7 +206,8 @@ def main():
     ap.add_argument("--samples", type=int, default=1); ap.add_argument("--test-sents")
     ap.add_argument("--attr-vocab", help="multitask scripts: one attribute word per line"); ap.add_argument("--alpha", type=float, default=0.05)
     a = ap.parse_args()
-    cfg = e2e_config(n_epochs=a.epochs, batch_size=a.batch_size, model_path=a.model_path, multisample=a.samples, alpha=a.alpha)
+    cfg = e2e_config(n_epochs=a.epochs, batch_size=a.batch_size, model_path=a.model_path, multisample=a.samples, alpha=a.alpha,
+                     **({"model_name": "e2e_reinforce_model"} if a.reinforce else {}))       # (its own files beside the XE run's in one --model-path)
     sents, frames = data.get_video_frame_caption_pair(a.train_sents, a.frames, cfg.n_video_lstm_step)
     variables = None
     if a.cnn_npz:
