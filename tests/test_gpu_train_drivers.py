@@ -383,3 +383,78 @@ def test_command_lines_of_integration_md(tmp_path, launcher):
     assert "Epoch 0 is done" in r.stdout and "multilabel" in r.stdout and r.stdout.count("Epoch 0 is done") == 1        # rank 0 alone logs
     cks = glob.glob(str(tmp_path / "m" / "*"))
     assert cks, "no checkpoint written"
+
+
+CHILD_DP_E2E_RL = r"""
+import os, sys
+sys.path.insert(0, os.environ["S2VT_ROOT"])
+import numpy as np, torch
+import s2vt_amd
+from s2vt_amd import data, train_e2e
+tmp, out = sys.argv[1], sys.argv[2]
+rank = int(os.environ.get("RANK", "0"))
+vocab = ["<en_unk>", "a", "red", "green", "blue", "square", "is", "shown"]
+sents, frames = data.get_video_frame_caption_pair(os.path.join(tmp, "sents.txt"), os.path.join(tmp, "frames"), 3)
+torch.manual_seed(0)
+cnn = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, stride=2), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(8, 24), torch.nn.ReLU())
+cfg = train_e2e.e2e_config(dim_image=24, lstm_dim=32, word_dim=16, n_video_lstm_step=3, n_caption_lstm_step=8, n_epochs=1, batch_size=8, multisample=2,
+                           start_learning_rate=1e-2, max_steps_per_epoch=2, model_path=os.path.join(tmp, "m%d" % rank), alpha=0.3)
+trainer, hist = train_e2e.train_reinforce(cfg, sents, frames, vocab, cnn=cnn, width=24, height=24, log=lambda *_: None,
+                                          attr_vocabulary=["red", "green", "blue"], test=(sents, frames))
+torch.cuda.synchronize()
+assert trainer.model.global_step == 2
+if rank == 0:
+    m = hist[-1]["multilabel"]
+    np.save(out, np.concatenate([trainer.model.store.theta.cpu().numpy(), trainer.theta.cpu().numpy(),
+                                 [hist[-1]["ciderD"], m["true_positive"], m["true_negative"], m["false_positive"], m["false_negative"]]]))
+    assert os.path.exists(hist[-1]["checkpoint"]) and os.path.exists(hist[-1]["cnn_checkpoint"])
+else:
+    assert "checkpoint" not in hist[-1]
+import torch.distributed as dist
+if dist.is_initialized():
+    dist.barrier(); dist.destroy_process_group()
+print("child ok", rank)
+"""
+
+
+def test_e2e_reinforce_driver_two_ranks_equal_one(tmp_path):
+    """train_e2e.train_reinforce under two ranks (each B/2 videos of every global batch; gloo, one GPU) == one rank after 2 steps -- captioner AND CNN
+    variables -- and the evaluation (greedy CIDEr-D, multilabel confusion counts) is summed over both ranks' videos."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(1)
+    colours = {"red": (220, 30, 30), "green": (30, 220, 30), "blue": (30, 30, 220)}
+    with open(tmp_path / "sents.txt", "w") as f:
+        for v in range(10):
+            name = list(colours)[v % 3]
+            os.makedirs(tmp_path / "frames" / f"vid{v}")
+            for k in range(1, 9):
+                img = np.clip(np.asarray(colours[name])[None, None, :] + rng.integers(-20, 20, (24, 24, 3)), 0, 255).astype(np.uint8)
+                Image.fromarray(img).save(tmp_path / "frames" / f"vid{v}" / f"{k:06d}.jpg")
+            f.write(f"vid{v}\ta {name} square is shown\nvid{v}\ta {name} square\n")
+    outs = {}
+    for world in (1, 2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        out = str(tmp_path / f"w{world}.npy")
+        base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        base.update(S2VT_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), S2VT_DIST_BACKEND="gloo")
+        ps = []
+        for rk in range(world):
+            env = dict(base)
+            if world > 1:
+                env.update(RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(world))
+            ps.append(subprocess.Popen([sys.executable, "-c", CHILD_DP_E2E_RL, str(tmp_path), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        for p in ps:
+            so, se = p.communicate(timeout=600)
+            assert p.returncode == 0 and "child ok" in so, f"rc={p.returncode}\n{so[-2000:]}\n{se[-4000:]}"
+        outs[world] = np.load(out)
+    a, b = outs[1], outs[2]
+    assert np.abs(a[:-5] - b[:-5]).max() <= 5e-4, np.abs(a[:-5] - b[:-5]).max()
+    assert a[-4:].sum() == 30 and b[-4:].sum() == 30                    # 10 videos x 3 attributes, every one counted once
+    assert abs(a[-5] - b[-5]) <= 0.05 * max(1.0, abs(a[-5]))
