@@ -603,6 +603,18 @@ class Video_Caption_Generator:
             raise S2VTChainTimeout("a persistent LSTM recurrence timed out (is another process running persistent kernels on this GPU?); "
                                    "the variables are intact: call recover() and repeat the step")
 
+    def state_dict(self, with_optimizer=True, step_name="g_step"):
+        """Variables under the reference's TF names (+ Adam slots, beta powers, the step counter with with_optimizer): store.state_dict with this
+        model's counters -- the same two methods attention.Attention_Caption_Generator has."""
+        return self.store.state_dict(self.global_step if with_optimizer else None, self.adam_t, step_name=step_name)
+
+    def load_state_dict(self, sd):
+        loaded = self.store.load_state_dict(sd)
+        if self.store.restored_step is not None:
+            self.global_step = self.store.restored_step
+            self.adam_t = self.store.restored_adam_t if self.store.restored_adam_t is not None else self.global_step
+        return loaded
+
     def recover(self, disable_persistent=True):
         """After S2VTChainTimeout: synchronise, learn from the device which update was the last one APPLIED (updates behind
         the fault were skipped), rewind the host-side step counter to it, acknowledge the fault and (default) switch the

@@ -458,3 +458,23 @@ def test_e2e_reinforce_driver_two_ranks_equal_one(tmp_path):
     assert np.abs(a[:-5] - b[:-5]).max() <= 5e-4, np.abs(a[:-5] - b[:-5]).max()
     assert a[-4:].sum() == 30 and b[-4:].sum() == 30                    # 10 videos x 3 attributes, every one counted once
     assert abs(a[-5] - b[-5]) <= 0.05 * max(1.0, abs(a[-5]))
+
+
+def test_model_state_dict_round_trip(gpu):
+    """Video_Caption_Generator.state_dict() / load_state_dict() (the two methods the attention class has): TF variable names, Adam slots and both
+    counters survive the round trip into a fresh model."""
+    import torch
+    from s2vt_amd import hostglue, model as M
+    a = M.Video_Caption_Generator(24, 50, 12, 20, 4, 0, 3, 6, seed=1)
+    rng = np.random.default_rng(0)
+    video = np.abs(rng.standard_normal((4, 3, 24))).astype(np.float32)
+    cap = rng.integers(1, 50, (4, 6)).astype(np.int32); cap[:, -1] = 0
+    for _ in range(3):
+        a.xe_update(video, cap, hostglue.masks_from_ids(cap), lr=1e-2)
+    sd = a.state_dict()
+    assert "s2vt/LSTM1/basic_lstm_cell/weights" in sd and "Wemb/Adam_1" in sd and int(sd["g_step"]) == 3
+    b = M.Video_Caption_Generator(24, 50, 12, 20, 4, 0, 3, 6, seed=2)
+    b.load_state_dict(sd)
+    assert b.global_step == 3 and b.adam_t == 3
+    assert torch.equal(a.store.theta, b.store.theta) and torch.equal(a.store.m, b.store.m) and torch.equal(a.store.v, b.store.v)
+    assert set(a.state_dict(with_optimizer=False)) == {a.store.tf_names[n] for n in a.store.names}
