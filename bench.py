@@ -24,7 +24,9 @@ Other single-GPU configurations of BASELINE.json (their own metric names; the de
   --workload e2e        configs[4] per-GPU shape: B=16 (128 / 8 GPUs) x 5 frames x 299^2 through Inception-ResNet-v2
                         (torch / MIOpen fp32) + the captioner, REINFORCE step K=1 (reinforcement_e2e.py:1085-1140);
                         e2e_xe: the XE step of e2e_tf_s2vt.py:482-700.  CNN-bound: the roofline object still describes
-                        the dominant kernel of THIS library, `config.cnn_ms` says what MIOpen took.
+                        the dominant kernel of THIS library; `config.cnn_ms` {fwd, bwd} (HIP events around the CNN forward and
+                        the backward through it, per step) and `config.cnn_flops_frac` (conv / linear MACs x frames against
+                        the fp32 MFMA peak) say what MIOpen took.
 """
 import argparse
 import hashlib
@@ -241,14 +243,40 @@ def cpu_baseline():
                 "sample": f"one greedy sampler pass at B={B} ({tp:.1f} s, torch-CPU fp32); step rate extrapolated x{4 * K + 1} by flops"}
     m = {k: torch.zeros_like(v) for k, v in p.items()}
     v = {k: torch.zeros_like(x) for k, x in p.items()}
-    nsteps = max(1, min(4, int(15.0 / max(est, 1e-3))))          # ~10-30 s of CPU work
+    # The 64-row sampler pass is the LEAST parallel leg of the step; the fwd/bwd at K*B = 320 rows takes more threads.  The thread count the
+    # baseline runs with is therefore chosen on the WHOLE reference-structured step: one step per candidate (after one untimed step that pages
+    # the weights and autograd buffers in), candidates the sampler probe's pick and the larger pool sizes up to the physical cores -- bounded:
+    # no further candidates once ~45 s of probing have been spent.
+    step_i = [0]
+
+    def one_step():
+        t0 = time.time()
+        T.reference_structured_step(p, m, v, step_i[0], video, K, TC, r, b, gen=g)
+        step_i[0] += 1
+        return time.time() - t0
+    one_step()
+    cand = sorted({min(ncpu, c) for c in (cores, 16, 32, 64, phys) if c >= min(cores, 16)})
+    by_step, spent = {}, 0.0
+    for c in cand:
+        if spent > 45.0 and by_step:
+            break
+        torch.set_num_threads(c)
+        ts = one_step()
+        by_step[c] = round(ts, 3)
+        spent += ts
+    cores_step = min(by_step, key=by_step.get)
+    torch.set_num_threads(cores_step)
+    probe_note["step_seconds_by_threads"] = by_step
+    probe_note["threads_chosen_on"] = "one whole reference-structured step per candidate (sampler-pass probe listed beside it)"
+    nsteps = max(1, min(4, int(15.0 / max(by_step[cores_step], 1e-3))))          # ~10-30 s of CPU work
     t0 = time.time()
     for i in range(nsteps):
-        T.reference_structured_step(p, m, v, i, video, K, TC, r, b, gen=g)
+        one_step()
     dt = (time.time() - t0) / nsteps
-    return {"value": K * B * TC / dt, "unit": "tokens/s", "cores": cores, "host_cores": ncpu, "cpu_model": cpu_model(), "kind": "port", **probe_note,
+    return {"value": K * B * TC / dt, "unit": "tokens/s", "cores": cores_step, "host_cores": ncpu, "cpu_model": cpu_model(), "kind": "port", **probe_note,
             "sample": f"{nsteps} full REINFORCE step(s) (B={B}, K={K}, Tc={TC}, |V|={V}) structured as the reference: "
-                      f"{K}+1 sampler passes + fwd/bwd at {K * B} rows + clip + Adam, torch-CPU fp32, {cores} threads, {dt:.1f} s/step"}
+                      f"{K}+1 sampler passes + fwd/bwd at {K * B} rows + clip + Adam, torch-CPU fp32, {cores_step} threads (the fastest of "
+                      f"{sorted(by_step)} on the whole step), {dt:.1f} s/step"}
 
 
 def make_e2e_step(workload, mdl, dev, rank, B, K, info):
@@ -260,6 +288,7 @@ def make_e2e_step(workload, mdl, dev, rank, B, K, info):
     tr = e2e.EndToEnd(mdl, irv2.InceptionResnetV2(), seed=1234)
     info["cnn_params"] = int(tr.theta.numel())
     info["trainer"] = tr
+    info["cnn_macs_per_frame"] = tr.conv_macs_per_frame(299, 299)
     rng = np.random.default_rng(1234 + rank)
     frames = torch.as_tensor(rng.uniform(-1, 1, (B, TV, 3, 299, 299)).astype(np.float32)).to(dev)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -456,6 +485,8 @@ def main():
         # per-step durations: one event per step boundary on the launching stream (negligible next to ~600 launches)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         dp.timing_enable(world > 1)
+        if "trainer" in info:
+            info["trainer"].timing_enable(True)          # HIP events around every CNN forward / backward of the timed region (4 per step)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -482,6 +513,8 @@ def main():
         drift = dp.replica_drift(mdl.store.theta)         # every rank takes part (collective); must be exactly 0.0
         if "trainer" in info:
             drift = max(drift, dp.replica_drift(info["trainer"].theta))
+            info["cnn_timing"] = info["trainer"].timing_collect()
+            info["trainer"].timing_enable(False)
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         return dict(dt=dt, warm_rows=warm_rows, nprof=nprof, rows=rows, ar_ms=ar_ms, ar_n=ar_n, drift=drift, per_step=per_step, loss=float(st.loss) if st is not None else None,
                     dp_overlap=bool(getattr(mdl, "dp_overlap", False)))
@@ -566,7 +599,24 @@ def main():
         if "cnn_params" in info:
             out["config"]["cnn_params"] = info["cnn_params"]
             out["config"]["note"] = ("CNN-bound step: the convolutions run on MIOpen through PyTorch (not a kernel of this library); "
-                                     "the roofline object describes this library's dominant kernel only")
+                                     "the roofline object describes this library's dominant kernel only, config.cnn_ms / cnn_flops_frac the CNN half")
+            ct = info.get("cnn_timing")
+            if ct:
+                # the CNN half of the step (e2e_tf_s2vt.py:112-121): HIP events around EndToEnd.extract's network call and around the backward
+                # through it, per step; priced at 2 flops per multiply-accumulate of the convolution / linear layers x frames, backward = 2 x
+                # forward (data + weight gradients), against the fp32 MFMA peak (MIOpen's fp32 convolutions: what the reference's arithmetic is)
+                fwd_ms, bwd_ms = ct["fwd"] / args.steps, ct["bwd"] / args.steps
+                frames = B * TV
+                f_fwd = 2.0 * info["cnn_macs_per_frame"] * frames * ct["fwd_calls"] / args.steps
+                f_bwd = 4.0 * info["cnn_macs_per_frame"] * frames * ct["bwd_calls"] / args.steps
+                out["config"]["cnn_ms"] = {"fwd": round(fwd_ms, 3), "bwd": round(bwd_ms, 3), "share_of_step": round((fwd_ms + bwd_ms) / ms_step, 3),
+                                           "fwd_calls_per_step": ct["fwd_calls"] / args.steps, "bwd_calls_per_step": ct["bwd_calls"] / args.steps,
+                                           "how": "HIP events on the launching stream around the CNN forward / the backward through it"}
+                out["config"]["cnn_gmacs_per_frame"] = round(info["cnn_macs_per_frame"] / 1e9, 3)
+                out["config"]["cnn_flops_frac"] = {"fwd": round(f_fwd / (fwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if fwd_ms else None,
+                                                   "bwd": round(f_bwd / (bwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if bwd_ms else None,
+                                                   "both": round((f_fwd + f_bwd) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if fwd_ms + bwd_ms else None,
+                                                   "peak_tflops": PEAK_FP32_MFMA_TFLOPS}
         if args.batch_per_gpu > 0:
             out["config"]["batch_per_gpu_override"] = B
         if "active_steps" in info:
@@ -587,37 +637,56 @@ def main():
     # line and ends the rank -- the run still yields its number.  An explicit S2VT_DP_OVERLAP in the environment is respected and not probed.
     probe_ok = world > 1 and hasattr(mdl, "dp_overlap") and args.workload in ("rl", "rl_ref", "rl_msvd", "rl_msvd_eos", "xe") and "S2VT_DP_OVERLAP" not in os.environ
     if not probe_ok:
-        out = make_line(measure(), None)
+        m_ = measure()
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(make_line(m_, None)), flush=True)
     else:
         import threading
         probe = {"off": probe_mode(False, 0), "on": None}
         mdl.dp_overlap = False
-        line_off = make_line(measure(), dict(probe))
+        m_off = measure()
+        ms_off = m_off["dt"] / args.steps * 1e3
+        line_off = make_line(m_off, dict(probe)) if rank == 0 else None       # (rank 0 only: the line reads profiles/ and, at N=1, times the CPU baseline)
         done = threading.Event()
+        # A stalled or failed overlapped mode must not cost the run its number: the blocking-mode line is complete at this point, and every way out of
+        # the overlapped attempt below -- the watchdog (a hang), an exception on this rank (replica drift, an RCCL error), the normal end -- prints
+        # exactly ONE line on rank 0.  The abnormal ways leave through os._exit without another collective (a barrier could hang on the very
+        # communicator that just failed); their exit code is 0 so that the run yields its number, or S2VT_BENCH_STALL_EXIT_CODE for callers that want
+        # to tell such a run from a clean one.
+        bad_exit = int(os.environ.get("S2VT_BENCH_STALL_EXIT_CODE", "0"))
 
-        def bail():
+        def give_up(why):
             if done.is_set():
                 return
+            done.set()
             if rank == 0:
-                line_off["config"]["dp_overlap_probe_ms"] = {"off": probe["off"], "on": "stalled: the blocking-mode measurement is reported"}
+                line_off["config"]["dp_overlap_probe_ms"] = {"off": probe["off"], "on": f"{why}: the blocking-mode measurement is reported"}
                 print(json.dumps(line_off), flush=True)
-            os._exit(0)
-        deadline = float(os.environ.get("S2VT_BENCH_WATCHDOG_S", "0")) or max(120.0, 40.0 * line_off["ms_per_step"] * args.steps / 1e3)
-        wd = threading.Timer(deadline, bail)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(bad_exit)
+        deadline = float(os.environ.get("S2VT_BENCH_WATCHDOG_S", "0")) or max(120.0, 40.0 * ms_off * args.steps / 1e3)
+        wd = threading.Timer(deadline, give_up, args=("stalled",))
         wd.daemon = True
         wd.start()
-        if os.environ.get("S2VT_BENCH_FAKE_STALL") == "1":      # test hook (tests/test_gpu_dp.py): the overlapped mode "hangs" -- the watchdog must deliver the line
-            time.sleep(1e6)
-        probe["on"] = probe_mode(True, 100)
-        if probe["on"] < probe["off"]:
-            mdl.dp_overlap = True
-            out = make_line(measure(), dict(probe))
-        else:
-            mdl.dp_overlap = False
-            out = line_off
-            out["config"]["dp_overlap_probe_ms"] = dict(probe)
+        out = None
+        try:
+            if os.environ.get("S2VT_BENCH_FAKE_STALL") == "1":      # test hook (tests/test_gpu_dp.py): the overlapped mode "hangs" -- the watchdog must deliver the line
+                time.sleep(1e6)
+            if os.environ.get("S2VT_BENCH_FAKE_FAIL") == "1":       # test hook: the overlapped mode raises (what a drifted replica or an RCCL error does)
+                raise AssertionError("replicas drifted by 1.0 with dp_overlap=True (S2VT_BENCH_FAKE_FAIL)")
+            probe["on"] = probe_mode(True, 100)
+            if probe["on"] < probe["off"]:
+                mdl.dp_overlap = True
+                m_on = measure()
+                out = make_line(m_on, dict(probe)) if rank == 0 else None
+            else:
+                mdl.dp_overlap = False
+                out = line_off
+                if rank == 0:
+                    out["config"]["dp_overlap_probe_ms"] = dict(probe)
+        except BaseException as e:                                    # noqa: BLE001 -- whatever it was, the blocking-mode line stands
+            print(f"bench.py: rank {rank}: overlapped exchange failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            give_up(f"failed on rank {rank} ({type(e).__name__}: {str(e)[:160]})")
         done.set()
         wd.cancel()
         if rank == 0:

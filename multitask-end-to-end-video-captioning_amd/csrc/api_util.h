@@ -58,7 +58,7 @@ inline void seg_from_operand(ASeg& s, const s2vt_operand* o, int kw)
     s.rowmod = o->rowmod;
 }
 
-// The optional second stream of the backward passes (defined in train.hip; one per process): weight-gradient contractions that do not feed a
+// The optional second stream of the backward passes (defined in train.hip; one per DEVICE, picked by hipGetDevice at the call): weight-gradient contractions that do not feed a
 // recurrence run there BESIDE the persistent backward recurrence they are independent of, released by a gate once the recurrence's grid is
 // resident (internal.h ChainGate).  S2VT_OVERLAP: 2 (default) gated, 1 the ungated round-1 form (S2VT path only), 0 one stream.
 struct SideStream {
@@ -68,7 +68,7 @@ struct SideStream {
     int mode = 0;
 };
 SideStream& side_stream();
-std::mutex& side_stream_mutex();     // held while a call ENQUEUES work that uses the side stream and its events (they are one per process)
+std::mutex& side_stream_mutex();     // held while a call ENQUEUES work that uses the side stream and its events (one set per device; the one mutex serialises enqueueing, not execution)
 hipError_t fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev);      // `to` waits for everything issued so far on `from`
 
 constexpr int kPickStride = 16;      // sampler workspace: one packed pick per 128-byte line (GemmArgs::pick_stride)

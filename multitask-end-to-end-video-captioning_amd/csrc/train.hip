@@ -18,27 +18,40 @@ namespace s2vt_api {
 // matrix pipes idle) run on the caller's stream while weight-gradient contractions that do not depend on them
 // run here, forked / joined with events so the call keeps its stream semantics.  Created once per process.
 // (mode 1: S2VT_OVERLAP=1, ungated, below; 2: gated overlap with the persistent backward recurrences, round 5)
+// One per DEVICE (the first version was a process-wide static created on whichever device was current at first use -- a second model
+// on another GPU then recorded / waited on device 0's events): indexed by hipGetDevice like chain.hip's per-device state, each entry created on
+// first use with its device current.  A device index beyond the table, or a creation failure, yields the one-stream entry (ok = false).
 SideStream& side_stream()
 {
-    static SideStream ss = [] {
-        SideStream t;
-        // Opt-in (S2VT_OVERLAP=1).  Measured on MI355X: the two streams do run concurrently, but the kernels
+    constexpr int kMaxDev = 32;
+    static SideStream table[kMaxDev];
+    static bool made[kMaxDev] = {};
+    static SideStream none;                              // ok = false, mode 0
+    static const int mode = [] {
+        // Mode 1 (S2VT_OVERLAP=1, ungated).  Measured on MI355X: the two streams do run concurrently, but the kernels
         // only slow each other down (TN 724 -> 1462 us, slab GEMM 28 -> 46 us per launch) for a net 0.1 ms of
-        // 15.6, and per-launch durations stop meaning anything for the roofline, so one stream is the default.
+        // 15.6, and per-launch durations stop meaning anything for the roofline.
         // Mode 2 (round 5, the default; S2VT_OVERLAP=0 switches it off): the weight-gradient contractions that do not feed a recurrence run
         // on the side stream BESIDE the persistent backward recurrence they are independent of -- dWout beside LSTM2's, LSTM2's three beside
         // LSTM1's -- released by a gate once the recurrence's grid is resident (internal.h ChainGate).  A persistent recurrence at <= 256 rows
         // is one wave per SIMD at <= 380 VGPRs that waits in hand-offs half the time; the contraction fills the other half of the pipe.
         const char* on = getenv("S2VT_OVERLAP");
-        t.mode = on ? atoi(on) : 2;
-        if (t.mode < 1 || t.mode > 2) { t.mode = 0; return t; }
-        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return t;
-        for (auto& e : t.ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return t;
-        t.ok = true;
-        return t;
+        const int m = on ? atoi(on) : 2;
+        return (m < 1 || m > 2) ? 0 : m;
     }();
-    return ss;
+    int dev = -1;
+    if (mode == 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return none;
+    std::lock_guard<std::mutex> lk(side_stream_mutex());
+    if (!made[dev]) {
+        made[dev] = true;
+        SideStream& t = table[dev];
+        t.mode = mode;
+        bool good = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess;
+        for (auto& e : t.ev)
+            good = good && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        t.ok = good;
+    }
+    return table[dev];
 }
 // side waits for everything issued so far on `from`
 hipError_t fork_to(hipStream_t from, hipStream_t to, hipEvent_t ev)

@@ -240,8 +240,8 @@ class LazyScalar:
     """A device-side scalar that is only computed when somebody reads it (float(x), x.item()): the multitask steps' attribute-loss term
     bce.sum() * scale is a reporting value -- two tensor-library launches per step when formed eagerly, none when nobody asks."""
 
-    def __init__(self, fn):
-        self._fn, self._val = fn, None
+    def __init__(self, fn, unscaled=None):
+        self._fn, self._val, self._unscaled = fn, None, unscaled
 
     def tensor(self):
         if self._val is None:
@@ -250,6 +250,10 @@ class LazyScalar:
 
     def __float__(self):
         return float(self.tensor())
+
+    def unscaled(self):
+        """The term without the objective's weight on it (sum(bce) * normaliser, not alpha * that), when the maker provided it."""
+        return self._unscaled() if self._unscaled is not None else self.tensor()
 
     def item(self):
         return float(self)
@@ -263,17 +267,30 @@ class StepStats:
 
 
 class Video_Caption_Generator:
-    """Same constructor as the reference (tf_s2vt.py:54-66); `device`, `seed`, `label_dim`, `alpha`
-    are additions (the multitask scripts add label_dim / alpha, reinforce_multitask_e2e_attribute_loss.py:71-80)."""
+    """Same constructor as the reference, positional order included: the twelve arguments of tf_s2vt.py:54-66, then
+    `width, height, channels, feature_dim, label_dim, alpha` of the multitask / end-to-end classes
+    (reinforce_multitask_e2e_attribute_loss.py:71-76, reinforce_multitask_e2e_attribute_s2vt.py:71-76).  Defaults differ in
+    ONE place, stated: label_dim defaults to 0 (= the base class of tf_s2vt.py, no attribute head; the multitask class says 400) --
+    multitask.Video_Caption_Generator is this class with the multitask defaults (label_dim=400, alpha=0.2, multisample=1).
+    `device`, `seed`, `multisample` (the K the reference hard-codes into build_loss, batch_size*8 at
+    reinforcement_multisampling_tf_s2vt.py:228) are additions.  width / height / channels describe the frame placeholder the
+    build_* graphs expose once a CNN is attached (attach_cnn); feature_dim is the attribute head's input width and must equal
+    dim_image (it reads mean_t(video), :375)."""
 
     def __init__(self, dim_image, n_words, word_dim, lstm_dim, batch_size, n_lstm_steps, n_video_lstm_step,
                  n_caption_lstm_step, bias_init_vector=None, loss_weight=1, decay_value=0.00005, dropout_rate=0.9,
-                 label_dim=0, alpha=0.0, device="cuda", seed=1234, multisample=8):
+                 width=299, height=299, channels=3, feature_dim=None, label_dim=0, alpha=0.0, device="cuda", seed=1234,
+                 multisample=8):
         self.dim_image, self.n_words, self.word_dim, self.lstm_dim = dim_image, n_words, word_dim, lstm_dim
         self.batch_size, self.n_lstm_steps = batch_size, n_lstm_steps
         self.n_video_lstm_step, self.n_caption_lstm_step = n_video_lstm_step, n_caption_lstm_step
         self.loss_weight, self.decay_value, self.dropout_rate = loss_weight, decay_value, dropout_rate
+        self.width, self.height, self.channels = width, height, channels
+        self.feature_dim = dim_image if feature_dim is None else feature_dim
+        if label_dim and self.feature_dim != dim_image:
+            raise ValueError(f"feature_dim ({self.feature_dim}) must equal dim_image ({dim_image}): the attribute head reads mean_t(video)")
         self.label_dim, self.alpha = label_dim, alpha
+        self.e2e = None                          # e2e.EndToEnd once a CNN is attached: the video placeholders then take frames
         self.multisample = multisample          # the reference hard-codes batch_size*8 in build_loss (:228)
         self.device = torch.device(device)
         self.dims = ops.make_dims(dim_image, n_words, word_dim, lstm_dim, n_video_lstm_step, n_caption_lstm_step, label_dim)
@@ -337,6 +354,65 @@ class Video_Caption_Generator:
             return blocks[0].contiguous(), B
         return v.contiguous(), v.shape[0]
 
+    # -------------------------------------------------------------------------------- video feeds (features, or frames once a CNN is attached)
+    def attach_cnn(self, cnn, **kw):
+        """Put a CNN in front of every graph, as the end-to-end scripts build Inception-ResNet-v2 into each build_*
+        (e2e_tf_s2vt.py:106-121, reinforce_multitask_e2e_attribute_loss.py:116-131): from here on the video placeholders are
+        the reference's frame placeholders [batch, n_video_lstm_step, height, width, channels]; build_sampler / build_generator /
+        evaluate_multilabel run the CNN in inference mode, build_model / build_loss / build_multinomial_sampler add slim.dropout
+        (keep = dropout_rate) on the pooled features, and every train op back-propagates into the CNN and clips / updates both
+        halves together.  Returns the e2e.EndToEnd that owns the CNN's flat parameter, gradient and Adam buffers (kw: its
+        constructor's).  A feature block [n, Tv, dim_image] fed to the same placeholder is still taken as features."""
+        from .e2e import EndToEnd
+        return EndToEnd(self, cnn, **kw)                         # (registers itself as self.e2e)
+
+    def _video_placeholder(self, batch):
+        if self.e2e is not None:
+            return Placeholder("video_frames", (batch, self.n_video_lstm_step, self.height, self.width, self.channels), np.float32)
+        return Placeholder("video", (batch, self.n_video_lstm_step, self.dim_image), np.float32)
+
+    @staticmethod
+    def _is_frames(v):
+        return len(v.shape if hasattr(v, "shape") else np.shape(v)) == 5
+
+    def _frames(self, v):
+        """A frame feed as [B, Tv, channels, H, W]: the reference's placeholders are [B, Tv, H, W, channels]
+        (reinforce_multitask_e2e_attribute_loss.py:118); a channel-first block (what e2e.EndToEnd takes) passes through."""
+        if self.e2e is None:
+            raise ValueError("a frame block [B, Tv, H, W, C] was fed but no CNN is attached (attach_cnn); feed features [B, Tv, dim_image]")
+        f = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float32))
+        if f.shape[-1] != self.channels and f.shape[2] == self.channels:
+            return f
+        if f.shape[-1] != self.channels:
+            raise ValueError(f"frame feed {tuple(f.shape)}: expected [B, Tv, H, W, {self.channels}]")
+        return f.permute(0, 1, 4, 2, 3)
+
+    def _features(self, v, dropout=False, draw=0, video_base=0):
+        """A video-placeholder feed -> the feature block [n, Tv, dim_image] on the device (frames go through the attached CNN,
+        batch norm in inference mode; dropout / draw: slim.dropout on the pooled features with the draw-th independent mask)."""
+        if not self._is_frames(v):
+            return self._dev(v, torch.float32)
+        f = self._frames(v)                                          # (raises when no CNN is attached)
+        return self.e2e.extract(f, dropout=dropout, track=False, video_base=video_base, draws=(draw,))[0]
+
+    def _decay_everything(self):
+        """Which weight-decay predicate the graphs use: tf_s2vt.py:163 skips names with 'bias'; the multitask and end-to-end
+        classes' `if 'bias' or 'BatchNorm' not in v.name` is always true (reinforce_multitask_e2e_attribute_loss.py:222,
+        e2e_tf_s2vt.py:199), so with an attribute head or an attached CNN every trainable variable is decayed.
+        `self.decay_all_variables` (None = this rule) overrides."""
+        forced = getattr(self, "decay_all_variables", None)
+        return (self.label_dim > 0 or self.e2e is not None) if forced is None else bool(forced)
+
+    def l2_term(self):
+        """weight_decay_loss of the build_model graph as a host float: decay_value * sum(l2_loss(v)) over the variables the
+        predicate keeps (with an attached CNN: its trainable variables too, e2e_tf_s2vt.py:199)."""
+        st = self.store
+        th = st.theta[:st.numel] if self._decay_everything() else st.theta[:st.n_decayed]      # (pad slots are zeros)
+        sq = torch.dot(th, th)
+        if self.e2e is not None and self._decay_everything():
+            sq = sq + torch.dot(self.e2e.theta, self.e2e.theta)
+        return float(sq) * (0.5 * self.decay_value)
+
     # -------------------------------------------------------------------------------- samplers
     def sample(self, video, K, with_greedy=True, seed=None, video_base=0, stop_at_eos=False):
         """K multinomial captions per video (+ the greedy caption): (sampled [K*B,Tc], greedy [B,Tc])
@@ -352,22 +428,22 @@ class Video_Caption_Generator:
 
     def build_sampler(self):
         """Greedy sampler (tf_s2vt.py:217-266): returns (sampled_captions, video)."""
-        video = Placeholder("video", (None, self.n_video_lstm_step, self.dim_image), np.float32)
+        video = self._video_placeholder(None)
 
         def fn(v):
-            _, g = self.sample(v, 0, True)
+            _, g = self.sample(self._features(v), 0, True)      # (frames: CNN + no feature dropout, reinforcement_e2e.py:466)
             return {"sampled_captions": g.cpu().numpy().astype(np.int64)}
         return Output("sampled_captions", fn, [video]), video
 
     def build_multinomial_sampler(self):
         """One multinomial caption per video (reinforcement_multisampling_tf_s2vt.py:294-339).
         Every run draws from a fresh Philox stream (the TF op is stateful too)."""
-        video = Placeholder("video", (self.batch_size, self.n_video_lstm_step, self.dim_image), np.float32)
+        video = self._video_placeholder(self.batch_size)
         state = {"calls": 0}
 
         def fn(v):
-            state["calls"] += 1
-            s, _ = self.sample(v, 1, False, seed=self.sample_seed + 7919 * state["calls"])
+            state["calls"] += 1                                  # (frames: slim.dropout is ON in this graph, reinforcement_e2e.py:399)
+            s, _ = self.sample(self._features(v, dropout=True, draw=0), 1, False, seed=self.sample_seed + 7919 * state["calls"])
             return {"sampled_captions": s.cpu().numpy().astype(np.int64)}
         return Output("sampled_captions", fn, [video]), video
 
@@ -377,10 +453,11 @@ class Video_Caption_Generator:
         unshifted_softmax=True reproduces the reference's word choice to the letter: argmax of
         exp(l) / sum(exp(l)) computed in fp32 without a max shift (:208-209) -- NaN, hence <eos>, once a logit
         reaches 88.72; the default is argmax of the logits, which is what that expression means wherever it is finite."""
-        video = Placeholder("video", (1, self.n_video_lstm_step, self.dim_image), np.float32)
+        video = self._video_placeholder(1)
         Tc = self.n_caption_lstm_step
 
         def fn(v):
+            v = self._features(v)
             if beam_size > 1:                    # final_beam_search.py:226-294 (B = 1, TopN beams)
                 from .beam_generator import BeamSearchGenerator
                 sent, _, _ = BeamSearchGenerator(self, beam_size, length_normalization_factor).generate(v)
@@ -453,7 +530,7 @@ class Video_Caption_Generator:
         return max(1, min(Tc, int(active_steps)))
 
     def _forward_loss(self, video, caption, coef_tm, smoothing, rep, video_base, keep, reuse_sampler_state=False, target_tm=None,
-                      steps=None, live=None):
+                      steps=None, live=None, row_ids=None):
         """Teacher-forced forward + softmax-NLL fwd/bwd.  caption [N,Tc] int32 device, coef_tm
         time-major [Tc*N].  Leaves dlogits + activations ready for backward().  steps < Tc: only the first `steps` decode
         steps are unrolled (the caller vouches that coef_tm is zero behind them); nll / lp then have steps*N entries."""
@@ -461,7 +538,9 @@ class Video_Caption_Generator:
         N = caption.shape[0]
         steps = self.n_caption_lstm_step if steps is None else int(steps)
         R = steps * N
-        vid, sid = self._row_ids(B, rep, video_base)
+        # row_ids: the (video id, sample id) keys of the rows' dropout streams when they are not the sample-major numbering of
+        # `video`'s own rows (mixed_update with a feature block per row block)
+        vid, sid = self._row_ids(B, rep, video_base) if row_ids is None else row_ids
         seed = self.dropout_seed + 104729 * self.global_step
         state = None
         if reuse_sampler_state:
@@ -609,10 +688,16 @@ class Video_Caption_Generator:
         return self.store.state_dict(self.global_step if with_optimizer else None, self.adam_t, step_name=step_name)
 
     def load_state_dict(self, sd):
+        """store.load_state_dict + the counters, positioned as optimistic_restore does (set_step: the device-side count of APPLIED updates
+        recover() rewinds to follows, and a sampler trajectory saved under the old variables is dropped).  A checkpoint that carries Adam's
+        count (beta1_power / adam_t) but no step counter -- an XE checkpoint's optimizer slots under a REINFORCE run's names -- moves adam_t only."""
         loaded = self.store.load_state_dict(sd)
-        if self.store.restored_step is not None:
-            self.global_step = self.store.restored_step
-            self.adam_t = self.store.restored_adam_t if self.store.restored_adam_t is not None else self.global_step
+        step, t = self.store.restored_step, self.store.restored_adam_t
+        if step is not None:
+            self.set_step(step, t if t is not None else step)
+        elif t is not None:
+            self.set_step(self.global_step, t)
+        self._sampler_state = None                   # the variables changed, whatever the counters say
         return loaded
 
     def recover(self, disable_persistent=True):
@@ -686,13 +771,7 @@ class Video_Caption_Generator:
         attr_scale = None
         attr_loss = None
         if multitask:
-            y = self._dev(true_labels, torch.float32)
-            Bg = video.shape[0] * self.world_size
-            mean, z, bce = ops.attr_head_fwd(video, self.store.p["attr_W"], self.store.p["attr_b"], y)
-            dz = ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
-            attr_scale = self.alpha / float(self.label_dim * Bg)
-            self._attr_ctx = (dz, attr_scale)                   # for callers that differentiate through `video` (e2e.py)
-            attr_loss = LazyScalar(lambda bce=bce, sc=attr_scale: bce.sum() * sc)
+            attr_scale, attr_loss = self._attr_terms(video, true_labels)
         self.apply_gradients(None if fused else msum, lr, clip_norm, attr_scale=attr_scale, extra_sumsq=extra_sumsq, loss_terms=(coef, nll, msum))
         st = StepStats(self._loss[0], self._sumsq, msum[0])
         st.attr_loss = attr_loss
@@ -700,9 +779,13 @@ class Video_Caption_Generator:
         return st
 
     def xe_update(self, video, caption, caption_mask, lr, clip_norm=10.0, q1=True, smoothing=0.05, video_base=0, keep=None,
-                  extra_sumsq=None, decay_all=False, active_steps="auto", live_mask="auto"):
+                  extra_sumsq=None, decay_all=False, active_steps="auto", live_mask="auto", true_labels=None, attr_normalised=True):
         """build_model + train_op of tf_s2vt.py:90-167,445-448 (label smoothing 0.05, Q1 batch-mean
         semantics, weight decay on the non-'bias' variables, clip 10).
+        true_labels [B, label_dim] (model built with label_dim > 0): the multitask cross-entropy objective
+            (1 - alpha) * XE / sum(mask) + weight decay + alpha * multilabel_loss
+        of multitask_e2e_attribute_s2vt.py:208-222 (multilabel_loss = sum(bce) / (label_dim * B), attr_normalised=True) and of
+        reinforce_multitask_e2e_attribute_loss.py:211-225 (multilabel_loss = sum(bce), attr_normalised=False).
         active_steps: as reinforce_update -- the padding behind the longest caption of the batch is not unrolled.  "auto"
         reads a host-resident caption_mask; data parallel with q1 it needs the GLOBAL batch's longest caption, which only the
         caller knows (train_xe passes it), so "auto" keeps the full unroll there.
@@ -717,29 +800,48 @@ class Video_Caption_Generator:
         N = cap.shape[0]
         n_glob = float(N * self.world_size)
         keep = self.dropout_rate if keep is None else keep
+        multitask = true_labels is not None and self.label_dim > 0
+        lw = float(self.loss_weight) * (1.0 - float(self.alpha)) if multitask else self.loss_weight
         if not dp.active() and cap.shape[1] <= 128:
             # one process: coefficients, time-major targets and sum(mask) in ONE library launch (the expressions below, same order)
-            coef, target_tm, msum = ops.xe_prep(mask.contiguous(), cap.contiguous(), self.loss_weight, n_glob, q1)
+            coef, target_tm, msum = ops.xe_prep(mask.contiguous(), cap.contiguous(), lw, n_glob, q1)
             nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep, steps=steps, live=live, target_tm=target_tm)
         else:
             colsum = mask.sum(0)
             if q1:
                 dp.allreduce_small(colsum)
-                coef = (colsum[:, None] / n_glob).expand(-1, N) * self.loss_weight
+                coef = (colsum[:, None] / n_glob).expand(-1, N) * lw
             else:
-                coef = mask.t() * self.loss_weight
+                coef = mask.t() * lw
             coef = coef.contiguous().view(-1)
             nll, _ = self._forward_loss(video, cap, coef, smoothing, 1, video_base, keep, steps=steps, live=live)
             msum = mask.sum().reshape(1)
         coef = self._coef_used
         self.backward()
+        attr_scale = attr_loss = None
+        if multitask:
+            attr_scale, attr_loss = self._attr_terms(video, true_labels, attr_normalised)
         self.apply_gradients(msum, lr, clip_norm, weight_decay=self.decay_value, extra_sumsq=extra_sumsq, decay_all=decay_all,
-                             loss_terms=(coef, nll, msum))
-        return StepStats(self._loss[0], self._sumsq, msum[0])
+                             loss_terms=(coef, nll, msum), attr_scale=attr_scale)
+        st = StepStats(self._loss[0], self._sumsq, msum[0])
+        st.attr_loss = attr_loss
+        return st
+
+    def _attr_terms(self, video, true_labels, normalised=True):
+        """The attribute head's half of a multitask update: its gradients into the bucket's attr range (unscaled), the scale
+        alpha / (label_dim * B_global) (or alpha, for the un-normalised sum of reinforce_multitask_e2e_attribute_loss.py:221) that
+        apply_gradients() finalises that range with, and the loss term as a lazily evaluated device scalar."""
+        y = self._dev(true_labels, torch.float32)
+        mean, z, bce = ops.attr_head_fwd(video, self.store.p["attr_W"], self.store.p["attr_b"], y)
+        dz = ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
+        scale = float(self.alpha) / float(self.label_dim * video.shape[0] * self.world_size) if normalised else float(self.alpha)
+        self._attr_ctx = (dz, scale)                            # for callers that differentiate through `video` (e2e.py)
+        norm = scale / float(self.alpha) if self.alpha else (1.0 / float(self.label_dim * video.shape[0] * self.world_size) if normalised else 1.0)
+        return scale, LazyScalar(lambda bce=bce, sc=scale: bce.sum() * sc, unscaled=lambda bce=bce, nm=norm: bce.sum() * nm)
 
     def mixed_update(self, video, sampled, mask, rewards, baseline, gt_caption, gt_mask, lr, lambda_loss=0.5, clip_norm=5.0,
                      video_base=0, keep=None, q1=True, smoothing=0.05, true_labels=None, active_steps="auto", decay_all=False,
-                     reuse_sampler_state=False):
+                     reuse_sampler_state=False, video_gt=None, extra_sumsq=None):
         """The mixed objective of reinforce_multitask_e2e_attribute_s2vt.py:850 (BASELINE configs[3]):
             sum_loss = -(1 - lambda) * PG / sum(mask_pg)  +  lambda * model_loss
         with PG the reward-scaled log-likelihood of the SAMPLED captions (build_loss) and model_loss the
@@ -757,7 +859,12 @@ class Video_Caption_Generator:
         tf_s2vt.py:163's filter (names without 'bias').
         reuse_sampler_state: as reinforce_update -- the sample() call that produced `sampled` ran just before on this very video tensor with the
         current weights; LSTM1 never sees a word or a dropout mask, so its trajectory is the same for the sampled AND the ground-truth rows of
-        the pass and is taken from the sampler's workspace instead of being recomputed (one 25-step recurrence less per step)."""
+        the pass and is taken from the sampler's workspace instead of being recomputed (one 25-step recurrence less per step).
+        video_gt [B, Tv, dim_image]: the feature block the GROUND-TRUTH rows read when it is not `video` -- with the CNN in the loop the
+        two graphs draw independent slim.dropout masks on the pooled features (reinforce_multitask_e2e_attribute_s2vt.py:131 in
+        build_model, :307 in build_loss), so the same frames give each objective its own block.  The pass then runs on (rep+1)*B
+        distinct feature rows (LSTM1 per row block) with the SAME dropout-stream keys as the shared-block form: row k*B+j keeps
+        (video j, sample k).  video_grad() afterwards is [(rep+1)*B, Tv, dim_image], the sampled blocks first."""
         if active_steps == "auto":          # both blocks decide: the longest sample and the longest ground-truth caption
             sa, sb = self.active_steps(mask), self.active_steps(gt_mask)
             active_steps = None if (sa is None or sb is None or (q1 and self.world_size > 1)) else max(sa, sb)
@@ -782,13 +889,21 @@ class Video_Caption_Generator:
         keep = self.dropout_rate if keep is None else keep
         lam = float(lambda_loss)
         N = (rep + 1) * B
+        row_ids, video_attr = None, video
+        if video_gt is not None:
+            assert not reuse_sampler_state, "video_gt: the ground-truth rows read their own feature block, LSTM1 runs per row block"
+            video_gt = self._dev(video_gt, torch.float32)
+            assert video_gt.shape == video.shape
+            row_ids = self._row_ids(B, rep + 1, video_base)
+            video = torch.cat([video] * rep + [video_gt], 0).contiguous()      # one feature row per unrolled row
         fused = not dp.active() and self.n_caption_lstm_step <= 128
         if fused:
             # one process: both blocks' coefficients, the smoothing vector, the joined caption block and the two mask sums in ONE
             # library launch (the expressions of the branch below, in their order); the loss terms in one more
             coef, smooth_tm, cap_all, target_tm, sums = ops.mixed_prep(mask.contiguous(), gmask.contiguous(), self._dev(rewards, torch.float32), self._dev(baseline, torch.float32),
                                                             cap.contiguous(), gcap.contiguous(), lam, self.loss_weight, q1, smoothing, float(B * self.world_size))
-            nll, _ = self._forward_loss(video, cap_all, coef, smooth_tm, rep + 1, video_base, keep, reuse_sampler_state, steps=steps, live=live, target_tm=target_tm)
+            nll, _ = self._forward_loss(video, cap_all, coef, smooth_tm, 1 if row_ids else rep + 1, video_base, keep, reuse_sampler_state, steps=steps,
+                                        live=live, target_tm=target_tm, row_ids=row_ids)
             losses = ops.mixed_loss(self._coef_used, nll, live, N, rep * B)
             loss_total = losses[2]
         else:
@@ -812,8 +927,8 @@ class Video_Caption_Generator:
             smooth = torch.zeros((rep + 1) * B, dtype=torch.float32, device=self.device)
             smooth[rep * B:] = float(smoothing)
             smooth_tm = smooth.repeat(self.n_caption_lstm_step).contiguous()
-            nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, rep + 1, video_base, keep,
-                                        reuse_sampler_state, steps=steps, live=live)
+            nll, _ = self._forward_loss(video, torch.cat([cap, gcap], 0).contiguous(), coef, smooth_tm, 1 if row_ids else rep + 1, video_base, keep,
+                                        reuse_sampler_state, steps=steps, live=live, row_ids=row_ids)
             terms = self._coef_used * nll
             if live is None:
                 per_row = terms.view(-1, N)
@@ -825,16 +940,12 @@ class Video_Caption_Generator:
         self.backward(accumulate=False, overlap=False)
         attr_scale = attr_loss = None
         if true_labels is not None and self.label_dim > 0:
-            y = self._dev(true_labels, torch.float32)
-            mean, z, bce = ops.attr_head_fwd(video, self.store.p["attr_W"], self.store.p["attr_b"], y)
-            dz = ops.attr_head_bwd(mean, z, y, 1.0, self.store.g["attr_W"], self.store.g["attr_b"])
-            attr_scale = self.alpha / float(self.label_dim * B * self.world_size)
-            self._attr_ctx = (dz, attr_scale)
-            attr_loss = LazyScalar(lambda bce=bce, sc=attr_scale: bce.sum() * sc)
+            attr_scale, attr_loss = self._attr_terms(video_attr, true_labels)
         one = getattr(self, "_one_over_world", None)                      # the bucket is already normalised: global "sum(mask)" = 1
         if one is None or one[1] != self.world_size:
             one = self._one_over_world = (torch.full((), 1.0 / self.world_size, device=self.device), self.world_size)
-        self.apply_gradients(one[0], lr, clip_norm, weight_decay=lam * self.decay_value, attr_scale=attr_scale, decay_all=decay_all)
+        self.apply_gradients(one[0], lr, clip_norm, weight_decay=lam * self.decay_value, attr_scale=attr_scale, decay_all=decay_all,
+                             extra_sumsq=extra_sumsq)
         st = StepStats(loss_total, self._sumsq, sums[0])
         st.attr_loss = attr_loss
         return st
@@ -849,35 +960,63 @@ class Video_Caption_Generator:
     def evaluate_multilabel(self, threshold=0.5):
         """evaluate_multilabel(threshold) -> (video, scores) of reinforce_multitask_e2e_attribute_loss.py:606-626:
         scores = sigmoid(xw_plus_b(reduce_mean(video, axis=1), attr_W, attr_b)), [batch, label_num].  The reference's
-        placeholder takes frames and runs the CNN in inference mode first (:608-620); with precomputed features the feed is
-        the feature block [n, Tv, dim_image] (e2e.EndToEnd.evaluate_multilabel goes through the CNN).  `threshold` is
-        accepted and unused, exactly as there (the caller thresholds the scores)."""
-        video = Placeholder("video", (None, self.n_video_lstm_step, self.dim_image), np.float32)
+        placeholder takes frames and runs the CNN in inference mode first (:608-620) -- so does this one once a CNN is attached
+        (attach_cnn); with precomputed features the feed is the feature block [n, Tv, dim_image].  `threshold` is accepted and
+        unused, exactly as there (the caller thresholds the scores)."""
+        video = self._video_placeholder(None)
 
         def fn(v):
-            return {"scores": self.attribute_scores(v).cpu().numpy()}
+            return {"scores": self.attribute_scores(self._features(v)).cpu().numpy()}
         return video, Output("scores", fn, [video])
 
-    def build_model(self):
-        """(loss, video, caption, caption_mask, probs) as tf_s2vt.py:90-167.  Fetching `loss`
-        evaluates the forward only; `train_op` (see make_train_op) also updates the variables."""
+
+
+    def build_model(self, multilabel_normalised=False, with_multilabel_loss=False):
+        """The cross-entropy graph.  Base class (label_dim == 0): (loss, video, caption, caption_mask, probs) as tf_s2vt.py:90-167.
+        With an attribute head (label_dim > 0) the multitask classes' tuples:
+          (loss, video_frames, caption, caption_mask, probs, true_labels)            reinforce_multitask_e2e_attribute_loss.py:116-226
+          (..., probs, true_labels, multilabel_loss)  with_multilabel_loss=True       multitask_e2e_attribute_s2vt.py:116-223
+        where loss = (1 - alpha) * XE / sum(mask) + weight_decay_loss + alpha * multilabel_loss, weight decay over EVERY
+        trainable variable (Q3), and multilabel_loss = sum(bce) (:221 of the first script; multilabel_normalised=False) or
+        sum(bce) / (label_dim * batch_size) (:219 of the second; True).  `video` is the frame placeholder once a CNN is attached
+        (attach_cnn: the graph then starts at the frames, slim.dropout on the pooled features, :131).
+        Fetching `loss` / `probs` evaluates the forward only; minimize() builds the train_op."""
         B, Tc = self.batch_size, self.n_caption_lstm_step
-        video = Placeholder("video", (B, self.n_video_lstm_step, self.dim_image), np.float32)
+        video = self._video_placeholder(B)
         caption = Placeholder("caption", (B, Tc), np.int32)
         caption_mask = Placeholder("caption_mask", (B, Tc), np.float32)
+        multitask = self.label_dim > 0
+        true_labels = Placeholder("true_labels", (B, self.label_dim), np.float32) if multitask else None
 
-        def fn(v, c, m):
-            v = self._dev(v, torch.float32); c = self._dev(c, torch.int32); m = self._dev(m, torch.float32)
-            coef = ((m.sum(0)[:, None] / float(c.shape[0])).expand(-1, c.shape[0]) * self.loss_weight).contiguous().view(-1)
+        def fn(v, c, m, y=None):
+            v = self._features(v, dropout=True, draw=0)
+            c = self._dev(c, torch.int32); m = self._dev(m, torch.float32)
+            n = c.shape[0]
+            coef = ((m.sum(0)[:, None] / float(n)).expand(-1, n) * self.loss_weight).contiguous().view(-1)
             vid, sid = self._row_ids(v.shape[0], 1, 0)
             seed = self.dropout_seed + 104729 * self.global_step
-            logits, _ = ops.teacher_forced_fwd(self.dims, self.store.params, v, c, c.shape[0], self.dropout_rate, seed, vid, sid)
-            probs = logits.view(Tc, c.shape[0], -1).clone()
+            logits, _ = ops.teacher_forced_fwd(self.dims, self.store.params, v, c, n, self.dropout_rate, seed, vid, sid)
+            probs = logits.view(Tc, n, -1).clone()
             nll, _ = ops.softmax_nll_fwd_bwd(logits, c.t().contiguous().view(-1), coef, 0.05)
-            th = self.store.theta[:self.store.n_decayed]        # every variable without 'bias' in its TF name (Q3); pad slots are 0
-            loss = float(torch.dot(coef, nll) / m.sum() + (0.5 * self.decay_value) * torch.dot(th, th))
-            return {"loss": loss, "probs": probs.cpu().numpy()}
-        return Output("loss", fn, [video, caption, caption_mask]), video, caption, caption_mask, Output("probs", fn, [video, caption, caption_mask])
+            xe = float(torch.dot(coef, nll) / m.sum())
+            out = {"probs": probs.cpu().numpy()}
+            if multitask:
+                _, _, bce = ops.attr_head_fwd(v, self.store.p["attr_W"], self.store.p["attr_b"], self._dev(y, torch.float32))
+                ml = float(bce.sum()) / (float(self.label_dim * n) if multilabel_normalised else 1.0)
+                out["multilabel_loss"] = ml
+                out["loss"] = (1.0 - self.alpha) * xe + self.l2_term() + self.alpha * ml
+            else:
+                out["loss"] = xe + self.l2_term()
+            return out
+        inputs = [video, caption, caption_mask] + ([true_labels] if multitask else [])
+        loss, probs = Output("loss", fn, inputs), Output("probs", fn, inputs)
+        loss.graph = {"kind": "build_model", "inputs": inputs, "normalised": multilabel_normalised, "multilabel_loss": None}
+        if not multitask:
+            return loss, video, caption, caption_mask, probs
+        ml = loss.graph["multilabel_loss"] = Output("multilabel_loss", fn, inputs)
+        if with_multilabel_loss:
+            return loss, video, caption, caption_mask, probs, true_labels, ml
+        return loss, video, caption, caption_mask, probs, true_labels
 
     # ---- the nodes the reference's train() adds around the model's graphs
     def placeholder(self, name, shape=(None,), dtype=np.float32):
@@ -896,55 +1035,155 @@ class Video_Caption_Generator:
 
     def minimize(self, build_model_outputs, learning_rate, clip_norm=10.0):
         """train_op of tf_s2vt.py:442-445: AdamOptimizer(learning_rate).compute_gradients(tf_loss) ->
-        clip_by_global_norm(10) -> apply_gradients(global_step).  `build_model_outputs` = the tuple build_model()
-        returned; sess.run([train_op, tf_loss], feed_dict={tf_video, tf_caption, tf_caption_mask}) is ONE update, and
-        the loss fetched beside it is the one the update differentiated (same dropout masks, pre-update weights)."""
-        loss, video, caption, caption_mask = build_model_outputs[:4]
+        clip_by_global_norm(10) -> apply_gradients(global_step) -- and of multitask_e2e_attribute_s2vt.py:715-717 /
+        e2e_tf_s2vt.py:533-536, the same statement over the multitask loss and over CNN + captioner.  `build_model_outputs` =
+        the tuple build_model() returned (5, 6 or 7 long); sess.run([train_op, tf_loss(, tf_multilabel_loss)], feed_dict) is ONE
+        update, and the losses fetched beside it are the ones the update differentiated (same dropout masks, pre-update weights)."""
+        loss = build_model_outputs[0]
+        graph = getattr(loss, "graph", None) or {"inputs": list(build_model_outputs[1:4]), "normalised": True, "multilabel_loss": None}
         lr = learning_rate.value if hasattr(learning_rate, "value") else (lambda: float(learning_rate))
 
-        def fn(v, c, m):
-            th = self.store.theta[:self.store.n_decayed]
-            wd = float((0.5 * self.decay_value) * torch.dot(th, th))           # the l2 term of tf_s2vt.py:163-166, pre-update
-            st = self.xe_update(v, c, m, lr(), clip_norm=clip_norm, q1=True, smoothing=0.05)
-            return {"train_op": None, "loss": float(st.loss) + wd}
-        return Output("train_op", fn, [video, caption, caption_mask], provides={loss: "loss"})
+        def fn(v, c, m, y=None):
+            wd = self.l2_term()                                                # the l2 term of tf_s2vt.py:163-166, pre-update
+            if self._is_frames(v):
+                st = self.e2e.xe_step(self._frames(v), c, m, lr(), clip_norm=clip_norm, true_labels=y, attr_normalised=graph["normalised"])
+            else:
+                st = self.xe_update(v, c, m, lr(), clip_norm=clip_norm, q1=True, smoothing=0.05, decay_all=self._decay_everything(),
+                                    true_labels=y, attr_normalised=graph["normalised"])
+            out = {"train_op": None, "loss": float(st.loss) + wd}
+            if getattr(st, "attr_loss", None) is not None:
+                out["loss"] += float(st.attr_loss)
+                out["multilabel_loss"] = float(st.attr_loss.unscaled())
+            return out
+        provides = {loss: "loss"}
+        if graph["multilabel_loss"] is not None:
+            provides[graph["multilabel_loss"]] = "multilabel_loss"
+        return Output("train_op", fn, graph["inputs"], provides=provides)
 
     def reinforce_train_op(self, build_loss_outputs, rewards, base_line, learning_rate, clip_norm=5.0):
         """(train_op, sum_loss) of reinforcement_multisampling_tf_s2vt.py:641-652:
             norm = sum(loss_masks); sum_loss = -sum(loss * (rewards - base_line)) / norm;
             clip_by_global_norm(tf.gradients(sum_loss), 5); Adam.apply_gradients(global_step).
-        Fed as there (:821-823): {loss_masks, loss_captions, loss_features (the K-times tiled block), rewards, base_line}."""
-        _, video, caption, caption_mask = build_loss_outputs
-        lr = learning_rate.value if hasattr(learning_rate, "value") else (lambda: float(learning_rate))
-
-        def fn(v, c, m, r, b):
-            vh = None if isinstance(v, torch.Tensor) else v
-            v = self._dev(v, torch.float32)
-            c = self._dev(c, torch.int32)
-            v, _ = self._untile(v, c.shape[0], host=vh)
-            st = self.reinforce_update(v, c, m, np.asarray(r, np.float32).reshape(-1), np.asarray(b, np.float32).reshape(-1), lr(),
-                                       clip_norm=clip_norm)
-            return {"train_op": None, "sum_loss": float(st.loss)}
-        inputs = [video, caption, caption_mask, rewards, base_line]
-        return Output("train_op", fn, inputs), Output("sum_loss", fn, inputs)
+        Fed as there (:821-823): {loss_masks, loss_captions, loss_features (the K-times tiled block), rewards, base_line}.
+        (= multitask_train_op without an attribute term or a cross-entropy mix.)"""
+        return self.multitask_train_op(build_loss_outputs[:4], rewards, base_line, learning_rate, clip_norm=clip_norm)
 
     def build_loss(self):
-        """(loss, video, caption, caption_mask) as reinforcement_multisampling_tf_s2vt.py:227-292.
-        The reference returns the dense [N,Tc,V] tensor log_softmax*onehot*mask; it has one non-zero
-        per (n,t), so the fetch here is the [N,Tc] array of those values (lp * mask)."""
+        """The REINFORCE graph: (loss, video, caption, caption_mask) as reinforcement_multisampling_tf_s2vt.py:227-292, and with an
+        attribute head (label_dim > 0) the multitask class's (loss, video_frames, caption, caption_mask, true_labels,
+        multilabel_loss) of reinforce_multitask_e2e_attribute_loss.py:228-380, multilabel_loss = sum(bce) / (label_dim * batch).
+        The reference returns the dense [N,Tc,V] tensor log_softmax*onehot*mask; it has one non-zero per (n,t), so the fetch here is
+        the [N,Tc] array of those values (lp * mask).  With a CNN attached `video` is the frame placeholder (slim.dropout on the
+        pooled features with this graph's own mask, :250)."""
         N, Tc = self.batch_size * self.multisample, self.n_caption_lstm_step
-        video = Placeholder("video", (N, self.n_video_lstm_step, self.dim_image), np.float32)
+        video = self._video_placeholder(N)
         caption = Placeholder("caption", (N, Tc), np.int32)
         caption_mask = Placeholder("caption_mask", (N, Tc), np.float32)
 
         def fn(v, c, m):
-            vh = None if isinstance(v, torch.Tensor) else v
-            v = self._dev(v, torch.float32); c = self._dev(c, torch.int32); m = self._dev(m, torch.float32)
-            v, B = self._untile(v, c.shape[0], host=vh)
+            v, B = self._loss_features(v, np.shape(c)[0])
+            c = self._dev(c, torch.int32); m = self._dev(m, torch.float32)
             vid, sid = self._row_ids(B, c.shape[0] // B, 0)
             seed = self.dropout_seed + 104729 * self.global_step
             logits, _ = ops.teacher_forced_fwd(self.dims, self.store.params, v, c, c.shape[0], self.dropout_rate, seed, vid, sid)
             zero = torch.zeros(logits.shape[0], dtype=torch.float32, device=self.device)
             _, lp = ops.softmax_nll_fwd_bwd(logits, c.t().contiguous().view(-1), zero, 0.0)
             return {"loss": (lp.view(Tc, -1).t() * m).cpu().numpy()}
-        return Output("loss", fn, [video, caption, caption_mask]), video, caption, caption_mask
+        loss = Output("loss", fn, [video, caption, caption_mask])
+        loss.graph = {"kind": "build_loss"}
+        if not self.label_dim:
+            return loss, video, caption, caption_mask
+        true_labels = Placeholder("true_labels", (N, self.label_dim), np.float32)
+
+        def fn_ml(v, y):
+            y = self._dev(y, torch.float32)
+            v, _ = self._loss_features(v, y.shape[0])
+            _, _, bce = ops.attr_head_fwd(v, self.store.p["attr_W"], self.store.p["attr_b"], y)
+            return {"multilabel_loss": float(bce.sum()) / float(self.label_dim * v.shape[0])}
+        return loss, video, caption, caption_mask, true_labels, Output("multilabel_loss", fn_ml, [video, true_labels])
+
+    def _loss_features(self, v, N):
+        """build_loss's video feed -> (the B distinct feature rows on the device, B): the K-times tiled block of
+        reinforcement_multisampling_tf_s2vt.py:779-782 is recognised on the host (_untile); frames go through the CNN with the
+        loss graph's own slim.dropout mask (draw 1; the sampler's is draw 0)."""
+        if self._is_frames(v):
+            f = self._frames(v)
+            f, B = self._untile(f, N, host=None if f.is_cuda else f.numpy())
+            return self._features(f, dropout=True, draw=1), B
+        vh = None if isinstance(v, torch.Tensor) else v
+        return self._untile(self._dev(v, torch.float32), N, host=vh)
+
+    def multitask_train_op(self, build_loss_outputs, rewards, base_line, learning_rate, clip_norm=10.0, alpha=None,
+                           build_model_outputs=None, lambda_loss=None):
+        """(train_op, sum_loss) of the multitask / end-to-end REINFORCE scripts' train():
+
+        * reinforce_multitask_e2e_attribute_loss.py:953-960 (build_loss_outputs = the 6-tuple, `alpha` given or the model's):
+              norm = sum(loss_masks); residual = rewards - base_line
+              sum_loss = -(1 - alpha) * sum(loss * residual) / norm + alpha * multilabel_loss
+              clip_by_global_norm(tf.gradients(sum_loss, trainable_variables), 10); Adam.apply_gradients(global_step)
+          fed {loss_masks, loss_captions, loss_features, rewards, base_line, true_labels} (:1113) -- the script also feeds
+          model_features / model_captions / model_caption_masks, which sum_loss does not read; Session.run ignores them too.
+        * reinforce_multitask_e2e_attribute_s2vt.py:846-855 (lambda_loss and build_model_outputs given; clip_norm=5 there):
+              sum_loss = -(1 - lambda_loss) * sum(loss * residual) / norm + lambda_loss * model_loss
+          with model_loss the cross-entropy graph on the ground-truth captions of the same videos (label smoothing, Q1, weight
+          decay on every variable), fed additionally {model_features, model_captions, model_caption_masks} (:977).
+        * a 4-tuple build_loss and no lambda: reinforcement_multisampling_tf_s2vt.py:641-652 (reinforce_train_op).
+
+        Lowered onto ONE fused update each: reinforce_update(true_labels=) / mixed_update, or -- when the video feed is a frame
+        block and a CNN is attached -- e2e.EndToEnd.reinforce_update / mixed_update (gradient through the CNN, one clip norm and one
+        Adam over both halves).  sum_loss fetched beside train_op is the pre-update value the update differentiated."""
+        video, caption, caption_mask = build_loss_outputs[1:4]
+        true_labels = build_loss_outputs[4] if len(build_loss_outputs) >= 6 else None
+        lr = learning_rate.value if hasattr(learning_rate, "value") else (lambda: float(learning_rate))
+        mixed = lambda_loss is not None
+        inputs = [video, caption, caption_mask, rewards, base_line]
+        if true_labels is not None:
+            inputs.append(true_labels)
+        if mixed:
+            if build_model_outputs is None:
+                raise ValueError("lambda_loss mixes in model_loss: pass build_model_outputs (the tuple build_model() returned)")
+            inputs += list(build_model_outputs[1:4])
+
+        def fn(v, c, m, r, b, *rest):
+            rest = list(rest)
+            y = rest.pop(0) if true_labels is not None else None
+            r = np.asarray(r, np.float32).reshape(-1); b = np.asarray(b, np.float32).reshape(-1)
+            frames, v_fed = self._is_frames(v), v
+            n_rows = np.shape(c)[0]
+            if frames:
+                f = self._frames(v)
+                v, _ = self._untile(f, n_rows, host=None if f.is_cuda else f.numpy())
+            else:
+                vh = None if isinstance(v, torch.Tensor) else v
+                v, _ = self._untile(self._dev(v, torch.float32), n_rows, host=vh)
+            if y is not None and np.shape(y)[0] != v.shape[0]:
+                y = np.asarray(y, np.float32)[:v.shape[0]]                    # labels arrive tiled like the features
+            saved = self.alpha
+            if alpha is not None:
+                self.alpha = alpha
+            try:
+                if not mixed:
+                    upd = self.e2e.reinforce_update if frames else self.reinforce_update
+                    st = upd(v, c, m, r, b, lr(), clip_norm=clip_norm, true_labels=y)
+                    total = float(st.loss)
+                else:
+                    mv, mc, mm = rest
+                    wd = float(lambda_loss) * self.l2_term()                   # lambda * weight_decay_loss inside model_loss, pre-update
+                    same = mv is v_fed                                       # the script feeds the one video_batch to both graphs (:977)
+                    if not same and not isinstance(mv, torch.Tensor) and not isinstance(v_fed, torch.Tensor):
+                        mva = np.asarray(mv, np.float32)
+                        same = np.array_equal(mva, np.asarray(v_fed, np.float32)[:mva.shape[0]])
+                    if frames:
+                        if not same:
+                            raise ValueError("model_features and loss_features must be the same frame batch (the script feeds video_batch to both, :977)")
+                        st = self.e2e.mixed_update(v, c, m, r, b, mc, mm, lr(), lambda_loss=lambda_loss, clip_norm=clip_norm, true_labels=y)
+                    else:
+                        st = self.mixed_update(v, c, m, r, b, mc, mm, lr(), lambda_loss=lambda_loss, clip_norm=clip_norm, true_labels=y,
+                                               decay_all=self._decay_everything(), video_gt=None if same else self._dev(mv, torch.float32))
+                    total = float(st.loss) + wd
+            finally:
+                self.alpha = saved
+            if getattr(st, "attr_loss", None) is not None:
+                total += float(st.attr_loss)
+            return {"train_op": None, "sum_loss": total}
+        return Output("train_op", fn, inputs), Output("sum_loss", fn, inputs)

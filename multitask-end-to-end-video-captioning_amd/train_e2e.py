@@ -27,21 +27,73 @@ def e2e_config(**kw):
     return Config(**base)
 
 
+_CNN_OPT = ("_s2vt/cnn_adam_m", "_s2vt/cnn_adam_v", "_s2vt/cnn_adam_t")
+
+
 def save_cnn(trainer, cfg: Config, epoch: int):
+    """The fine-tuned CNN beside the captioner's checkpoint: every tensor of the module's state_dict (weights, batch-norm beta and moving
+    statistics) under its torch key, plus the CNN half of the optimizer -- the flat Adam moments and the CNN's own update count
+    (e2e.EndToEnd.m / .v / .adam_t) -- so that `resume` continues BOTH halves of the joint update (the first version wrote the
+    weights only and nothing read them back)."""
     os.makedirs(cfg.model_path, exist_ok=True)
     path = os.path.join(cfg.model_path, f"{cfg.model_name}-cnn-{epoch}.npz")
-    np.savez(path, **{k: v.detach().cpu().numpy() for k, v in trainer.cnn.state_dict().items()})
+    sd = {k: v.detach().cpu().numpy() for k, v in trainer.cnn.state_dict().items()}
+    sd[_CNN_OPT[0]] = trainer.m.detach().cpu().numpy()
+    sd[_CNN_OPT[1]] = trainer.v.detach().cpu().numpy()
+    sd[_CNN_OPT[2]] = np.int64(trainer.adam_t)
+    np.savez(path, **sd)
     return path
 
 
+def cnn_checkpoint_of(captioner_checkpoint: str):
+    """The `<model_name>-cnn-<epoch>.npz` file save_cnn wrote beside the captioner checkpoint `<model_name>-<epoch>[.npz]`."""
+    d, base = os.path.split(captioner_checkpoint)
+    stem = base[:-4] if base.endswith(".npz") else base
+    name, _, epoch = stem.rpartition("-")
+    return os.path.join(d, f"{name}-cnn-{epoch}.npz")
+
+
+def load_cnn(trainer, path: str):
+    """Restore what save_cnn wrote into an EndToEnd trainer: module tensors by torch key (shape-checked; the parameters are views of the
+    trainer's flat buffer, so the copy lands there), Adam moments and update count.  Raises when the file is missing, matches no tensor
+    of this CNN, or leaves a parameter of it unset -- a resumed run must not silently pair a trained captioner with a fresh CNN."""
+    import torch
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"resume: no CNN checkpoint at {path} (save_cnn writes it beside the captioner's; pass resume_cnn= / --resume-cnn)")
+    with np.load(path) as z:
+        arrays = {k: z[k] for k in z.files}
+    own = trainer.cnn.state_dict()
+    loaded = []
+    with torch.no_grad():
+        for k, t in own.items():
+            a = arrays.get(k)
+            if a is not None and tuple(a.shape) == tuple(t.shape):
+                t.copy_(torch.as_tensor(a).to(device=t.device, dtype=t.dtype))
+                loaded.append(k)
+    missing = [k for k, _ in trainer.cnn.named_parameters() if k not in loaded]
+    if not loaded or missing:
+        raise ValueError(f"resume: {path} restored {len(loaded)} of {len(own)} CNN tensors; parameters left unset: {missing[:5]}"
+                         f"{' ...' if len(missing) > 5 else ''} (a TF-slim dump goes through cnn_variables= / --cnn-npz instead)")
+    if all(k in arrays for k in _CNN_OPT) and arrays[_CNN_OPT[0]].shape == tuple(trainer.m.shape):
+        trainer.m.copy_(torch.as_tensor(arrays[_CNN_OPT[0]]).to(trainer.m.device))
+        trainer.v.copy_(torch.as_tensor(arrays[_CNN_OPT[1]]).to(trainer.v.device))
+        trainer.adam_t = int(arrays[_CNN_OPT[2]])
+        loaded += list(_CNN_OPT)
+    else:
+        raise ValueError(f"resume: {path} holds no Adam state for this CNN ({_CNN_OPT[0]} ...): it is not a checkpoint of a run to continue")
+    return loaded
+
+
 def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, width=299, height=299, restore=None,
-          cnn_variables=None, log=print, freeze_cnn=False, resume=None):
+          cnn_variables=None, log=print, freeze_cnn=False, resume=None, resume_cnn=None):
     """freeze_cnn: fix_e2e_tf_s2vt.py's variant (:120, :284 -- the CNN in the loop behind tf.stop_gradient; that script also runs
     batch 64 at lr 1e-3: the caller's cfg).
     restore: initialise the captioner's VARIABLES from a checkpoint of another run (an XE model, as the reference's saver.restore of
     tf_s2vt's file, which holds neither optimizer slots nor a counter, tf_s2vt.py:440): Adam starts from zero moments and the staircase
     from step 0 -- inheriting the XE run's moments and update count beside a CNN whose moments start at zero would bias-correct the
-    latter as if they had seen t updates.  resume: continue THIS run -- slots, update count and step counter are taken over."""
+    latter as if they had seen t updates.  resume: continue THIS run -- the captioner's slots, update count and step counter AND the CNN's
+    weights, batch-norm statistics, Adam moments and update count (resume_cnn, default: the `-cnn-<epoch>.npz` beside `resume`; missing or
+    non-matching -> an error, never a silent fresh CNN)."""
     import torch
     from . import e2e, irv2, model as M
     par = DataParallel(model.device if model is not None else None)      # cfg.batch_size is the GLOBAL batch (16 in the reference)
@@ -62,6 +114,8 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
         if cnn_variables is not None:
             log(f"cnn variables restored: {len(cnn.load_slim_checkpoint(cnn_variables))}")
     trainer = e2e.EndToEnd(model, cnn, seed=cfg.seed)
+    if resume:
+        log(f"cnn resumed: {len(load_cnn(trainer, resume_cnn or cnn_checkpoint_of(resume)))} tensors")
     rng = random.Random(cfg.seed)
     history = []
     for epoch in range(cfg.n_epochs):
@@ -91,7 +145,7 @@ def train(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, wi
 
 
 def train_reinforce(cfg: Config, sents, video_frames, vocabulary, cnn=None, model=None, width=299, height=299, restore=None, cnn_variables=None,
-                    log=print, resume=None, attr_vocabulary=None, test=None):
+                    log=print, resume=None, attr_vocabulary=None, test=None, resume_cnn=None):
     """The REINFORCE loop with the CNN in it: train() of reinforcement_e2e.py:1085-1140 (BASELINE configs[4]) and, with attr_vocabulary, of the
     multitask scripts (reinforce_multitask_e2e_attribute_loss.py:1085-1140: bag-of-words labels per video, the attribute head's term in the objective,
     the multilabel metrics of its test loop :1042-1073).  Per step: B x Tv jpgs -> ONE CNN forward -> cfg.multisample sampled + the greedy captions ->
@@ -121,6 +175,8 @@ def train_reinforce(cfg: Config, sents, video_frames, vocabulary, cnn=None, mode
         if cnn_variables is not None:
             log(f"cnn variables restored: {len(cnn.load_slim_checkpoint(cnn_variables))}")
     trainer = e2e.EndToEnd(model, cnn, seed=cfg.seed)
+    if resume:
+        log(f"cnn resumed: {len(load_cnn(trainer, resume_cnn or cnn_checkpoint_of(resume)))} tensors")
 
     def side(sents_, frames_):
         index = data.CaptionIndex(sents_)
@@ -198,7 +254,8 @@ def main():
     ap.add_argument("--train-sents", required=True); ap.add_argument("--frames", required=True)
     ap.add_argument("--vocab", required=True); ap.add_argument("--cnn-npz")
     ap.add_argument("--restore", help="variables only, from another run's checkpoint (e.g. the XE model)")
-    ap.add_argument("--resume", help="a checkpoint of this run: variables, Adam slots, update count, step counter")
+    ap.add_argument("--resume", help="a checkpoint of this run: variables, Adam slots, update count, step counter (+ the CNN's, from the -cnn- file beside it)")
+    ap.add_argument("--resume-cnn", help="the CNN checkpoint to resume from when it is not the one beside --resume")
     ap.add_argument("--epochs", type=int, default=30); ap.add_argument("--batch-size", type=int, default=16)
     ap.add_argument("--model-path", default="./new_e2e_models")
     ap.add_argument("--freeze-cnn", action="store_true", help="fix_e2e_tf_s2vt.py: no gradient into the CNN")
@@ -217,9 +274,10 @@ def main():
         test = data.get_video_frame_caption_pair(a.test_sents, a.frames, cfg.n_video_lstm_step) if a.test_sents else None
         attr = [l.strip() for l in open(a.attr_vocab)] if a.attr_vocab else None
         train_reinforce(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, resume=a.resume, cnn_variables=variables,
-                        attr_vocabulary=attr, test=test)
+                        attr_vocabulary=attr, test=test, resume_cnn=a.resume_cnn)
         return
-    train(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, resume=a.resume, cnn_variables=variables, freeze_cnn=a.freeze_cnn)
+    train(cfg, sents, frames, data.read_vocabulary(a.vocab), restore=a.restore, resume=a.resume, cnn_variables=variables, freeze_cnn=a.freeze_cnn,
+          resume_cnn=a.resume_cnn)
 
 
 if __name__ == "__main__":

@@ -272,3 +272,28 @@ def test_bench_watchdog_delivers_the_blocking_mode_line_when_the_overlapped_prob
     cfg = out["config"]
     assert out["n_gpus"] == 2 and cfg["dp_overlap"] is False and cfg["replica_max_abs_diff"] == 0.0 and out["value"] > 0
     assert cfg["dp_overlap_probe_ms"]["off"] > 0 and str(cfg["dp_overlap_probe_ms"]["on"]).startswith("stalled")
+
+
+@pytest.mark.parametrize("exit_code", [0, 7])
+def test_bench_delivers_the_blocking_mode_line_when_the_overlapped_probe_raises(exit_code):
+    """an exception inside the overlapped probe (replica drift asserts, an RCCL error) must not lose the finished blocking-mode
+    measurement either: ONE line, dp_overlap_probe_ms.on carrying the error string; rc 0 by default, S2VT_BENCH_STALL_EXIT_CODE for callers that
+    want such a run to be distinguishable."""
+    import json
+    import subprocess
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "S2VT_DP_OVERLAP")}
+    env.update(S2VT_DIST_BACKEND="nccl" if torch.cuda.device_count() >= 2 else "gloo", S2VT_BENCH_FAKE_FAIL="1", S2VT_BENCH_WATCHDOG_S="60",
+               S2VT_BENCH_STALL_EXIT_CODE=str(exit_code))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert (r.returncode == 0) == (exit_code == 0), r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["dp_overlap"] is False and cfg["replica_max_abs_diff"] == 0.0 and out["value"] > 0
+    on = str(cfg["dp_overlap_probe_ms"]["on"])
+    assert cfg["dp_overlap_probe_ms"]["off"] > 0 and on.startswith("failed on rank") and "AssertionError" in on

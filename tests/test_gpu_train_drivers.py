@@ -141,6 +141,28 @@ def test_e2e_driver_frames_to_checkpoint(tmp_path):
     assert os.path.exists(hist[-1]["checkpoint"]) and os.path.exists(hist[-1]["cnn_checkpoint"])
     g = trainer.generate(torch.from_numpy(data.image_reading_processing([frames["vid0"], frames["vid1"]], 24, 24)))
     assert g.shape == (2, 8)
+    # resume continues BOTH halves: a fresh, differently initialised CNN + captioner pick up the run's variables, Adam moments and
+    # update counts -- the CNN's from the `-cnn-<epoch>.npz` beside the captioner's checkpoint
+    import dataclasses
+    torch.manual_seed(123)
+    cnn2 = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, stride=2), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(),
+                               torch.nn.Linear(8, 24), torch.nn.ReLU())
+    cfg0 = dataclasses.replace(cfg, n_epochs=0)
+    tr2, _ = train_e2e.train(cfg0, sents, frames, vocab, cnn=cnn2, width=24, height=24, log=lambda *_: None, resume=hist[-1]["checkpoint"])
+    assert train_e2e.cnn_checkpoint_of(hist[-1]["checkpoint"]) == hist[-1]["cnn_checkpoint"]
+    assert torch.equal(tr2.theta, trainer.theta) and torch.equal(tr2.m, trainer.m) and torch.equal(tr2.v, trainer.v)
+    assert tr2.adam_t == trainer.adam_t > 0 and float(tr2.m.abs().sum()) > 0
+    assert tr2.model.global_step == trainer.model.global_step and tr2.model.adam_t == trainer.model.adam_t
+    assert torch.equal(tr2.model.store.theta, trainer.model.store.theta) and torch.equal(tr2.model.store.m, trainer.model.store.m)
+    assert torch.equal(tr2.generate(torch.from_numpy(data.image_reading_processing([frames["vid0"], frames["vid1"]], 24, 24))), g)
+    # ... and refuses to continue with a CNN it could not restore
+    with pytest.raises(FileNotFoundError, match="no CNN checkpoint"):
+        train_e2e.train(cfg0, sents, frames, vocab, cnn=cnn2, width=24, height=24, log=lambda *_: None, resume=hist[-1]["checkpoint"],
+                        resume_cnn=str(tmp_path / "nowhere.npz"))
+    np.savez(tmp_path / "slim.npz", **{"Conv2d_1a_3x3/weights": np.zeros((3, 3, 3, 8), np.float32)})
+    with pytest.raises(ValueError, match="restored 0 of"):
+        train_e2e.train(cfg0, sents, frames, vocab, cnn=cnn2, width=24, height=24, log=lambda *_: None, resume=hist[-1]["checkpoint"],
+                        resume_cnn=str(tmp_path / "slim.npz"))
 
 
 def test_e2e_reinforce_driver(tmp_path):

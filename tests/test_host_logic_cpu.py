@@ -338,3 +338,43 @@ def test_python_dash_m_runs_the_drivers_through_the_import_alias():
     for mod, flag in (("train_rl", "--attr-vocab"), ("train_xe", "--train-sents"), ("train_e2e", "--reinforce"), ("train_attention", "--frames")):
         r = subprocess.run([sys.executable, "-m", "s2vt_amd." + mod, "--help"], cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and flag in r.stdout, (mod, r.stderr[-1500:])
+
+
+# ---- round 6 ---------------------------------------------------------------------------------------------------------------------
+def test_multitask_class_surface_constructor_and_tuples():
+    import pytest
+    """SURVEY 8(b): the multitask / end-to-end class's constructor (reinforce_multitask_e2e_attribute_loss.py:71-76: the base twelve, then
+    width, height, channels, feature_dim, label_dim, alpha -- positionally) and the lengths / placeholder shapes of its build_* tuples
+    (:226 6-tuple, :380 6-tuple; multitask_e2e_attribute_s2vt.py:223 7-tuple; reinforce_multitask_e2e_attribute_s2vt.py:226,375 5 / 4)."""
+    from s2vt_amd import model as M, multitask
+    m = M.Video_Caption_Generator(24, 50, 8, 16, 2, 8, 3, 5, None, 1, 0.00005, 0.9, 9, 11, 3, 24, 6, 0.3, device="cpu")
+    assert (m.width, m.height, m.channels, m.feature_dim, m.label_dim, m.alpha) == (9, 11, 3, 24, 6, 0.3)
+    assert tuple(m.store.p["attr_W"].shape) == (24, 6) and m._decay_everything()
+    with pytest.raises(ValueError, match="feature_dim"):
+        M.Video_Caption_Generator(24, 50, 8, 16, 2, 8, 3, 5, feature_dim=32, label_dim=6, device="cpu")
+    base = M.Video_Caption_Generator(24, 50, 8, 16, 2, 8, 3, 5, device="cpu")
+    assert len(base.build_model()) == 5 and len(base.build_loss()) == 4 and not base._decay_everything()
+    mm = multitask.Video_Caption_Generator(1536, 50, 8, 16, 2, 8, 3, 5, device="cpu")
+    assert (mm.width, mm.height, mm.channels, mm.feature_dim, mm.label_dim, mm.alpha, mm.multisample) == (299, 299, 3, 1536, 400, 0.2, 1)
+    loss, video, caption, caption_mask, probs, true_labels = mm.build_model()
+    assert video.shape == (2, 3, 1536) and true_labels.shape == (2, 400) and caption.shape == (2, 5)
+    assert len(mm.build_model(with_multilabel_loss=True)) == 7
+    loss, video, caption, caption_mask, true_labels, multilabel_loss = mm.build_loss()
+    assert true_labels.shape == (2, 400) and multilabel_loss.inputs == [video, true_labels]
+    # the lambda-mixed script's class: attribute head commented out (:58-60) -> label_dim=0 -> the 5- / 4-tuples, every variable decayed
+    s2 = multitask.Video_Caption_Generator(1536, 50, 8, 16, 2, 8, 3, 5, label_dim=0, device="cpu")
+    assert len(s2.build_model()) == 5 and len(s2.build_loss()) == 4 and s2._decay_everything()
+    # with a CNN attached the placeholders are the frame placeholders [batch, Tv, height, width, channels] (:118)
+    s2.e2e = object()
+    assert s2.build_model()[1].shape == (2, 3, 299, 299, 3) and s2.build_sampler()[1].shape == (None, 3, 299, 299, 3)
+    # train-op wiring: which placeholders each form reads
+    s2.e2e = None
+    r, b = mm.placeholder("rewards", [None]), mm.placeholder("base_line", [None])
+    bl = mm.build_loss()
+    op, sl = mm.multitask_train_op(bl, r, b, 1e-3, alpha=0.2)
+    assert op.inputs == [bl[1], bl[2], bl[3], r, b, bl[4]] and sl.fn is op.fn
+    bm, bl = s2.build_model(), s2.build_loss()
+    op, _ = s2.multitask_train_op(bl, r, b, 1e-3, clip_norm=5, build_model_outputs=bm, lambda_loss=0.5)
+    assert op.inputs == [bl[1], bl[2], bl[3], r, b, bm[1], bm[2], bm[3]]
+    with pytest.raises(ValueError, match="build_model_outputs"):
+        s2.multitask_train_op(bl, r, b, 1e-3, lambda_loss=0.5)
