@@ -19,6 +19,8 @@ struct CfgEntry {
     KernelFn vec, scalar;   // 16-byte vector loads / scalar loads (unaligned or odd shapes)
     int BM, CG, NT, lds_bytes;
     KernelFn vec_om, scalar_om;   // the live-row forms (GemmArgs::omap / m_dev): cell-step and pick tiles only
+    int fallback;                 // LDS-DMA entries (vector path only): the table index of the register-staged tile that takes the launch
+                                  // when the operands are not 16-byte aligned (-1: this entry has a scalar form of its own)
 };
 
 template <int WM, int WN, int TM, int TN, int NG, int EPI, int BKT = 32, int PW = 0, bool BT = false>
@@ -31,7 +33,18 @@ constexpr CfgEntry make_entry(const char* name)
         om_s = gemm_kernel<WM, WN, TM, TN, NG, EPI, false, BKT, PW, BT, true>;
     }
     return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT>,
-                    gemm_kernel<WM, WN, TM, TN, NG, EPI, false, BKT, PW, BT>, C::BM, C::CG, C::NT, C::LDS_FLOATS * 4, om, om_s};
+                    gemm_kernel<WM, WN, TM, TN, NG, EPI, false, BKT, PW, BT>, C::BM, C::CG, C::NT, C::LDS_FLOATS * 4, om, om_s, -1};
+}
+// LDS-DMA ring tiles (gemm_mfma.h, DM > 0): PW loader waves issue buffer_load ... lds pieces DM stages deep, the MFMA waves only read
+// fragments and multiply.  Vector path only; `fallback` names the register-staged tile for unaligned operands.
+template <int WM, int WN, int TM, int TN, int NG, int EPI, int BKT, int PW, int DM, bool BT = false>
+constexpr CfgEntry make_dma_entry(const char* name, int fallback)
+{
+    using C = GemmCfg<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT, DM>;
+    KernelFn om = nullptr;
+    if constexpr (EPI == EPI_LSTM || EPI == EPI_LSTM_GW || EPI == EPI_PICK) om = gemm_kernel<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT, true, DM>;
+    return CfgEntry{name, gemm_kernel<WM, WN, TM, TN, NG, EPI, true, BKT, PW, BT, false, DM>, nullptr, C::BM, C::CG, C::NT, C::LDS_FLOATS * 4, om,
+                    nullptr, fallback};
 }
 
 // name = BMxBN(wavesMxwavesN)
@@ -44,6 +57,11 @@ const CfgEntry kStore[] = {
     make_entry<2, 2, 2, 3, 1, EPI_STORE>("64x96(2x2)"),
     make_entry<2, 2, 3, 3, 1, EPI_STORE>("96x96(2x2)"),
     make_entry<2, 2, 3, 4, 1, EPI_STORE>("96x128(2x2)"),
+    // LDS-DMA ring (round 6): 4 loader waves, 2 stages
+    make_dma_entry<2, 2, 4, 4, 1, EPI_STORE, 32, 4, 2>("128x128(2x2)+4dma2", 2),
+    make_dma_entry<2, 2, 3, 3, 1, EPI_STORE, 32, 4, 2>("96x96(2x2)+4dma2", 6),
+    make_dma_entry<2, 2, 3, 3, 1, EPI_STORE, 32, 4, 3>("96x96(2x2)+4dma3", 6),
+    make_dma_entry<2, 2, 4, 4, 1, EPI_STORE, 32, 2, 2>("128x128(2x2)+2dma2", 2),
 };
 // the same tiles for C = A . W^T with W given as [N][K] (backward data-gradient products): index-compatible with kStore
 const CfgEntry kStoreNT[] = {
@@ -55,6 +73,10 @@ const CfgEntry kStoreNT[] = {
     make_entry<2, 2, 2, 3, 1, EPI_STORE, 32, 0, true>("nt64x96(2x2)"),
     make_entry<2, 2, 3, 3, 1, EPI_STORE, 32, 0, true>("nt96x96(2x2)"),
     make_entry<2, 2, 3, 4, 1, EPI_STORE, 32, 0, true>("nt96x128(2x2)"),
+    make_dma_entry<2, 2, 4, 4, 1, EPI_STORE, 32, 4, 2, true>("nt128x128(2x2)+4dma2", 2),
+    make_dma_entry<2, 2, 3, 3, 1, EPI_STORE, 32, 4, 2, true>("nt96x96(2x2)+4dma2", 6),
+    make_dma_entry<2, 2, 3, 3, 1, EPI_STORE, 32, 4, 3, true>("nt96x96(2x2)+4dma3", 6),
+    make_dma_entry<2, 2, 4, 4, 1, EPI_STORE, 32, 2, 2, true>("nt128x128(2x2)+2dma2", 2),
 };
 const CfgEntry kLstm[] = {
     // all four gates of 16 (32) units in one wave
@@ -72,8 +94,17 @@ const CfgEntry kLstm[] = {
     // + 4 loader waves (the MFMA waves issue no loads / LDS stores): 3-5 % over the plain tiles at M = 320 / 384
     make_entry<1, 4, 5, 1, 4, EPI_LSTM_GW, 32, 4>("gw80x16u(1x4)+4"),
     make_entry<1, 4, 6, 1, 4, EPI_LSTM_GW, 32, 4>("gw96x16u(1x4)+4"),
+    // LDS-DMA ring (round 6): 4 loader waves x DM stages; M <= 64: 16-row tiles, 2 / 4 loader waves, 8 / 5 stages deep
+    make_dma_entry<1, 4, 6, 1, 4, EPI_LSTM_GW, 32, 4, 4>("gw96x16u(1x4)+4dma4", 11),
+    make_dma_entry<1, 4, 1, 1, 4, EPI_LSTM_GW, 32, 2, 8>("gw16x16u(1x4)+2dma8", 9),
+    make_dma_entry<1, 4, 1, 1, 4, EPI_LSTM_GW, 64, 4, 5>("gw16x16u(1x4)k64+4dma5", 9),
+    make_dma_entry<1, 4, 2, 1, 4, EPI_LSTM_GW, 32, 4, 6>("gw32x16u(1x4)+4dma6", 4),
+    make_dma_entry<1, 4, 4, 1, 4, EPI_LSTM_GW, 32, 4, 4>("gw64x16u(1x4)+4dma4", 6),
+    make_dma_entry<1, 4, 6, 1, 4, EPI_LSTM_GW, 64, 4, 3>("gw96x16u(1x4)k64+4dma3", 11),
+    make_dma_entry<1, 4, 6, 1, 4, EPI_LSTM_GW, 32, 4, 6>("gw96x16u(1x4)+4dma6", 11),
 };
 constexpr int kLstmGw80L = 10, kLstmGw96L = 11;
+constexpr int kLstmGw96D = 12, kLstmGw16D = 13, kLstmGw16k64D = 14, kLstmGw32D = 15, kLstmGw64D = 16, kLstmGw96D6 = 18;
 constexpr int kLstmGw16k64 = 9;     // 64-deep chunks for the M <= 64 step: 8 MFMAs per wave per 32-deep chunk leave the barrier dominant
 constexpr int kLstmGwFirst = 3;      // index of gw16x16u; the gw entries follow in order of rows
 const CfgEntry kPick[] = {
@@ -84,12 +115,33 @@ const CfgEntry kPick[] = {
     make_entry<2, 2, 2, 3, 1, EPI_PICK>("64x96(2x2)"),
     make_entry<2, 2, 3, 2, 1, EPI_PICK>("96x64(2x2)"),
     make_entry<2, 2, 1, 3, 1, EPI_PICK>("32x96(2x2)"),
+    // LDS-DMA ring (round 6)
+    make_dma_entry<2, 2, 2, 3, 1, EPI_PICK, 32, 2, 2>("64x96(2x2)+2dma2", 4),
+    make_dma_entry<2, 2, 2, 3, 1, EPI_PICK, 32, 4, 2>("64x96(2x2)+4dma2", 4),
+    make_dma_entry<2, 2, 1, 3, 1, EPI_PICK, 32, 4, 6>("32x96(2x2)+4dma6", 6),
+    make_dma_entry<2, 2, 1, 3, 1, EPI_PICK, 32, 2, 6>("32x96(2x2)+2dma6", 6),
+    make_dma_entry<2, 2, 3, 3, 1, EPI_PICK, 32, 2, 3>("96x96(2x2)+2dma3", 4),
+    make_dma_entry<2, 2, 3, 3, 1, EPI_PICK, 32, 4, 3>("96x96(2x2)+4dma3", 4),
+    make_dma_entry<2, 2, 1, 3, 1, EPI_PICK, 64, 4, 4>("32x96(2x2)k64+4dma4", 6),
+    make_dma_entry<2, 2, 3, 3, 1, EPI_PICK, 64, 4, 2>("96x96(2x2)k64+4dma2", 4),
 };
+constexpr int kPick64x96D2 = 7, kPick64x96D4 = 8, kPick32x96D4 = 9, kPick32x96D2 = 10;
 // vocab pick, tile by M (tools/tune_pick_m.py on MI355X, H = 1000, |V| = 12000; us per launch 64x96 / 64x64 / 32x96):
 // M=64: 62/51/49, 128: 63/57/58, 192: 76/75/67, 256: 78/76/76, 320: 102/90/92, 384: 101/110/103.  Below M ~ 128 every
 // tile sits on a ~50 us floor (one workgroup per CU streaming its 192-256 KB slice of W and of the state, latency-bound).
 constexpr int kPick64x96 = 4, kPick64x64 = 0, kPick32x96 = 6;
-int choose_pick(int M) { return M <= 256 ? kPick32x96 : (M <= 352 ? kPick64x64 : kPick64x96); }
+// S2VT_DMA (default 1): the LDS-DMA ring tiles where they exist for the shape; 0 = the register-staged tiles of round 5 (A/B switch)
+bool dma_tiles()
+{
+    static const int on = [] { const char* e = getenv("S2VT_DMA"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+int choose_pick(int M)
+{
+    // (tools/tune_dma.py, round 6: no LDS-DMA pick tile beats its register-staged twin -- 64x96 needs three workgroups per CU, which leaves
+    //  the ring two stages, one chunk of look-ahead; the 32x96 tile at <= 64 rows is bound by its 32 barriers, not by its loads)
+    return M <= 256 ? kPick32x96 : (M <= 352 ? kPick64x64 : kPick64x96);
+}
 
 const CfgEntry* table(int epi, int* n)
 {
@@ -141,6 +193,7 @@ int choose(const CfgEntry* t, int n, int M, int N, int splits = 1)
     int best = 0;
     double best_cost = 1e300;
     for (int i = 0; i < n; ++i) {
+        if (t[i].fallback >= 0) continue;                  // LDS-DMA variants are selected by name (below), not by the cost model
         const long wgs = (long)ceil_div(M, t[i].BM) * ceil_div(N, t[i].CG) * (splits > 1 ? splits : 1);
         const long per_cu = (wgs + 255) / 256;
         const double tile = (double)t[i].BM * t[i].CG;
@@ -162,6 +215,10 @@ int choose_lstm(int M)
     if (M > 384) return ceil_div(M, 80) * 80 < ceil_div(M, 64) * 64 ? kLstmGw80L : kLstmGwFirst + 3;
     const int rows = ceil_div(ceil_div(M, 4), 16) * 16;       // 16, 32, ... rows per workgroup
     const int step = rows / 16;                                // 1..6 -> gw16 .. gw96
+    if (dma_tiles()) {
+        if (step == 4) return kLstmGw64D;                  // (tools/tune_dma.py: 16- and 32-row tiles are faster register-staged)
+        if (step >= 6) return kLstmGw96D6;
+    }
     if (step <= 1) return kLstmGw16k64;
     if (step == 5) return kLstmGw80L;
     if (step >= 6) return kLstmGw96L;
@@ -285,7 +342,16 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int cfg, hipStream_t st)
     const CfgEntry* t = table(epi, &n);
     // vocab pick: 64x96 tiles put ~3 independent workgroups on every CU at M = (K+1)*B = 384 (750 tiles); measured
     // 109 us vs 131 us for one 96x192 8-wave workgroup per CU and 136 us for 64x128
-    if (cfg < 0 || cfg >= n) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : (epi == EPI_PICK && a.M >= 32 ? choose_pick(a.M) : choose(t, n, a.M, a.N, a.splits));
+    const bool auto_cfg = cfg < 0 || cfg >= n;
+    if (auto_cfg) cfg = epi == EPI_LSTM ? choose_lstm(a.M) : (epi == EPI_PICK && a.M >= 32 ? choose_pick(a.M) : choose(t, n, a.M, a.N, a.splits));
+    // many-tile store shapes (>= two rounds of workgroups): the LDS-DMA ring twin of the chosen tile -- 119-127 -> 130-135 TFLOP/s on the
+    // step's batched products (tools/tune_store.py, round 6); short launches keep the register-staged tiles (their ring fills faster)
+    // (in the step, profiles/r06_dma_ab.json: logits 128x128 122.7 -> 129.6, hoisted 96x96 117.7 -> 124.9, dX2 nt128x128 126.8 -> 133.5;
+    //  dO2's nt96x96 -- K = 12000, W^T rows 48 KB apart -- went 124.1 -> 118.0 and keeps its register-staged tile)
+    if (auto_cfg && dma_tiles() && (epi == EPI_STORE || epi == EPI_STORE_NT) && a.splits <= 1 && (cfg == 2 || (cfg == 6 && epi == EPI_STORE)) &&
+        (long)ceil_div(a.M, t[cfg].BM) * ceil_div(a.N, t[cfg].CG) >= 512)
+        cfg = cfg == 2 ? 8 : 9;
+    if (t[cfg].fallback >= 0 && !can_vec(a, epi == EPI_STORE_NT)) cfg = t[cfg].fallback;       // LDS-DMA tiles: aligned operands only
     const CfgEntry& e = t[cfg];
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     const int mt = ceil_div(a.M, e.BM), nt = ceil_div(a.N, e.CG);

@@ -154,7 +154,7 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define S2VT_STAMP_AT(i)
 #endif
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0, bool BT = false>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0, bool BT = false, int DM = 0>
 struct GemmCfg {
     // K-chunk depth of this configuration (k per barrier): 32 by default; 64 for the tiles whose chunk holds few
     // MFMAs per wave (M = 64 step kernels: 8 per chunk at 32), where the per-chunk barrier and waits dominate
@@ -189,7 +189,11 @@ struct GemmCfg {
     static constexpr int BITEMS = BT ? BN * KQ : BK * (BN / 4);   // float4 items of one B chunk
     static constexpr int B4 = (BITEMS + NTL - 1) / NTL;
     static constexpr int BBUF = BT ? 4 * BN * KQ : BK * SB;       // floats per B stage
-    static constexpr int LOOP_FLOATS = 2 * (ABUF + BBUF);
+    // DM > 0 (with PW > 0): the PW loader waves feed a DM-stage LDS ring by LDS-DMA (buffer_load_dwordx4 ... lds) -- no staging
+    // registers, no ds_write pass -- and the images are laid out for that: A rows as they lie in memory ([BM][BK], 16-byte groups
+    // XOR-swizzled through the DMA source address), B rows unpadded ([BK][BN], rotated by 16 floats per k % 4); see the kernel.
+    static constexpr int DSTAGE = BM * BKT + BKT * BN;
+    static constexpr int LOOP_FLOATS = DM > 0 ? DM * DSTAGE : 2 * (ABUF + BBUF);
     static constexpr int LDS_FLOATS = (GW && BM * ZS > LOOP_FLOATS) ? BM * ZS : LOOP_FLOATS;
     // Prefetch ring depth (chunks in flight per thread), from a register budget: small tiles (few accumulators) get a
     // deeper ring, big tiles run two workgroups per CU and keep two chunks.
@@ -205,15 +209,16 @@ struct GemmCfg {
     static constexpr int PF_RAW = (PW > 0 ? 2 : 1) * S2VT_PF_BUDGET / (4 * (A4 + B4));   // loader waves hold no accumulators
     static constexpr int PF = PF_RAW < 2 ? 2 : (PF_RAW > 6 ? 6 : PF_RAW);
     static_assert(NG4 == 2 || NG4 == 4, "A planes: two or four b128 groups per row");
-    static_assert(!BT || (EPI == EPI_STORE && NG == 1 && PW == 0), "transposed-W form: plain store tiles only");
+    static_assert(!BT || (EPI == EPI_STORE && NG == 1 && (PW == 0 || DM > 0)), "transposed-W form: plain store tiles only");
     static_assert(GW || TN % NG == 0, "TN must split evenly over the column groups");
     static_assert(!GW || (WN == 4 && NG == 4), "gate-per-wave needs four waves along N");
+    static_assert(DM == 0 || (PW > 0 && VEC), "LDS-DMA ring: loader waves, aligned operands");
 };
 
-template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0, bool BT = false, bool OM = false>
+template <int WM, int WN, int TM, int TN, int NG, int EPI, bool VEC, int BKT = 32, int PW = 0, bool BT = false, bool OM = false, int DM = 0>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArgs g)
 {
-    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, BKT, PW, BT>;
+    using Cfg = GemmCfg<WM, WN, TM, TN, NG, EPI, VEC, BKT, PW, BT, DM>;
     constexpr int BK = Cfg::BK, KQ = Cfg::KQ, RS = Cfg::RS, PL = Cfg::PL, ABUF = Cfg::ABUF;   // (BK shadows the namespace-scope default)
     constexpr int NG4 = Cfg::NG4, SWZ_SHIFT = Cfg::SWZ_SHIFT;
     constexpr int NT = Cfg::NT, NTL = Cfg::NTL, NCW = WM * WN, BM = Cfg::BM, BN = Cfg::BN, TNG = Cfg::TNG, CG = Cfg::CG, SB = Cfg::SB;
@@ -454,6 +459,195 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_kernel(const GemmArg
     const int b_frag = BT ? lq * PLB + l15 * KQ : lq * SB + l15;
     auto b_col = [&](int j) __attribute__((always_inline)) { return Cfg::GW ? wn * CG + j * 16 : (j / TNG) * CG + (wn * TNG + j % TNG) * 16; };
 
+    if constexpr (DM > 0) {
+      // ---- LDS-DMA ring (round 6).  tools/micro/stream_probe.hip: a wave moves ~14.5 GB/s through buffer_load_dwordx4 however many
+      // loads it keeps in flight (one 1-KiB wave-instruction per ~170 clocks), a CU up to ~100 GB/s from L2 given enough waves -- and
+      // every sampler-step kernel of round 5 sat at ~20 GB/s per CU, its loads spliced into the MFMA stream (each issue holds the wave
+      // for that long) or carried by loader waves that also ran the LDS stores.  Here the PW loader waves do NOTHING but issue DMA
+      // pieces (global -> LDS, 1 KiB per wave-instruction, no staging registers, no ds_write), DM stages deep, and the MFMA waves
+      // nothing but fragment reads and MFMAs.  Same products in the same order per accumulator as the register-staged loop: the
+      // images differ, the arithmetic does not.
+      //   A stage: [BM][BK] floats, row r as it lies in memory, its 16-byte group q stored at position q ^ f(r) (the DMA source offset
+      //            does the permutation: a lane's 16 destination bytes are fixed, its source is free).  Fragment = ds_read_b32 of
+      //            float (k & 3) of group (k >> 2) ^ f(r): with f(r) = (r >> 1) & 7 for 128-byte rows (r & 15 for 256-byte rows) the
+      //            16 rows x 4 k of a wave hit 64 distinct banks.
+      //   B stage: [BK][BN] floats, unpadded; row kk rotated by R(kk) floats (16 (kk & 3) when rows are a multiple of 64 floats,
+      //            16 (kk >> 1 & 1) when they are 32 mod 64): the four k of a fragment read land in four disjoint 16-bank ranges.
+      static_assert(BK == 32 || BK == 64, "LDS-DMA ring: 128- or 256-byte A rows");
+      constexpr int NGR = BK / 4, RPP = 256 / BK;                   // 16-byte groups per A row; A rows per 1-KiB piece
+      constexpr int AST = BM * BK, BST = BK * BN, STG = AST + BST;
+      constexpr int APC = BM / RPP, BPC = BST / 256;                // 1-KiB pieces per chunk
+      static_assert(BM % RPP == 0 && BST % 256 == 0 && APC % PW == 0 && BPC % PW == 0, "pieces divide evenly over the loader waves");
+      static_assert(BT || BN % 64 == 0 || BN % 64 == 32, "B rotation");
+      //   B stage, W given transposed (BT: W^T[n][k], k contiguous -- the backward data-gradient products): [BN][BK], rows of n laid out
+      //            and read exactly like A's rows.
+      constexpr int APW = APC / PW, BPW = BPC / PW, PPW = APW + BPW;
+      constexpr int WAITD = (DM - 2) * PPW;
+      static_assert(DM >= 2 && WAITD <= 63, "vmcnt range");
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      auto brot = [](int kk) constexpr { return (BN % 64 == 0) ? 16 * (kk & 3) : 16 * ((kk >> 1) & 1); };
+      auto fswz = [](int r) constexpr { return BK == 32 ? (r >> 1) & 7 : r & 15; };
+      if (nchunks > 0) {
+        if (!mma_wave) {
+          // ================= loader waves
+          __builtin_amdgcn_s_setprio(3);
+          const int lw = wave - NCW;
+          uint32_t da0[APW], da1[APW], da2[APW], db[BPW];
+          int dq4[APW], dkk[BPW];
+          auto row_off1 = [&](int r, int sl, int rowmod, const int* rowidx, const unsigned long long* rowkey, int rks, int ld) __attribute__((always_inline)) {
+              int m = m0 + r;
+              int off = -1;
+              if (sl > 0 && m < MM) {
+                  if (rowmod <= 0 && !rowidx && !rowkey && !omapped) m -= m0;
+                  if (omapped) m = orow(m);
+                  if (rowmod > 0) m %= rowmod;
+                  if (rowidx) m = rowidx[m];
+                  if (rowkey) m = (int)(~(uint32_t)rowkey[(size_t)m * (rks > 0 ? rks : 1)]);
+                  off = m * ld + kbeg;
+              }
+              return off;
+          };
+#pragma unroll
+          for (int s_ = 0; s_ < APW; ++s_) {
+              const int r = (s_ * PW + lw) * RPP + lane / NGR, q = (lane % NGR) ^ fswz(r);
+              dq4[s_] = 4 * q;
+              const int o0 = row_off1(r, slen0, g.seg[0].rowmod, g.seg[0].rowidx, g.seg[0].rowkey, g.seg[0].rowkey_stride, g.seg[0].ld);
+              const int o1 = row_off1(r, slen1, g.seg[1].rowmod, g.seg[1].rowidx, g.seg[1].rowkey, g.seg[1].rowkey_stride, g.seg[1].ld);
+              const int o2 = row_off1(r, slen2, g.seg[2].rowmod, g.seg[2].rowidx, g.seg[2].rowkey, g.seg[2].rowkey_stride, g.seg[2].ld);
+              da0[s_] = o0 < 0 ? kOob : (uint32_t)(o0 + 4 * q) * 4u;
+              da1[s_] = o1 < 0 ? kOob : (uint32_t)(o1 + 4 * q) * 4u;
+              da2[s_] = o2 < 0 ? kOob : (uint32_t)(o2 + 4 * q) * 4u;
+          }
+#pragma unroll
+          for (int s_ = 0; s_ < BPW; ++s_) {
+              if constexpr (BT) {
+                  const int r = (s_ * PW + lw) * RPP + lane / NGR, q = (lane % NGR) ^ fswz(r);    // row of W^T = output column n0 + r
+                  dkk[s_] = 4 * q;
+                  db[s_] = n0 + r < g.N ? (uint32_t)((n0 + r) * g.ldw + 4 * q) * 4u : kOob;
+              } else {
+                  const int L = (s_ * PW + lw) * 256 + lane * 4;         // float index inside the B stage this lane's 16 bytes land at
+                  const int kk = L / BN, pp = L % BN;
+                  const int c0 = (pp - brot(kk) + BN) % BN;              // tile column of the group stored there
+                  const int grp = c0 / CG, cc = n0 + c0 % CG;
+                  dkk[s_] = kk;
+                  db[s_] = cc < g.N ? (uint32_t)(kk * g.ldw + grp * g.gstride + cc) * 4u : kOob;
+              }
+          }
+          const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, (int)kOob, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sp0), 0, (int)kOob, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sp1), 0, (int)kOob, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sp2), 0, (int)kOob, 0x00020000);
+          // the walk of the next chunk to issue (segment, k left in it, byte advances) -- the scalars of the register-staged loop
+          int wseg_ = -1, krem_ = 0;
+          uint32_t soffA_ = 0u, soffW_ = 0u;
+          uint32_t dva_[APW];
+#pragma unroll
+          for (int i_ = 0; i_ < APW; ++i_) dva_[i_] = kOob;
+#define S2VT_DWALK_ENTER()                                                                               \
+          do {                                                                                           \
+              ++wseg_;                                                                                   \
+              while (wseg_ < 3 && (wseg_ == 0 ? nch0 : (wseg_ == 1 ? nch1 : nch2)) == 0) ++wseg_;        \
+              if (wseg_ < 3) {                                                                           \
+                  krem_ = wseg_ == 0 ? slen0 : (wseg_ == 1 ? slen1 : slen2);                             \
+                  const int kw_ = (wseg_ == 0 ? skw0 : (wseg_ == 1 ? skw1 : skw2)) + kbeg;               \
+                  soffA_ = 0u;                                                                           \
+                  soffW_ = (uint32_t)kw_ * (BT ? 1u : (uint32_t)g.ldw) * 4u;                             \
+                  _Pragma("unroll") for (int i_ = 0; i_ < APW; ++i_)                                     \
+                      dva_[i_] = wseg_ == 0 ? da0[i_] : (wseg_ == 1 ? da1[i_] : da2[i_]);                \
+              } else {                                                                                   \
+                  krem_ = 0;                                                                             \
+              }                                                                                          \
+          } while (0)
+#define S2VT_DWALK_NEXT()                                                                                \
+          do {                                                                                           \
+              krem_ -= BK;                                                                               \
+              soffA_ += (uint32_t)BK * 4u;                                                               \
+              soffW_ += (uint32_t)BK * (BT ? 1u : (uint32_t)g.ldw) * 4u;                                 \
+              if (krem_ <= 0 && wseg_ < 3) S2VT_DWALK_ENTER();                                           \
+          } while (0)
+          auto issue_chunk = [&](int stage) __attribute__((always_inline)) {
+              float* const sb = smem + stage * STG;
+              // (the descriptor of the segment being walked: a wave-uniform choice between three SGPR quads)
+              static_for<0, APW>([&](auto s_) {
+                  constexpr int sl = decltype(s_)::value;
+                  const uint32_t vo = dq4[sl] < krem_ ? dva_[sl] : kOob;
+                  float* const dst = sb + (sl * PW + lw) * 256;
+                  if (wseg_ <= 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (lds_ptr)dst, 16, vo, soffA_, 0, 0);
+                  else if (wseg_ == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (lds_ptr)dst, 16, vo, soffA_, 0, 0);
+                  else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, (lds_ptr)dst, 16, vo, soffA_, 0, 0);
+              });
+              static_for<0, BPW>([&](auto s_) {
+                  constexpr int sl = decltype(s_)::value;
+                  const uint32_t vo = dkk[sl] < krem_ ? db[sl] : kOob;
+                  __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr)(sb + AST + (sl * PW + lw) * 256), 16, vo, soffW_, 0, 0);
+              });
+          };
+          S2VT_DWALK_ENTER();
+#pragma unroll
+          for (int j = 0; j < DM - 1; ++j) {
+              issue_chunk(j);
+              S2VT_DWALK_NEXT();
+          }
+          wait_vmcnt<WAITD>();
+          __syncthreads();
+          int stage_n = DM - 1;                                      // the stage chunk c + DM - 1 goes to
+          for (int c = 0; c < nchunks; ++c) {
+              issue_chunk(stage_n);
+              S2VT_DWALK_NEXT();
+              stage_n = stage_n + 1 == DM ? 0 : stage_n + 1;
+              S2VT_STAMP_AT(2);                                      // (dev build) loader: issue
+              wait_vmcnt<WAITD>();                                   // chunk c + 1 has landed; the younger ones stay in flight
+              S2VT_STAMP_AT(3);                                      // loader: ring wait
+              __syncthreads();
+              S2VT_STAMP_AT(7);                                      // loader: barrier
+          }
+          wait_vmcnt<0>();
+#undef S2VT_DWALK_ENTER
+#undef S2VT_DWALK_NEXT
+        } else {
+          // ================= MFMA waves: fragment reads + MFMAs, nothing else
+          const int fl4 = fswz(l15) << 2;                             // (rows of this lane differ by multiples of 16: one swizzle)
+          int aofs[KQ], bofs[TN];
+#pragma unroll
+          for (int ks = 0; ks < KQ; ++ks) aofs[ks] = ((wm * TM) * 16 + l15) * BK + ((ks * 4) ^ fl4) + lq;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+              bofs[j] = BT ? AST - ((wm * TM) * 16 + l15) * BK + (b_col(j) + l15) * BK        // (+ aofs[ks]: the same swizzled k offset, row b_col(j) + l15 of the W^T image)
+                           : AST + lq * BN + (b_col(j) + l15 + brot(lq)) % BN;
+          pin_epilogue_operands();
+          __syncthreads();
+          S2VT_STAMP_AT(0);
+          int stage_c = 0;
+          for (int c = 0; c < nchunks; ++c) {
+              const float* st = smem + stage_c * STG;
+              constexpr int MPK = TM * TN, PD = Cfg::PD;          // fragments are read PD k-steps ahead of their MFMAs (thin tiles: further)
+              float av[PD + 1][TM], bw[PD + 1][TN];
+              auto read_k = [&](auto ks_, float (&qa)[TM], float (&qb)[TN]) __attribute__((always_inline)) {
+                  constexpr int ks = decltype(ks_)::value;
+#pragma unroll
+                  for (int i = 0; i < TM; ++i) qa[i] = st[aofs[ks] + i * 16 * BK];
+#pragma unroll
+                  for (int jj = 0; jj < TN; ++jj) qb[jj] = BT ? st[bofs[jj] + aofs[ks]] : st[bofs[jj] + ks * 4 * BN];
+              };
+              static_for<0, (PD < KQ ? PD : KQ)>([&](auto k_) { constexpr int k = decltype(k_)::value; read_k(k_, av[k % (PD + 1)], bw[k % (PD + 1)]); });
+              S2VT_STAMP_AT(1);
+              static_for<0, KQ * MPK>([&](auto n_) {
+                  constexpr int n = decltype(n_)::value, ks = n / MPK, r = n % MPK, i = r / TN, jj = r % TN;
+                  if constexpr (r == 0) {
+                      if constexpr (ks + PD < KQ)
+                          read_k(std::integral_constant<int, ks + PD>{}, av[(ks + PD) % (PD + 1)], bw[(ks + PD) % (PD + 1)]);
+                      if constexpr (ks + 1 < KQ) __builtin_amdgcn_sched_barrier(0);
+                  }
+                  acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks % (PD + 1)][i], bw[ks % (PD + 1)][jj], acc[i][jj], 0, 0, 0);
+              });
+              S2VT_STAMP_AT(5);
+              stage_c = stage_c + 1 == DM ? 0 : stage_c + 1;
+              __syncthreads();
+              S2VT_STAMP_AT(6);
+          }
+        }
+      }
+    } else
     if constexpr (VEC) {
       if (nchunks > 0) {
         // ---- interleaved loop.  One wave per SIMD is the normal occupancy of the step kernels, so whatever is issued

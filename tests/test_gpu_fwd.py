@@ -49,7 +49,7 @@ def test_gemm_bitwise_all_tiles(gpu, oracle, M, K, N):
     b = rng.standard_normal(N).astype(np.float32)
     ref = oracle.bias_add(oracle.gemm_chain(A, W), b)
     dA, dW, db = _dev(A), _dev(W), _dev(b)
-    for cfg in range(-1, 8):                            # every entry of fwd.hip kStore (64x96, 96x96, 96x128 included)
+    for cfg in range(-1, 12):                           # every entry of fwd.hip kStore (64x96, 96x96, 96x128; 8-11: the LDS-DMA ring tiles)
         C = gpu.gemm([gpu.operand(dA)], dW, db, M=M, tile_cfg=cfg).cpu().numpy()
         assert np.array_equal(C, ref), f"tile cfg {cfg}"
     ref_t = oracle.det_tanh(ref)
@@ -72,7 +72,7 @@ def test_gemm_segments_gather_broadcast_cinit(gpu, oracle):
         oracle.gemm_chain(A2, W[k0 + k1:], ref)
         dW = _dev(W)
         segs = [gpu.operand(_dev(A0), rowmod=mod), gpu.operand(_dev(Tab), rowidx=_dev(idx)), gpu.operand(_dev(A2))]
-        for cfg in (-1, 0, 2):
+        for cfg in (-1, 0, 2, 8, 9):                   # (8, 9: LDS-DMA ring -- gathered / broadcast rows through the DMA source offsets)
             C = gpu.gemm(segs, dW, None, M=M, cinit=_dev(Ci), tile_cfg=cfg).cpu().numpy()
             assert np.array_equal(C, ref)
         # a zero segment is skipped but still consumes its rows of W
@@ -92,7 +92,7 @@ def test_lstm_cell_bitwise(gpu, oracle, M, E, H):
     for keep, code in ((1.0, 0), (0.9, 258), (0.5, 600)):
         mask = None if keep >= 1 else oracle.dropout_mask(77, vid, sid, code, keep, H)
         rc, rh, rout, rg, _ = oracle.lstm1_step(p, x, c, h, mask, keep, want_gates=True)
-        for cfg in range(-1, 13):
+        for cfg in range(-1, 18):                     # every tile of the table (12-16: the LDS-DMA ring tiles of round 6), 17 = out of range = auto
             gc, gh, gout, gg = gpu.lstm_cell_fwd(gpu.operand(_dev(x)), None, _dev(h), _dev(c), _dev(W), _dev(b), M, keep=keep,
                                                  seed=77, video_id=_dev(vid), sample_id=_dev(sid), drop_code=code,
                                                  want_gates=True, tile_cfg=cfg)
@@ -185,7 +185,7 @@ def test_gemm_nt_bitwise_all_tiles(gpu, oracle, M, K, N):
     b = rng.standard_normal(N).astype(np.float32)
     ref = oracle.bias_add(oracle.gemm_chain(A, np.ascontiguousarray(Wt.T)), b)
     dA, dWt, db = _dev(A), _dev(Wt), _dev(b)
-    for cfg in range(-1, 8):
+    for cfg in range(-1, 12):                           # (8-11: the LDS-DMA ring tiles with the W^T image)
         C = gpu.gemm_nt([gpu.operand(dA)], dWt, db, M=M, tile_cfg=cfg).cpu().numpy()
         assert np.array_equal(C, ref), f"tile cfg {cfg}"
     if K >= 8 and K % 8 == 0:                           # two K segments + a carried partial
@@ -193,8 +193,9 @@ def test_gemm_nt_bitwise_all_tiles(gpu, oracle, M, K, N):
         Ci = rng.standard_normal((M, N)).astype(np.float32)
         ref2 = Ci.copy(); oracle.gemm_chain(A, np.ascontiguousarray(Wt.T), ref2)
         segs = [gpu.operand(_dev(A[:, :k0])), gpu.operand(_dev(A[:, k0:]))]
-        C = gpu.gemm_nt(segs, dWt, None, M=M, cinit=_dev(Ci)).cpu().numpy()
-        assert np.array_equal(C, ref2)
+        for cfg in (-1, 8, 9):
+            C = gpu.gemm_nt(segs, dWt, None, M=M, cinit=_dev(Ci), tile_cfg=cfg).cpu().numpy()
+            assert np.array_equal(C, ref2), cfg
 
 
 def test_operands_larger_than_2gib_on_the_vector_path(gpu, oracle):
