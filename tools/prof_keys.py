@@ -4,11 +4,12 @@ import re
 
 
 def prof_key(kname):
-    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+), (true|false)(?:, (true|false))?>", kname)
+    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (\d+), (\d+), (true|false)(?:, (true|false))?(?:, (\d+))?>", kname)
     if m:
         WM, WN, TM, TN, NG, EPI, _, BKT, PW = [int(x) for x in m.groups()[:6]] + [0] + [int(x) for x in m.groups()[7:9]]
         bt = m.groups()[9] == "true"
-        sfx = (f"k{BKT}" if BKT != 32 else "") + (f"+{PW}" if PW else "") + ("[live]" if m.groups()[10] == "true" else "")
+        dm = int(m.groups()[11] or 0)                      # round 6: LDS-DMA ring stages (fwd.hip names "<tile>[k64]+<PW>dma<DM>")
+        sfx = (f"k{BKT}" if BKT != 32 else "") + (f"+{PW}" if PW else "") + (f"dma{dm}" if dm else "") + ("[live]" if m.groups()[10] == "true" else "")
         if EPI == 3:
             return f"1:gw{WM * TM * 16}x{TN * 16}u({WM}x{WN}){sfx}"
         if EPI == 1:
