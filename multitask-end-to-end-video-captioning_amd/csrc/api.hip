@@ -285,15 +285,22 @@ size_t carve_sample(Carver& c, const s2vt_dims* d, int B, int R, SampleWs* w)
     t.chain_sync = c.take<unsigned>(kChainSyncBytes / 4);
     t.chain_abuf = c.take<float>(chain_scratch_floats((int)H));
     t.wemb_p = t.w2_p = t.himg[0] = t.himg[1] = nullptr;
-#ifdef S2VT_EXPERIMENTAL       // (decode4.hip / decode_loop.hip: opt-in negative results, built by `make EXPERIMENTAL=1` only)
-    if ((R <= 64 || (R > 256 && R <= 384)) && (size_t)d->n_words * ((E + 15) / 16 * 16) * 4 < (1ull << 31)) {      // (sized by shape alone: the same carve whatever the device says)
+    // fragment-order operands of the persistent decode loop (decode_loop.hip: default at <= 64 rows since round 6; S2VT_DECLOOP=2 / S2VT_DEC4=1 also at
+    // 257-384 rows, where both forms measured no gain) -- sized by the shape and the two opt-in switches, never by the device: every caller of the
+    // size query sees the same carve.  (24.6 + 40 MB of packed operands at the bench dimensions: not taken at 384 rows unless asked for.)
+    static const bool big_rows = [] {
+        const char* a = getenv("S2VT_DECLOOP"); const char* b = getenv("S2VT_DEC4");
+        return (a && atoi(a) >= 2) || (b && b[0] == '1');
+    }();
+    static const bool small_rows = [] { const char* a = getenv("S2VT_DECLOOP"); return !a || atoi(a) >= 1; }();
+    if (((R <= 64 && small_rows) || (R > 256 && R <= 384 && big_rows)) && (H & 3) == 0 && H >= 132 &&
+        (size_t)d->n_words * ((E + 15) / 16 * 16) * 4 < (1ull << 31)) {
         Dec4Geom q;
         decode4_geometry(R, (int)H, (int)E, &q);
         t.wemb_p = c.take<float>((size_t)d->n_words * q.erow);
         t.w2_p = c.take<float>((size_t)q.ncg * 4 * q.ngt * 256);
         for (int i = 0; i < 2; ++i) t.himg[i] = c.take<float>((size_t)q.img_tiles * q.hgp * 256);
     }
-#endif
     t.live[0] = c.take<int32_t>(R); t.live[1] = c.take<int32_t>(R); t.nlive = c.take<int32_t>(Tc + 1);
     if (w) *w = t;
     return c.off;
@@ -414,7 +421,6 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
     NoiseIds ids{w.vid, w.sid, seed};
     const size_t enc = (size_t)Tv * B * H;   // where sample_encode left the encoder state: slot Tv of the history
     int cur2 = 0;
-#ifdef S2VT_EXPERIMENTAL
     // 257-384 rows: the LSTM2 step runs on fragment-order operands packed once per call (decode4.hip); same chain, same bits
     const bool loop1 = !stop_at_eos && w.wemb_p && (B & 15) == 0 && decode_loop_eligible(R, H, E, V) && chain_operands_ok(p->embed_word_W, V, w.himg[0]);
     const bool dec4 = !stop_at_eos && (loop1 || (w.wemb_p && decode4_eligible(R, H, E)));
@@ -443,9 +449,6 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
         HIP_TRY(hipGetLastError());
         return S2VT_OK;
     }
-#else
-    const bool dec4 = false;          // (the fragment-order decode step and the persistent decode loop are not part of the default build)
-#endif
     // Row groups (opt-in, S2VT_SAMPLE_GROUPS=2|3; round-4 verdict item 2): rows never interact, so the R rows can be cut into groups of whole
     // sample blocks, each group running its own chain of {LSTM2 step, pick} launches on a stream of its own -- pick(t) of one group
     // beside LSTM2(t+1) of another.  Same chains, same noise ids per row: token ids bit-identical.  Measured: see there.
@@ -492,7 +495,6 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
     }
     for (int t = 0; t < Tc; ++t) {
         const int nxt2 = cur2 ^ 1;
-#ifdef S2VT_EXPERIMENTAL
         if (dec4) {
             Dec4Launch a;
             std::memset(&a, 0, sizeof(a));
@@ -509,7 +511,6 @@ int sample_decode(const s2vt_dims* d, const s2vt_params* p, int B, int K, int wi
             cur2 = nxt2;
             continue;
         }
-#endif
         const float* h2p = t == 0 ? w.h2e + enc : w.h2[cur2];
         const float* c2p = t == 0 ? w.c2e + enc : w.c2[cur2];
         const int smod = t == 0 ? B : 0;
@@ -557,11 +558,7 @@ extern "C" {
 
 int s2vt_build_flags(void)
 {
-#ifdef S2VT_EXPERIMENTAL
-    return 1;
-#else
-    return 0;
-#endif
+    return 1;       // bit 0: the fragment-order decode kernels (decode4.hip, decode_loop.hip) are in this library (always, since round 6)
 }
 
 size_t s2vt_sample_workspace_bytes(const s2vt_dims* d, int32_t B, int32_t K, int32_t with_greedy)

@@ -56,6 +56,18 @@ struct DecLoopArgs {
 
 constexpr int kCG = 8, kNBUF = 3;                  // phase A: k-groups per chunk, LDS chunk buffers (decode4.hip's values)
 constexpr int kNB = 3, kRING = 3, kTNC = 3;        // phase B: LDS stages of W, A groups in flight per wave (pick_phase.hip: 3/3 .. 8/12 all 86-87 us), column tiles per workgroup
+// phase B at R <= 64 (round 6): waves 4-7 are LOADER waves -- state image and embed_word_W both go global -> LDS by DMA in stages of kKG k-groups,
+// kNSTG stages deep, and waves 0-3 only read fragments and multiply (tools/micro/stream_probe.hip: a wave that issues a vector-memory instruction is
+// held ~170 clocks, and this phase spent more wave-time issuing its own loads than multiplying: 28 us for 10 us of MFMAs)
+#ifndef S2VT_DL_KG
+#define S2VT_DL_KG 4
+#endif
+#ifndef S2VT_DL_NSTG
+#define S2VT_DL_NSTG 4
+#endif
+constexpr int kKG = S2VT_DL_KG, kNSTG = S2VT_DL_NSTG;
+constexpr int kB1Base = 8192;                      // floats: phase B's stages start behind phase A's ring + gate tiles (7424 floats at TPP = 1)
+constexpr int kB1Stage = 4 * kKG * 256 + kKG * 16 * 48;    // floats per stage: 4 row tiles x kKG image blocks + kKG x 16 rows x 48 columns of W
 
 #ifdef S2VT_DL_STAMP
 __device__ unsigned long long dl_stamp_acc[16];
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // (R <= 64: a k-group is 12 MFMAs per wave instead of 108 -- the W stages and the A fragments must be requested 3x as many groups
     //  ahead to cover the same latency: with the 384-row depths the loop ran 1070 cycles per group against 384 of MFMAs, round-5 stamps)
     constexpr int NB = TPP == 1 ? 8 : kNB, RING = TPP == 1 ? 6 : kRING, TNC = kTNC;
-    constexpr int ZA0 = NB * 16 * 48 > 4096 ? NB * 16 * 48 : 4096;   // floats: the accumulator slots of the pick epilogue start behind the W stages
+    constexpr int ZA0 = TPP == 1 ? kB1Base + kNSTG * kB1Stage : (NB * 16 * 48 > 4096 ? NB * 16 * 48 : 4096);   // floats: the accumulator slots of the pick epilogue start behind the W stages
     constexpr int TMW = TPP >= 5 ? 3 : 1;                      // phase B: row tiles per wave (8 waves x 3 >= 4 TPP; R <= 64: waves 0-3 one tile each)
     static_assert(8 * TMW >= 4 * TPP, "phase B covers every row tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -153,14 +165,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = 0; t < g.Tc; ++t) {
         const float* him_in = (t & 1) ? g.himg1 : g.himg0;
         float* him_out = (t & 1) ? g.himg0 : g.himg1;
+        // R <= 64: the loader waves (4-7) fetch embed_word_W for phase B; stage `sidx` of kKG x 16 rows x 48 columns goes to slot `slot` of
+        // phase B's LDS ring (behind phase A's region).  The first kNSTG - 1 stages are issued HERE, before phase A: they depend on nothing.
+        auto issue_w = [&](int sidx, int slot) __attribute__((always_inline)) {
+            if constexpr (TPP == 1) {
+                constexpr int KGc = kKG, WPWc = 12 * kKG / 16;
+                const int lw = wave - 4;
+                const int nstw = (g.hg + KGc - 1) / KGc;
+                float* const sb = smem + kB1Base + slot * kB1Stage + 4 * KGc * 256;
+                const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(g.Wout + (size_t)(sidx < nstw ? sidx : 0) * KGc * 16 * g.ldwo), 0, 0x7fffffff, 0x00020000);
+                static_for<0, WPWc>([&](auto n_) {
+                    constexpr int n = decltype(n_)::value;
+                    const int q = (lw + 4 * n) * 64 + lane, brow = q / 12, bc4 = (q % 12) * 4;
+                    const int k = sidx * KGc * 16 + brow;
+                    const unsigned off = (sidx < nstw && k < H && n0 + bc4 < g.V) ? (unsigned)(brow * g.ldwo + n0 + bc4) * 4u : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(sb + (lw + 4 * n) * 256), 16, off, 0, 0, 0);
+                });
+            }
+        };
+        if constexpr (TPP == 1) {
+            if (bact && wave >= 4) static_for<0, kNSTG - 1>([&](auto j_) { issue_w(decltype(j_)::value, decltype(j_)::value); });
+        }
         // =============================================================== phase A: LSTM2 step t
         if (aact && wave >= 4) {
             // waves 4-7 have no part in phase A: they keep its workgroup barriers (one per chunk, two behind the loop)
+            // (bare s_barrier: these waves touch nothing of phase A, and at R <= 64 their phase-B weight prefetch must stay in flight --
+            //  __syncthreads() would drain it in front of the first barrier and hold waves 0-3 there)
             for (int c0 = 0; c0 < nch; c0 += NBUF)
 #pragma unroll
-                for (int k = 0; k < NBUF; ++k) __syncthreads();
-            __syncthreads();
-            __syncthreads();
+                for (int k = 0; k < NBUF; ++k) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
         } else if (aact) {
             // tokens of this wave's DMA rows: the previous step's picks (agent-scope loads: the atomics' home), <bos> = 1 at t = 0
             int tokoff[TPP];
@@ -307,6 +343,97 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < TMW; ++i)
 #pragma unroll
                 for (int j = 0; j < TNC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int tvalid = 4 * TPP - wave * TMW;               // tiles of this wave inside the image
+            const bool bw = tvalid > 0;                            // (R <= 64: waves 4-7 hold no row tile -- they keep the barriers and leave the matrix pipe to waves 0-3)
+            if constexpr (TPP == 1) {
+              // ---- R <= 64: loader waves (4-7) + MFMA waves (0-3), kNSTG stages of kKG k-groups
+              constexpr int KG = kKG, NSTG = kNSTG, ASTG = 4 * KG * 256, STGF = kB1Stage;
+              static_assert(KG % 4 == 0, "W pieces divide over the four loader waves");
+              constexpr int WPW = 12 * KG / 16;                        // W pieces (64 float4 each) per loader wave per stage: KG * 16 rows * 12 float4 / 64 / 4
+              constexpr int IPW = KG + WPW;
+              static_assert((NSTG - 2) * IPW <= 63 && NSTG >= 2, "vmcnt range");
+              float* const Sb = smem + kB1Base;
+              const int nst = (kg + KG - 1) / KG;
+              if (wave >= 4) {
+                  const int lw = wave - 4;
+                  // image blocks of row tile lw (the image has 4 TPP = 4 tiles), sc1: another XCD wrote them
+                  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(him_out + (size_t)lw * g.hgp * 256, 0, g.hgp * 1024, 0x00020000);
+                  auto issue_a = [&](int sidx, int slot) __attribute__((always_inline)) {
+                      float* const sb = Sb + slot * STGF;
+                      static_for<0, KG>([&](auto gl_) {
+                          constexpr int gl = decltype(gl_)::value;
+                          const int gi = sidx * KG + gl;
+                          const int vo = (gi < kg && sidx < nst) ? lane * 16 : (int)0x80000000u;
+                          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(sb + (gl * 4 + lw) * 256), 16, vo, (gi < kg ? gi : 0) * 1024, 0, 16);
+                      });
+                  };
+                  // (the W parts of stages 0 .. NSTG-2 were issued during phase A -- they depend on nothing the step computes -- and have long landed)
+                  static_for<0, NSTG - 1>([&](auto j_) { issue_a(decltype(j_)::value, decltype(j_)::value); });
+                  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * KG) : "memory");
+                  __builtin_amdgcn_s_barrier();
+                  int slot_n = NSTG - 1;
+                  // iteration sidx issues stage sidx + NSTG - 1 (whole) and needs stage sidx + 1 landed: the instructions younger than that are
+                  // stages sidx + 2 .. sidx + NSTG - 1, of which those <= NSTG - 2 were image-only (KG instructions) -- peeled so the counts are constants
+                  static_for<0, NSTG - 2>([&](auto s_) {
+                      constexpr int sidx = decltype(s_)::value;
+                      if (sidx < nst) {
+                          issue_a(sidx + NSTG - 1, slot_n);
+                          issue_w(sidx + NSTG - 1, slot_n);
+                          slot_n = slot_n + 1 == NSTG ? 0 : slot_n + 1;
+                          constexpr int young = (NSTG - 3 - sidx) * KG + (sidx + 1) * IPW;     // image-only stages sidx+2 .. NSTG-2, whole stages NSTG-1 .. sidx+NSTG-1
+                          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(young) : "memory");
+                          __builtin_amdgcn_s_barrier();
+                      }
+                  });
+                  for (int sidx = NSTG - 2; sidx < nst; ++sidx) {
+                      issue_a(sidx + NSTG - 1, slot_n);
+                      issue_w(sidx + NSTG - 1, slot_n);
+                      slot_n = slot_n + 1 == NSTG ? 0 : slot_n + 1;
+                      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * IPW) : "memory");
+                      __builtin_amdgcn_s_barrier();
+                  }
+              } else {
+                  // MFMA waves.  The stage barrier sits BEFORE the last k-group's MFMAs (its fragments are already in registers): behind it the
+                  // next stage's first fragments are requested, and the barrier's latency and theirs pass under those twelve MFMAs.
+                  __builtin_amdgcn_s_barrier();
+                  int slot = 0;
+                  f32x4 a4[2];
+                  float bvv[2][4][TNC];
+                  auto read_g = [&](const float* sb, auto gl_, f32x4& qa, float (&qb)[4][TNC]) __attribute__((always_inline)) {
+                      constexpr int gl = decltype(gl_)::value;
+                      const f32x4* const ab = reinterpret_cast<const f32x4*>(sb) + wave * 64 + lane;
+                      const float* const wb = sb + ASTG + lq * 48 + l15;
+                      qa = ab[gl * 4 * 64];
+#pragma unroll
+                      for (int e = 0; e < 4; ++e)
+#pragma unroll
+                          for (int j = 0; j < TNC; ++j) qb[e][j] = wb[(gl * 16 + e * 4) * 48 + j * 16];
+                  };
+                  static_assert(KG % 2 == 0, "the first group of a stage takes register set 0");
+                  read_g(Sb, std::integral_constant<int, 0>{}, a4[0], bvv[0]);
+                  for (int sidx = 0; sidx < nst; ++sidx) {
+                      const float* const sb = Sb + slot * STGF;
+                      slot = slot + 1 == NSTG ? 0 : slot + 1;
+                      static_for<0, KG>([&](auto gl_) {
+                          constexpr int gl = decltype(gl_)::value;
+                          if constexpr (gl + 1 < KG) {
+                              read_g(sb, std::integral_constant<int, gl + 1>{}, a4[(gl + 1) & 1], bvv[(gl + 1) & 1]);
+                          } else {
+                              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // every fragment of this stage is in registers
+                              __builtin_amdgcn_s_barrier();                              // ... the loaders may refill its slot; the next stage has landed
+                              if (sidx + 1 < nst) read_g(Sb + slot * STGF, std::integral_constant<int, 0>{}, a4[0], bvv[0]);
+                          }
+                          __builtin_amdgcn_sched_barrier(0);
+                          static_for<0, 4>([&](auto e_) {
+                              constexpr int e = decltype(e_)::value;
+#pragma unroll
+                              for (int j = 0; j < TNC; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[gl & 1][e], bvv[gl & 1][e][j], acc[0][j], 0, 0, 0);
+                          });
+                          __builtin_amdgcn_sched_barrier(0);
+                      });
+                  }
+              }
+            } else {
             // W stage: 16 rows x 48 floats = 192 float4 = three 1-KiB DMA pieces; wave w < 3 issues piece w
             const int q = wave * 64 + lane, brow = q / 12, bc4 = (q % 12) * 4;
             auto issue_b = [&](int gi, int buf) __attribute__((always_inline)) {
@@ -319,8 +446,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             };
             // A fragments of this wave's row tiles: image block (tile, group) = 1 KB, lane-linear; sc1 (another XCD wrote it)
             // (wave w: row tiles 3w .. 3w+2; a tile beyond the 4 TPP of the image reads zeros through the bounds check)
-            const int tvalid = 4 * TPP - wave * TMW;               // tiles of this wave inside the image
-            const bool bw = tvalid > 0;                            // (R <= 64: waves 4-7 hold no row tile -- they keep the barriers and leave the matrix pipe to waves 0-3)
             const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(him_out + (size_t)wave * TMW * g.hgp * 256, 0,
                                                                                  (tvalid <= 0 ? 0 : (tvalid < TMW ? tvalid : TMW)) * g.hgp * 1024, 0x00020000);
             f32x4 a[RING][TMW];
@@ -381,6 +506,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 });
             }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DL_STAMP(4);
             // ---- the PICK epilogue of gemm_mfma.h (EPI_PICK, two-tier Gumbel-max) on this layout: accumulator (i, j)[r] = row
@@ -392,6 +518,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // instructions; unrolled six times it leaves the instruction cache): the accumulators go through a lane-private LDS
             // slot (each lane reads back what it wrote: no barrier), beyond the W stages other waves may still be reading.
             f32x4* const za = reinterpret_cast<f32x4*>(smem + ZA0) + wave * (TMW * TNC * 64) + lane;
+            if (bw || TPP != 1)              // (R <= 64: waves 4-7 are loader waves, they hold no accumulators and no slots)
 #pragma unroll
             for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -503,7 +630,8 @@ struct DecLoopCfg { int tpp; DecLoopFn fn; const char* name; };
 const DecLoopCfg kDecLoop[] = {{5, decode_loop_kernel<5>, "decloop(m320)"}, {6, decode_loop_kernel<6>, "decloop(m384)"}, {1, decode_loop_kernel<1>, "decloop(m64)"}};
 int decloop_lds_bytes(int tpp)
 {
-    const int nb = tpp == 1 ? 8 : kNB, za0 = nb * 16 * 48 > 4096 ? nb * 16 * 48 : 4096;
+    if (tpp == 1) return (kB1Base + kNSTG * kB1Stage) * 4 + 4 * kTNC * 64 * 16;      // phase A region | phase B stages | accumulator slots of waves 0-3 (one row tile x kTNC column tiles each)
+    const int nb = kNB, za0 = nb * 16 * 48 > 4096 ? nb * 16 * 48 : 4096;
     const int a = (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4, b = za0 * 4 + 8 * 3 * kTNC * 64 * 16;      // phase A ring + gate tiles | phase B stages + accumulator slots
     return a > b ? a : b;
 }
@@ -513,12 +641,14 @@ constexpr int kDecLoopGrid = 256;
 
 }  // namespace
 
-// The shape fits, the device has a CU for every workgroup, and the form is switched on (S2VT_DECLOOP=1; default off until it
-// is the faster one -- see DESIGN.md section 11 for the measurement).
+// The shape fits, the device has a CU for every workgroup, and the form is switched on for it.  S2VT_DECLOOP: unset / 1 = at <= 64 rows (round 6: the
+// loader-wave form of phase B made it the faster one there -- multitask step 4.12 -> 3.94 ms, 57 -> 40 us per decode step); 2 = also at 257-384 rows
+// (measured slower than the launches, profiles/NOTES.md); 0 = off.
 bool decode_loop_eligible(int R, int H, int E, int V)
 {
-    static const int on = [] { const char* e = getenv("S2VT_DECLOOP"); return e ? atoi(e) : 0; }();
-    if (!on || !(R <= 64 || (R > 256 && R <= 384)) || (H & 3) || H < 132 || H > 1008 || E < 1 || (V & 3) || (V + 15) / 16 > kDecLoopGrid * kTNC) return false;
+    static const int on = [] { const char* e = getenv("S2VT_DECLOOP"); return e ? atoi(e) : 1; }();
+    const bool rows_ok = on >= 1 && (R <= 64 || (on >= 2 && R > 256 && R <= 384));
+    if (!rows_ok || (H & 3) || H < 132 || H > 1008 || E < 1 || (V & 3) || (V + 15) / 16 > kDecLoopGrid * kTNC) return false;
     if (chain_persistent_disabled()) return false;
     ChainHost h;
     if (!chain_host(&h) || h.num_cus < kDecLoopGrid) return false;

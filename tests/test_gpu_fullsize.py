@@ -65,14 +65,12 @@ def test_update_linearity_and_mask_normalisation(full):
 
 
 def test_fragment_order_decode_step_opt_in_bit_exact(gpu):
-    """decode4.hip (experimental build only, S2VT_DEC4=1: the sampler's LSTM2 step at 257-384 rows on fragment-order operands) draws
+    """decode4.hip (opt-in, S2VT_DEC4=1: the sampler's LSTM2 step at 257-384 rows on fragment-order operands) draws
     the token ids of the default path, bit for bit, at the bench dimensions (B = 64, K = 5: R = 384) and at R = 272."""
     import os
     import subprocess
     import sys
-    from test_gpu_decode_loop import experimental_lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = experimental_lib()
     code = r'''
 import os, sys
 sys.path.insert(0, os.environ["S2VT_ROOT"])
@@ -96,7 +94,7 @@ print("child ok")
     with tempfile.TemporaryDirectory() as td:
         for flag in ("0", "1"):
             f = os.path.join(td, f"ids{flag}.npz")
-            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, S2VT_ROOT=root, S2VT_DEC4=flag, S2VT_LIB=lib), capture_output=True, text=True,
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, S2VT_ROOT=root, S2VT_DEC4=flag), capture_output=True, text=True,
                                timeout=900)
             assert r.returncode == 0 and "child ok" in r.stdout, r.stderr[-3000:]
             res[flag] = dict(np.load(f))
