@@ -72,8 +72,11 @@ constexpr int kB1Stage = 4 * kKG * 256 + kKG * 16 * 48;    // floats per stage: 
 #ifdef S2VT_DL_STAMP
 __device__ unsigned long long dl_stamp_acc[16];
 #define DL_STAMP(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x == 40 && threadIdx.x == 0) atomicAdd(&dl_stamp_acc[i], n_ - st_prev); st_prev = n_; } while (0)
+// (loader wave 4 of the same workgroup: slots 8.. of the same table)
+#define DL_STAMP_L(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (blockIdx.x == 40 && threadIdx.x == 256) atomicAdd(&dl_stamp_acc[i], n_ - stl_prev); stl_prev = n_; } while (0)
 #else
 #define DL_STAMP(i) do { } while (0)
+#define DL_STAMP_L(i) do { } while (0)
 #endif
 
 template <int TPP>
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 {
 #ifdef S2VT_DL_STAMP
     unsigned long long st_prev = __builtin_readcyclecounter();
+    unsigned long long stl_prev = st_prev;
 #endif
     constexpr int ZS = 20;
     constexpr int CG = kCG, NBUF = kNBUF;
@@ -385,12 +389,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                           __builtin_amdgcn_s_barrier();
                       }
                   });
+                  DL_STAMP_L(8);                                       // (dev build) loader: everything up to the steady loop
                   for (int sidx = NSTG - 2; sidx < nst; ++sidx) {
                       issue_a(sidx + NSTG - 1, slot_n);
                       issue_w(sidx + NSTG - 1, slot_n);
                       slot_n = slot_n + 1 == NSTG ? 0 : slot_n + 1;
+                      DL_STAMP_L(9);                                   // loader: issue
                       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * IPW) : "memory");
+                      DL_STAMP_L(10);                                  // loader: data wait
                       __builtin_amdgcn_s_barrier();
+                      DL_STAMP_L(11);                                  // loader: barrier (waiting for the MFMA waves)
                   }
               } else {
                   // MFMA waves.  The stage barrier sits BEFORE the last k-group's MFMAs (its fragments are already in registers): behind it the

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev: A/B builds that differ in decode_loop.hip only (variants/lib_<name>.so):  bash tools/build_decloop_variants.sh stamp:"-DS2VT_DL_STAMP"
-# (experimental objects: run `make -C multitask-end-to-end-video-captioning_amd/csrc exp` first -- api_exp.o is api.hip built with -DS2VT_EXPERIMENTAL)
+# (experimental objects: run `make -C multitask-end-to-end-video-captioning_amd/csrc exp` first -- api.o is api.hip built with -DS2VT_EXPERIMENTAL)
 set -e
 cd "$(dirname "$0")/../multitask-end-to-end-video-captioning_amd/csrc"
 mkdir -p ../../variants
@@ -12,6 +12,6 @@ done
 wait
 for spec in "$@"; do
   name=${spec%%:*}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api_exp.o train.o attn.o attn_model.o attn_chain.o attn_chain_bwd.o session.o chain.o chain_bwd.o decode4.o /tmp/lvar_$name/decode_loop.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/lib_$name.so fwd.o aux.o api.o train.o attn.o attn_model.o attn_chain.o attn_chain_bwd.o session.o chain.o chain_bwd.o decode4.o /tmp/lvar_$name/decode_loop.o
 done
 ls ../../variants

@@ -22,4 +22,6 @@ a = np.array(list(out), dtype=np.float64)
 names = ["prologue (once)", "A: tokens+partial+chunk loop", "A: pointwise + image store", "A->B arrive + wait", "B: main loop", "B: pick epilogue", "B->A arrive + wait"]
 for n, v in zip(names, a):
     print(f"{n:<32} {v / TC:9.0f} shader cycles/step  ({v / TC / 2320:.1f} us at 2.32 GHz)")
+for i, n in ((8, "loader: rest of the step"), (9, "loader: stage issue"), (10, "loader: data wait"), (11, "loader: barrier")):
+    print(f"{n:<32} {a[i] / TC:9.0f} shader cycles/step  ({a[i] / TC / 2320:.1f} us)")
 print("total per step", a[1:7].sum() / TC / 2320, "us; timeouts", ops.chain_timeouts())
