@@ -55,7 +55,7 @@ struct DecLoopArgs {
 };
 
 constexpr int kCG = 8, kNBUF = 3;                  // phase A: k-groups per chunk, LDS chunk buffers (decode4.hip's values)
-constexpr int kNB = 3, kRING = 3, kTNC = 3;        // phase B: LDS stages of W, A groups in flight per wave (pick_phase.hip: 3/3 .. 8/12 all 86-87 us), column tiles per workgroup
+constexpr int kTNC = 3;                            // phase B: column tiles (16 vocabulary columns each) per workgroup
 // phase B at R <= 64 (round 6): waves 4-7 are LOADER waves -- state image and embed_word_W both go global -> LDS by DMA in stages of kKG k-groups,
 // kNSTG stages deep, and waves 0-3 only read fragments and multiply (tools/micro/stream_probe.hip: a wave that issues a vector-memory instruction is
 // held ~170 clocks, and this phase spent more wave-time issuing its own loads than multiplying: 28 us for 10 us of MFMAs)
@@ -95,13 +95,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert(YOUNGER <= 63, "vmcnt range");
     // (R <= 64: a k-group is 12 MFMAs per wave instead of 108 -- the W stages and the A fragments must be requested 3x as many groups
     //  ahead to cover the same latency: with the 384-row depths the loop ran 1070 cycles per group against 384 of MFMAs, round-5 stamps)
-    constexpr int NB = TPP == 1 ? 8 : kNB, RING = TPP == 1 ? 6 : kRING, TNC = kTNC;
-    constexpr int ZA0 = TPP == 1 ? kB1Base + kNSTG * kB1Stage : (NB * 16 * 48 > 4096 ? NB * 16 * 48 : 4096);   // floats: the accumulator slots of the pick epilogue start behind the W stages
-    constexpr int TMW = TPP >= 5 ? 3 : 1;                      // phase B: row tiles per wave (8 waves x 3 >= 4 TPP; R <= 64: waves 0-3 one tile each)
-    static_assert(8 * TMW >= 4 * TPP, "phase B covers every row tile");
+    constexpr int TNC = kTNC;
+    constexpr int ZA0 = TPP == 1 ? kB1Base + kNSTG * kB1Stage : 0;   // floats: the accumulator slots of the pick epilogue -- behind the stages (R <= 64), or IN the ring once it is dead (257-384 rows)
+    constexpr int TMW = TPP;                                   // phase B: row tiles per MFMA wave (waves 0-3: tile w * TPP + i of the image's 4 TPP); waves 4-7 load
+
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ab = smem;                                          // phase A: [NBUF][CG][PPG][64][4]
-    float* Bs = smem;                                          // phase B: [NB][16 * 48] (<= 4096 floats), then the accumulator slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* zb = smem + NBUF * CHF + (wave & 3) * (16 * ZS);
@@ -442,78 +441,88 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                   }
               }
             } else {
-            // W stage: 16 rows x 48 floats = 192 float4 = three 1-KiB DMA pieces; wave w < 3 issues piece w
-            const int q = wave * 64 + lane, brow = q / 12, bc4 = (q % 12) * 4;
-            auto issue_b = [&](int gi, int buf) __attribute__((always_inline)) {
-                if (wave < 3) {
-                    const int k = gi * 16 + brow;
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wout + (size_t)gi * 16 * g.ldwo), 0, 0x7fffffff, 0x00020000);
-                    const unsigned off = (k < H && gi < kg && n0 + bc4 < g.V) ? (unsigned)(brow * g.ldwo + n0 + bc4) * 4u : 0x80000000u;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(Bs + buf * (16 * 48) + wave * 256), 16, off, 0, 0, 0);
-                }
-            };
-            // A fragments of this wave's row tiles: image block (tile, group) = 1 KB, lane-linear; sc1 (another XCD wrote it)
-            // (wave w: row tiles 3w .. 3w+2; a tile beyond the 4 TPP of the image reads zeros through the bounds check)
-            const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(him_out + (size_t)wave * TMW * g.hgp * 256, 0,
-                                                                                 (tvalid <= 0 ? 0 : (tvalid < TMW ? tvalid : TMW)) * g.hgp * 1024, 0x00020000);
-            f32x4 a[RING][TMW];
-            static_for<0, RING>([&](auto r_) {
-                constexpr int r = decltype(r_)::value;
+              // ---- 257-384 rows (round 6, late): the same split -- waves 4-7 load, waves 0-3 multiply TPP row tiles x 3 column tiles each (the
+              // round-3 form had all eight waves load their own image blocks and multiply: 84 us of phase B for 60 us of MFMAs).  One k-group per
+              // stage (4 TPP image blocks + 3 KB of weights = 27 KB at 384 rows), kNSTG stages; the ring aliases phase A's LDS (the phases alternate).
+              constexpr int NSTG = kNSTG, ASTG = 4 * TPP * 256, STGF = ASTG + 16 * 48;
+              static_assert((NSTG - 2) * (TPP + 1) <= 63 && NSTG >= 3, "vmcnt range");
+              float* const Sb = smem;
+              const int nst = kg;
+              if (wave >= 4) {
+                  const int lw = wave - 4;
+                  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(him_out + (size_t)lw * TPP * g.hgp * 256, 0, TPP * g.hgp * 1024, 0x00020000);
+                  const int q = lw * 64 + lane, brow = q / 12, bc4 = (q % 12) * 4;       // this lane's float4 of the 16 x 48 weight stage (loaders 0-2)
+                  auto issue_stage = [&](int sidx, int slot) __attribute__((always_inline)) {
+                      float* const sb = Sb + slot * STGF;
+                      static_for<0, TPP>([&](auto i_) {
+                          constexpr int i = decltype(i_)::value;
+                          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(sb + (lw * TPP + i) * 256), 16, lane * 16, (i * g.hgp + sidx) * 1024, 0, 16);
+                      });
+                      if (lw < 3) {
+                          const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wout + (size_t)sidx * 16 * g.ldwo), 0, 0x7fffffff, 0x00020000);
+                          const int k = sidx * 16 + brow;
+                          const unsigned off = (k < H && n0 + bc4 < g.V) ? (unsigned)(brow * g.ldwo + n0 + bc4) * 4u : 0x80000000u;
+                          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(sb + ASTG + lw * 256), 16, off, 0, 0, 0);
+                      }
+                  };
+                  // (stages beyond the last are NOT issued -- an out-of-range DMA still writes zeros, and the ring is reused for the epilogue's
+                  //  accumulator slots: the tail of the loop therefore waits for everything instead of for a count)
 #pragma unroll
-                for (int i = 0; i < TMW; ++i) a[r][i] = bload16_sc1(rsI, lane * 16, (i * g.hgp + (r < kg ? r : kg - 1)) * 1024);
-            });
-            static_for<0, NB - 1>([&](auto g_) { issue_b(decltype(g_)::value, decltype(g_)::value); });
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int buf = 0, nbuf = NB - 1;
-            float bvc[4][TNC], bvn[4][TNC];
-            {
-                const float* b = Bs + lq * 48 + l15;
+                  for (int j = 0; j < NSTG - 1; ++j)
+                      if (j < nst) issue_stage(j, j);
+                  if (lw < 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (TPP + 1)) : "memory");
+                  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * TPP) : "memory");
+                  __builtin_amdgcn_s_barrier();
+                  int slot_n = NSTG - 1;
+                  for (int sidx = 0; sidx < nst; ++sidx) {
+                      if (sidx + NSTG - 1 < nst) {
+                          issue_stage(sidx + NSTG - 1, slot_n);
+                          slot_n = slot_n + 1 == NSTG ? 0 : slot_n + 1;
+                          if (lw < 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (TPP + 1)) : "memory");
+                          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * TPP) : "memory");
+                      } else {
+                          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                      }
+                      __builtin_amdgcn_s_barrier();
+                  }
+              } else {
+                  __builtin_amdgcn_s_barrier();
+                  f32x4 a4[2][TPP];
+                  float bvv[2][4][TNC];
+                  auto read_s = [&](int slot, f32x4 (&qa)[TPP], float (&qb)[4][TNC]) __attribute__((always_inline)) {
+                      const float* const sb = Sb + slot * STGF;
+                      const f32x4* const ab = reinterpret_cast<const f32x4*>(sb) + (wave * TPP) * 64 + lane;
+                      const float* const wb = sb + ASTG + lq * 48 + l15;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                      for (int i = 0; i < TPP; ++i) qa[i] = ab[i * 64];
 #pragma unroll
-                    for (int j = 0; j < TNC; ++j) bvc[e][j] = b[e * 4 * 48 + j * 16];
-            }
-            for (int g0 = 0; g0 < kg; g0 += RING) {
-                static_for<0, RING>([&](auto r_) {
-                    constexpr int r = decltype(r_)::value;
-                    const int gi = g0 + r;
-                    if (gi < kg) {
-                        issue_b(gi + NB - 1, nbuf);
-                        const int b1 = buf + 1 == NB ? 0 : buf + 1;
-                        const float* b = Bs + b1 * (16 * 48) + lq * 48 + l15;
+                      for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                          for (int j = 0; j < TNC; ++j) qb[e][j] = wb[(e * 4) * 48 + j * 16];
+                  };
+                  read_s(0, a4[0], bvv[0]);
+                  int slot = 0;
+                  for (int s0 = 0; s0 < nst; s0 += 2) {
+                      static_for<0, 2>([&](auto k_) {
+                          constexpr int k = decltype(k_)::value;
+                          if (s0 + k < nst) {
+                              slot = slot + 1 == NSTG ? 0 : slot + 1;
+                              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this stage's fragments are in registers
+                              __builtin_amdgcn_s_barrier();                              // ... its slot may be refilled; the next stage has landed
+                              if (s0 + k + 1 < nst) read_s(slot, a4[(k + 1) & 1], bvv[(k + 1) & 1]);
+                              __builtin_amdgcn_sched_barrier(0);
+                              static_for<0, 4>([&](auto e_) {
+                                  constexpr int e = decltype(e_)::value;
 #pragma unroll
-                            for (int j = 0; j < TNC; ++j) bvn[e][j] = b[e * 4 * 48 + j * 16];
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (bw) {
-                        static_for<0, 4>([&](auto e_) {
-                            constexpr int e = decltype(e_)::value;
+                                  for (int i = 0; i < TPP; ++i)
 #pragma unroll
-                            for (int i = 0; i < TMW; ++i)
-#pragma unroll
-                                for (int j = 0; j < TNC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][i][e], bvc[e][j], acc[i][j], 0, 0, 0);
-                        });
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int gn = gi + RING < kg ? gi + RING : kg - 1;
-#pragma unroll
-                        for (int i = 0; i < TMW; ++i) a[r][i] = bload16_sc1(rsI, lane * 16, (i * g.hgp + gn) * 1024);
-                        __builtin_amdgcn_sched_barrier(0);
-                        // stage gi + 2 must have landed (its DMA was issued NB - 3 groups ago); the A loads just issued stay in flight
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TMW + (NB - 3) * (TMW + 1)) : "memory");
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int j = 0; j < TNC; ++j) bvc[e][j] = bvn[e][j];
-                        nbuf = buf;
-                        buf = b1;
-                    }
-                });
-            }
+                                      for (int j = 0; j < TNC; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[k][i][e], bvv[k][e][j], acc[i][j], 0, 0, 0);
+                              });
+                              __builtin_amdgcn_sched_barrier(0);
+                          }
+                      });
+                  }
+              }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DL_STAMP(4);
@@ -525,18 +534,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // The tile loop below stays ROLLED (its body -- three Philox blocks, the two-tier keys, the lane reduction -- is ~1500
             // instructions; unrolled six times it leaves the instruction cache): the accumulators go through a lane-private LDS
             // slot (each lane reads back what it wrote: no barrier), beyond the W stages other waves may still be reading.
-            f32x4* const za = reinterpret_cast<f32x4*>(smem + ZA0) + wave * (TMW * TNC * 64) + lane;
-            if (bw || TPP != 1)              // (R <= 64: waves 4-7 are loader waves, they hold no accumulators and no slots)
+            // slot of (tile, column tile j): any wave can finish any tile -- at 257-384 rows the 4 TPP tiles are dealt over all EIGHT waves (the loader
+            // waves are idle here), at <= 64 rows waves 0-3 finish their own tile
+            f32x4* const zt = reinterpret_cast<f32x4*>(smem + ZA0) + lane;
+            if constexpr (TPP != 1) __syncthreads();             // every MFMA wave has read its last fragments, every DMA has landed: the ring is dead
+            if (bw)
 #pragma unroll
             for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int j = 0; j < TNC; ++j) za[(i * TNC + j) * 64] = acc[i][j];
+                for (int j = 0; j < TNC; ++j) zt[((wave * TMW + i) * TNC + j) * 64] = acc[i][j];
+            if constexpr (TPP != 1) __syncthreads();
+            constexpr int TSTEP = TPP == 1 ? 4 : 8;              // waves that finish tiles
 #pragma nounroll
-            for (int i = 0; i < (bw ? TMW : 0); ++i) {
+            for (int tile = wave; tile < (wave < TSTEP ? 4 * TPP : 0); tile += TSTEP) {
                 f32x4 ac[TNC];
 #pragma unroll
-                for (int j = 0; j < TNC; ++j) ac[j] = za[(i * TNC + j) * 64];
-                const int trow = (wave * TMW + i) * 16;                 // (uniform) first row of the tile: B is a multiple of 16, so the
+                for (int j = 0; j < TNC; ++j) ac[j] = zt[(tile * TNC + j) * 64];
+                const int trow = tile * 16;                             // (uniform) first row of the tile: B is a multiple of 16, so the
                 const int tq = __builtin_amdgcn_readfirstlane(trow / g.B);      // tile lies in ONE sample block
                 const int mrow = trow + lq * 4;
                 // noise ids of the row whose Philox blocks this lane draws (quad lane e4: row lq * 4 + e4), as sampler_rows_kernel
@@ -639,8 +653,9 @@ const DecLoopCfg kDecLoop[] = {{5, decode_loop_kernel<5>, "decloop(m320)"}, {6, 
 int decloop_lds_bytes(int tpp)
 {
     if (tpp == 1) return (kB1Base + kNSTG * kB1Stage) * 4 + 4 * kTNC * 64 * 16;      // phase A region | phase B stages | accumulator slots of waves 0-3 (one row tile x kTNC column tiles each)
-    const int nb = kNB, za0 = nb * 16 * 48 > 4096 ? nb * 16 * 48 : 4096;
-    const int a = (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4, b = za0 * 4 + 8 * 3 * kTNC * 64 * 16;      // phase A ring + gate tiles | phase B stages + accumulator slots
+    // 257-384 rows: phase A's chunk ring + gate tiles | phase B's stage ring (4 tpp image blocks + 16 x 48 weights per stage), which aliases it and
+    // later holds the epilogue's accumulator slots (4 tpp x kTNC KB: smaller than the ring)
+    const int a = (kNBUF * kCG * tpp * 256 + 4 * 16 * 20) * 4, b = kNSTG * (4 * tpp * 256 + 16 * 48) * 4;
     return a > b ? a : b;
 }
 std::once_flag g_dl_once;

@@ -37,7 +37,7 @@ struct Args {
     float* sink;
 };
 
-template <int NL, int DEPTH, bool DMA>
+template <int NL, int DEPTH, bool DMA, int AUX = 0>
 __global__ __launch_bounds__(64 * NL) void stream_kernel(const Args g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * NL) void stream_kernel(const Args g)
     auto issue = [&](int p, int s) __attribute__((always_inline)) {
         if constexpr (DMA) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass drops a kernel instantiation that names a builtin it does not know)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + (s * NL + wave) * 256), 16, offset(p), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + (s * NL + wave) * 256), 16, offset(p), 0, 0, AUX);
 #endif
         } else {
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ring[s]) : "v"(offset(p)), "s"(rs) : "memory");
@@ -136,6 +136,30 @@ void report4(const char* pattern, const Args& a0, size_t bytes_per_wg)
     const double per_cu = (double)a.pieces * 4 * NL * 256 / (us * 1e-6) / 1e9;
     printf("{\"pattern\": \"%s\", \"mode\": \"dma dword (256 B per instruction)\", \"loader_waves\": %d, \"depth_instr_per_wave\": %d, \"us\": %.1f, "
            "\"gb_s_per_cu\": %.1f, \"instr_per_us_per_wave\": %.2f}\n", pattern, NL, DEPTH, us, per_cu, (double)a.pieces * 4 / us);
+    fflush(stdout);
+}
+
+// the same DMA stream with sc1 loads (aux 16: the load form of a cross-XCD hand-off, what the persistent kernels read their state image with)
+template <int NL, int DEPTH>
+void report_sc1(const char* pattern, const Args& a0, size_t bytes_per_wg)
+{
+    Args a = a0;
+    a.pieces = (int)(bytes_per_wg / 1024 / NL);
+    const size_t lds = (size_t)DEPTH * NL * 1024;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel<NL, DEPTH, true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((stream_kernel<NL, DEPTH, true, 16>), dim3(256), dim3(64 * NL), lds, 0, a);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((stream_kernel<NL, DEPTH, true, 16>), dim3(256), dim3(64 * NL), lds, 0, a);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms / 20 * 1e3;
+    printf("{\"pattern\": \"%s\", \"mode\": \"dma sc1\", \"loader_waves\": %d, \"depth_kib_per_wave\": %d, \"us\": %.1f, \"gb_s_per_cu\": %.1f}\n", pattern, NL, DEPTH, us,
+           (double)a.pieces * NL * 1024 / (us * 1e-6) / 1e9);
     fflush(stdout);
 }
 
@@ -217,6 +241,10 @@ int main()
         report<4, 8, true>("cell M=64 operand PACKED: contiguous 384 KiB per unit group, 4 share", privc, 1, 384 * 1024);
         report<8, 8, true>("cell M=64 operand PACKED: contiguous 384 KiB per unit group, 4 share", privc, 1, 384 * 1024);
     }
+    report_sc1<1, 16>("one 1.5 MB buffer read by every WG, sc1 loads", shared, 1536 * 1024);
+    report_sc1<4, 16>("one 1.5 MB buffer read by every WG, sc1 loads", shared, 1536 * 1024);
+    report_sc1<8, 16>("one 1.5 MB buffer read by every WG, sc1 loads", shared, 1536 * 1024);
+    report<4, 16, true>("one 1.5 MB buffer read by every WG, plain loads (same run)", shared, 1, 1536 * 1024);
     report4<1, 16>("one 3 MiB buffer per XCD, strided 4-byte gather", xshared, 768 * 1024);
     report4<4, 16>("one 3 MiB buffer per XCD, strided 4-byte gather", xshared, 768 * 1024);
     report4<4, 32>("one 3 MiB buffer per XCD, strided 4-byte gather", xshared, 768 * 1024);
