@@ -378,3 +378,21 @@ def test_multitask_class_surface_constructor_and_tuples():
     assert op.inputs == [bl[1], bl[2], bl[3], r, b, bm[1], bm[2], bm[3]]
     with pytest.raises(ValueError, match="build_model_outputs"):
         s2.multitask_train_op(bl, r, b, 1e-3, lambda_loss=0.5)
+
+
+def test_profiler_keys_of_the_round6_kernel_names():
+    """tools/prof_keys.py maps rocprofv3 kernel names onto the launch profiler's (class : tile) keys that bench.py looks the stamped traffic / SQ
+    summaries up with: the LDS-DMA ring tiles carry a twelfth template argument (ring stages), the persistent decode loop files under class 2."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("prof_keys", os.path.join(root, "tools", "prof_keys.py"))
+    pk = importlib.util.module_from_spec(spec); spec.loader.exec_module(pk)
+    k = pk.prof_key
+    assert k("void s2vt::gemm_kernel<2, 2, 4, 4, 1, 0, true, 32, 4, false, false, 2>(s2vt::GemmArgs)") == "0:128x128(2x2)+4dma2"
+    assert k("void s2vt::gemm_kernel<2, 2, 3, 3, 1, 0, true, 32, 4, true, false, 2>(s2vt::GemmArgs)") == "4:nt96x96(2x2)+4dma2"
+    assert k("void s2vt::gemm_kernel<1, 4, 6, 1, 4, 3, true, 32, 4, false, false, 6>(s2vt::GemmArgs)") == "1:gw96x16u(1x4)+4dma6"
+    assert k("void s2vt::gemm_kernel<2, 2, 2, 3, 1, 2, true, 32, 0, false, false, 0>(s2vt::GemmArgs)") == "2:64x96(2x2)"
+    assert k("void s2vt::gemm_kernel<1, 4, 1, 1, 4, 3, true, 64, 0, false, true, 0>(s2vt::GemmArgs)") == "1:gw16x16u(1x4)k64[live]"
+    assert k("void s2vt::(anonymous namespace)::decode_loop_kernel<1>(s2vt::(anonymous namespace)::DecLoopArgs)") == "2:decloop(m64)"
+    assert k("void s2vt::(anonymous namespace)::decode_loop_kernel<6>(s2vt::(anonymous namespace)::DecLoopArgs)") == "2:decloop(m384)"
+    assert k("void s2vt::gemm_tn_dma_kernel<false, 16, 2>(s2vt::TnKArgs)") == "3:tn128x128(dma)"

@@ -47,6 +47,10 @@ def prof_key(kname):
     if m:
         ng, tmw, nc = [int(x) for x in m.groups()]
         return f"6:bchain{2 if nc == 2 else ''}(ng{ng},m{384 if nc == 2 else tmw * 64})"
+    m = re.search(r"decode_loop_kernel<(\d+)>", kname)
+    if m:                                                   # the persistent decode loop: the launch profiler files it under class 2 (vocabulary pick)
+        tpp = int(m.group(1))
+        return f"2:decloop(m{64 if tpp == 1 else tpp * 64})"
     m = re.search(r"attn_chain_kernel<(\d+)>", kname)
     if m:
         return f"9:attn_chain(ng{m.group(1)})"
