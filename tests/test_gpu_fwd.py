@@ -113,7 +113,7 @@ def test_vocab_pick_bitwise(gpu, oracle, M, H, V):
     vid = rng.integers(0, 500, M).astype(np.int32); sid = rng.integers(-1, 4, M).astype(np.int32)
     logits = oracle.xw_plus_b(o2, W, b)
     ref = oracle.pick_tokens(logits, vid, sid, 5, 2024)
-    for cfg in range(-1, 13):
+    for cfg in range(-1, 16):                          # every entry of fwd.hip kPick (7-14: LDS-DMA ring); 15 = out of range = auto
         tok, gl, _ = gpu.vocab_pick(_dev(o2), _dev(W), _dev(b), _dev(vid), _dev(sid), 5, 2024, want_logits=True, tile_cfg=cfg)
         assert np.array_equal(gl.cpu().numpy(), logits), cfg
         assert np.array_equal(tok.cpu().numpy(), ref), cfg
@@ -124,7 +124,7 @@ def test_vocab_pick_ties_lowest_index(gpu, oracle):
     o2 = np.zeros((M, H), np.float32); W = np.zeros((H, V), np.float32); b = np.zeros(V, np.float32)
     b[[40, 41, 200, 299]] = 3.0                        # exact ties across lanes, sub-tiles and tiles
     vid = np.zeros(M, np.int32); sid = -np.ones(M, np.int32)
-    for cfg in range(-1, 13):
+    for cfg in range(-1, 16):                          # every entry of fwd.hip kPick (7-14: LDS-DMA ring); 15 = out of range = auto
         tok, _, _ = gpu.vocab_pick(_dev(o2), _dev(W), _dev(b), _dev(vid), _dev(sid), 0, 1, tile_cfg=cfg)
         assert tok.cpu().numpy().tolist() == [40] * M
 
